@@ -1,0 +1,202 @@
+/*
+ * C ABI of libvtcnn_hip.so: the MI355X (gfx950) backend of the VTCNN hot path.
+ *
+ * The reference has no FFI layer: its boundary is the C++ header API (Layer / Tensor / Model /
+ * Trainer) consumed by main.cpp.  This header is the replacement boundary: every entry point
+ * names the reference function it replaces.  All functions return 0 on success, a positive
+ * hipError_t, or a negative VT_E* code; no C++ types, no torch types, plain pointers and sizes.
+ *
+ * Two levels:
+ *   1. launchers (vt_*_fwd / vt_*_bwd ...): one reference layer operation over a whole mini-batch
+ *      on caller-provided DEVICE buffers and a caller-provided stream.  They never allocate and
+ *      never synchronise.
+ *   2. model handle (vt_model_*): owns the parameter arena and the activation workspace and
+ *      chains the launchers into VTCNN::forward / backward / update_weights.
+ *
+ * Device tensor layouts ("token-major"): feature maps are [N, P, C] with P = H*W pixels and C
+ * channels innermost; token matrices are [N*L, D] row-major; parameters use the canonical arena
+ * of vtcnn_layout.h.  The only instantiation compiled today is the reference's own
+ * hyper-parameters (main.cpp:66-78): C1=8, C2=16, L=16, D=32, heads=2, P<=1024, K<=16;
+ * vt_model_create rejects anything else with VT_EUNSUPPORTED.
+ */
+#ifndef VTCNN_HIP_H
+#define VTCNN_HIP_H
+
+#include "vtcnn_layout.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VT_EINVAL (-1)
+#define VT_EUNSUPPORTED (-2)
+#define VT_ENOMEM (-3)
+#define VT_EIO (-4)
+#define VT_EFORMAT (-5)
+
+typedef void *vt_stream; /* hipStream_t */
+typedef struct vt_model vt_model;
+
+const char *vt_error_string(int code);
+int vt_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Level 2: model handle.
+ * ------------------------------------------------------------------------------------------- */
+
+/* VTCNN::VTCNN (model/vit_cnn.hpp:38-101).  Allocates the arena and a workspace for mini-batches
+ * of up to max_batch images on HIP device `device`.  If ext_arena / ext_grads are non-NULL they
+ * are device buffers of vt_layout.n_total / n_trainable floats supplied by the caller (e.g. so a
+ * collective library can all-reduce the gradient arena in place); otherwise the model allocates
+ * them.  Weights are NOT initialised: call vt_model_init_seed or vt_model_set_arena. */
+int vt_model_create(const vt_dims *dims, int max_batch, int device, float *ext_arena, float *ext_grads,
+                    vt_model **out);
+int vt_model_destroy(vt_model *m);
+int vt_model_layout(const vt_model *m, vt_layout *out);
+
+/* Weight initialisation in the reference's construction and draw order from mt19937(seed)
+ * (main.cpp:12; Tensor::kaiming_normal / rand_uniform, utils/tensor/tensor_cpu.hpp:69-106;
+ * order of construction model/vit_cnn.hpp:56-91).  Host-side, then uploaded. */
+int vt_model_init_seed(vt_model *m, unsigned seed);
+/* Host <-> device copies of the whole arena (n_total floats) / gradient arena (n_trainable). */
+int vt_model_set_arena(vt_model *m, const float *host);
+int vt_model_get_arena(vt_model *m, float *host);
+int vt_model_get_grads(vt_model *m, float *host);
+float *vt_model_arena_ptr(vt_model *m); /* device pointers */
+float *vt_model_grads_ptr(vt_model *m);
+
+/* VTCNN::save / VTCNN::load, byte-compatible v1 .bin layout (model/vit_cnn.hpp:276-546). */
+int vt_model_save(vt_model *m, const char *path);
+int vt_model_load(vt_model *m, const char *path);
+
+/* VTCNN::set_training (model/vit_cnn.hpp:262-269): only BatchNorm2D honours eval mode; the three
+ * BatchNorm1D layers always use batch statistics (layers/visual_transformer.hpp:221). */
+int vt_model_set_training(vt_model *m, int training);
+
+/* VTCNN::forward (model/vit_cnn.hpp:103-213).  d_images: device [n, Ci, H, W] fp32.
+ * d_probs: device [n, K] softmax output (may be NULL: the model's own buffer is used). */
+int vt_model_forward(vt_model *m, const float *d_images, int n, float *d_probs, vt_stream s);
+/* VTCNN::backward (model/vit_cnn.hpp:215-242) for the mini-batch of the last forward; d_labels:
+ * device int32 [n].  Leaves the summed gradients in the gradient arena (overwrites it). */
+int vt_model_backward(vt_model *m, const int *d_labels, vt_stream s);
+/* VTCNN::update_weights + SGD::update + zero_grad (model/vit_cnn.hpp:244-260,
+ * utils/optimizer.hpp:22-28):  g <- g * (1/divisor);  w <- w - g * lr  over the trainable region.
+ * The reference always passes divisor = Trainer::batch_size = 32 (utils/trainer.hpp:53). */
+int vt_model_sgd_step(vt_model *m, float lr, float divisor, vt_stream s);
+/* Tensor::compute_loss + argmax of the last forward (tensor_cpu.hpp:1137-1173, 1294-1307):
+ * d_loss_sum device float[1] = sum over samples of -log(p[label] + 1e-8); d_argmax device int32[n].
+ * Either may be NULL. */
+int vt_model_metrics(vt_model *m, const int *d_labels, float *d_loss_sum, int *d_argmax, vt_stream s);
+
+/* Test / tooling access to the workspace: copies the named intermediate of the last
+ * forward/backward to host.  Returns the number of floats, or a negative error. */
+long vt_model_read(vt_model *m, const char *name, float *host, long capacity);
+
+/* ---------------------------------------------------------------------------------------------
+ * Host-side data path (bit-exact integer / byte work; no GPU involved).
+ * ------------------------------------------------------------------------------------------- */
+
+/* loadImages2D / loadLabels (utils/load_dataset.hpp:20-85): big-endian IDX headers, pixel
+ * u8 / 255.0f, label u8 -> int.  Query sizes with out == NULL. */
+int vt_idx_read_images(const char *path, int max_images, float *out, int *n, int *rows, int *cols);
+int vt_idx_read_labels(const char *path, int max_labels, int *out, int *n);
+/* DataLoader shuffling (utils/load_dataset.hpp:112-127, 155-159): indices = iota(n), shuffled
+ * once by the constructor and once more by every reset(), all from one mt19937(seed) with
+ * libstdc++'s std::shuffle.  Writes the permutation after `resets` resets (0 = constructor only). */
+int vt_loader_indices(int n, unsigned seed, int resets, int *out);
+
+/* ---------------------------------------------------------------------------------------------
+ * Level 1: per-layer launchers.  All pointers are device pointers.
+ * ------------------------------------------------------------------------------------------- */
+
+/* Conv2DLayer::forward, 3x3 stride 1 pad 1 (layers/conv2d_layer.hpp:35-87) with the per-sample
+ * partial BatchNorm statistics fused in.  x [N,Ci,H,W]; w [C1,Ci,3,3]; b [C1];
+ * conv_out [N,P,C1]; part [N][2][C1] = (sum, centred second moment) per sample (may be NULL). */
+int vt_conv3x3_fwd(const float *x, const float *w, const float *b, float *conv_out, float *part, int N, int Ci,
+                   int H, int W, vt_stream s);
+/* Statistics step of BatchNorm2DLayer / BatchNormLayer1D::forward in training mode
+ * (layers/batch_normalization_layer.hpp:152-159, 274-283): combines per-block partials into
+ * stat[2][C] = (mean, 1/sqrt(var+eps)) and updates the running statistics. */
+int vt_bn_stats_finalize(const float *part, int nblocks, int C, long rows_per_block, long rows_total,
+                         float *running_mean, float *running_var, float *stat, vt_stream s);
+/* Eval-mode statistics (batch_normalization_layer.hpp:287-291): stat from the running buffers. */
+int vt_bn_stats_eval(const float *running_mean, const float *running_var, int C, float *stat, vt_stream s);
+/* BatchNorm2D apply + flatten/transpose (model/vit_cnn.hpp:127-134) + FilterTokenizer::forward
+ * (layers/tokenizer.hpp:22-48).  Writes tok_A [N,P,L], tokens [N*L,D] and per-sample partial
+ * statistics of the tokens for the transformer's first BatchNorm1D. */
+int vt_tokenizer_fwd(const float *conv_out, const float *bn_stat, const float *bn_gamma, const float *bn_beta,
+                     const float *w1, const float *b1, const float *w2, const float *b2, float *tok_A,
+                     float *tokens, float *part_n1, int N, int P, vt_stream s);
+/* TransformerLayer::forward up to the second BatchNorm's input (layers/transformer_layer.hpp:43-120);
+ * the attention branch contributes exactly 0 in the reference (Tensor::concat returns zeros,
+ * tensor_cpu.hpp:251).  rows = N*L.  Writes a, hdn (pre-ReLU), s2 = a + ffn(a) and the partial
+ * statistics of s2. */
+int vt_transformer_ffn_fwd(const float *tokens, const float *n1_stat, const float *n1_gamma, const float *n1_beta,
+                           const float *w1, const float *b1, const float *w2, const float *b2, float *a,
+                           float *hdn, float *s2, float *part_n2, long rows, vt_stream s);
+/* Second BatchNorm1D apply (transformer output o) + the token side of ProjectorLayer::forward
+ * (layers/projector_layer.hpp:72-88): k = o.Wk, v = o.Wv + bv and the folded score matrix
+ * Mq[c][l] = sum_d Wq[c][d] k[l][d] per sample.  pk [N][8*16 + 16*16 + 16*32] = (Mq, v, k). */
+int vt_projector_tokens_fwd(const float *s2, const float *n2_stat, const float *n2_gamma, const float *n2_beta,
+                            const float *wq, const float *wk, const float *wv, const float *bv, float *o,
+                            float *pk, int N, vt_stream s);
+/* Pixel side of ProjectorLayer::forward (projector_layer.hpp:65-104): attention over tokens,
+ * downsample residual.  Writes proj_a [N,P,L], z [N,P,C2] (BatchNorm1D input) and its partial stats. */
+int vt_projector_fwd(const float *conv_out, const float *bn_stat, const float *bn_gamma, const float *bn_beta,
+                     const float *pk, const float *wd, const float *bd, float *proj_a, float *z, float *part_pn,
+                     int N, int P, vt_stream s);
+/* Projector BatchNorm1D apply + ReLU (projector_layer.hpp:106-113), the [N,P,C2]->[N,C2,H,W]
+ * reinterpretation (model/vit_cnn.hpp:179), MaxPool2DLayer::forward (layers/pooling_layer.hpp:18-66),
+ * Flatten, fc DenseLayer::forward and SoftmaxLayer::forward (vit_cnn.hpp:185-203).
+ * pool_idx: uint8 [N,Q] window slot of the maximum. */
+int vt_head_fwd(const float *z, const float *pn_stat, const float *pn_gamma, const float *pn_beta, const float *wfc,
+                const float *bfc, float *pooled, unsigned char *pool_idx, float *logits, float *probs, int N,
+                int H, int K, vt_stream s);
+/* Tensor::argmax_batch + cross-entropy terms (tensor_cpu.hpp:1155-1173, 1294-1307). */
+int vt_metrics(const float *probs, const int *labels, int N, int K, float *loss_sum, int *argmax, vt_stream s);
+
+/* SoftmaxLayer::backward with targets (layers/softmax_layer.hpp:29), fc input delta
+ * (layers/dense_layer.hpp:98-99), MaxPool2DLayer::backward (pooling_layer.hpp:68-97), ReLU mask
+ * (layers/relu_layer.hpp:20-33) and the partial sums of the projector BatchNorm1D backward.
+ * Writes d_logits [N,K], du [N,P,C2] (masked delta) and part [N][2][C2] = (sum du, sum du*xhat). */
+int vt_head_bwd(const float *probs, const int *labels, const float *wfc, const unsigned char *pool_idx,
+                const float *z, const float *pn_stat, const float *pn_gamma, const float *pn_beta, float *d_logits,
+                float *du, float *part, int N, int H, int K, vt_stream s);
+/* fc DenseLayer::backward weight/bias gradients (dense_layer.hpp:92-96): gW = pooled^T . d_logits. */
+int vt_fc_wgrad(const float *pooled, const float *d_logits, float *gw, float *gb, float *scratch, int N, int Q, int K,
+                vt_stream s);
+/* BatchNorm backward reduction step (batch_normalization_layer.hpp:187-199, 316-326): from the
+ * partial sums produces grad gamma/beta and coef[2][C] = (scale, shift) such that
+ * delta_in = delta * scale + shift, including the reference's row-0 variance term. */
+int vt_bn_bwd_finalize(const float *part, int nblocks, int C, long rows_total, const float *gamma, const float *stat,
+                       const float *in_row0, float *ggamma, float *gbeta, float *coef, vt_stream s);
+/* ProjectorLayer::backward, pixel side (projector_layer.hpp:133-184, 204-213). */
+int vt_projector_bwd(const float *du, const float *pn_coef, const float *conv_out, const float *bn_stat,
+                     const float *bn_gamma, const float *bn_beta, const float *proj_a, const float *pk,
+                     const float *wq, const float *wd, float *pdx, float *dv, float *dk, float *gslab, int N,
+                     int P, vt_stream s);
+/* DenseLayer::backward over a row matrix (dense_layer.hpp:79-100): gW = X^T dY, gb = sum dY,
+ * dX = dY W^T (optionally accumulated into dX).  in,out <= 32. */
+int vt_dense_bwd_rows(const float *X, const float *W, const float *dY, float *gW, float *gb, float *dX,
+                      int accumulate_dx, float *scratch, long rows, int in, int out, int relu_x, vt_stream s);
+/* FilterTokenizer::backward2 (layers/tokenizer.hpp:50-107) + partial sums of BatchNorm2D backward. */
+int vt_tokenizer_bwd(const float *conv_out, const float *bn_stat, const float *bn_gamma, const float *bn_beta,
+                     const float *tok_A, const float *dT0, const float *w1, const float *pdx, float *dy,
+                     float *part, int N, int P, vt_stream s);
+/* BatchNorm2D backward apply + Conv2DLayer::backward weight/bias gradients
+ * (conv2d_layer.hpp:115-147); the conv input delta is never consumed and is not computed. */
+int vt_conv3x3_wgrad(const float *x, const float *dy, const float *bn_coef, float *gslab, int N, int Ci, int H, int W,
+                     vt_stream s);
+/* Column sums of a [rows][cols] slab into out[cols] (deterministic order). */
+int vt_reduce_rows(const float *slab, long rows, int cols, int ld, float *out, vt_stream s);
+/* update_weights + SGD::update (utils/optimizer.hpp:22-28) over n floats. */
+int vt_sgd_update(float *w, float *g, int n, float lr, float divisor, int zero_grad, vt_stream s);
+/* Textbook Adam over the arena.  NOT in the reference (utils/optimizer.hpp has SGD only):
+ * provided as an extension, parity unpinned. */
+int vt_adam_update(float *w, float *g, float *m1, float *m2, int n, float lr, float beta1, float beta2, float eps,
+                   int step, float divisor, vt_stream s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VTCNN_HIP_H */

@@ -1,0 +1,101 @@
+"""ctypes binding of libvtcnn_hip.so (C ABI: include/vtcnn_hip.h).  Fails loudly if missing."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvtcnn_hip.so")
+
+VT_NAME_LEN = 40
+VT_MAX_TENSORS = 96
+
+
+class VtDims(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("image_channels", "input_dim", "tokens", "token_channels",
+                                       "vt_channels", "heads", "num_classes")]
+
+
+class VtTensorInfo(C.Structure):
+    _fields_ = [("name", C.c_char * VT_NAME_LEN), ("offset", C.c_int), ("size", C.c_int), ("ndim", C.c_int),
+                ("shape", C.c_int * 4), ("kind", C.c_int)]
+
+
+class VtLayout(C.Structure):
+    _fields_ = [("n_tensors", C.c_int), ("n_trainable", C.c_int), ("n_total", C.c_int),
+                ("n_trainable_exact", C.c_int), ("t", VtTensorInfo * VT_MAX_TENSORS)]
+
+
+# name -> (restype, argtypes); every symbol declared in include/vtcnn_hip.h
+p, i, l, f, u = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_uint
+SIGNATURES = {
+    "vt_error_string": (C.c_char_p, [i]),
+    "vt_version": (i, []),
+    "vt_model_create": (i, [C.POINTER(VtDims), i, i, p, p, C.POINTER(p)]),
+    "vt_model_destroy": (i, [p]),
+    "vt_model_layout": (i, [p, C.POINTER(VtLayout)]),
+    "vt_model_init_seed": (i, [p, u]),
+    "vt_model_set_arena": (i, [p, p]),
+    "vt_model_get_arena": (i, [p, p]),
+    "vt_model_get_grads": (i, [p, p]),
+    "vt_model_arena_ptr": (p, [p]),
+    "vt_model_grads_ptr": (p, [p]),
+    "vt_model_save": (i, [p, C.c_char_p]),
+    "vt_model_load": (i, [p, C.c_char_p]),
+    "vt_model_set_training": (i, [p, i]),
+    "vt_model_forward": (i, [p, p, i, p, p]),
+    "vt_model_backward": (i, [p, p, p]),
+    "vt_model_sgd_step": (i, [p, f, f, p]),
+    "vt_model_metrics": (i, [p, p, p, p, p]),
+    "vt_model_read": (l, [p, C.c_char_p, p, l]),
+    "vt_idx_read_images": (i, [C.c_char_p, i, p, C.POINTER(i), C.POINTER(i), C.POINTER(i)]),
+    "vt_idx_read_labels": (i, [C.c_char_p, i, p, C.POINTER(i)]),
+    "vt_loader_indices": (i, [i, u, i, p]),
+    "vt_conv3x3_fwd": (i, [p, p, p, p, p, i, i, i, i, p]),
+    "vt_bn_stats_finalize": (i, [p, i, i, l, l, p, p, p, p]),
+    "vt_bn_stats_eval": (i, [p, p, i, p, p]),
+    "vt_tokenizer_fwd": (i, [p] * 11 + [i, i, p]),
+    "vt_transformer_ffn_fwd": (i, [p] * 12 + [l, p]),
+    "vt_projector_tokens_fwd": (i, [p] * 10 + [i, p]),
+    "vt_projector_fwd": (i, [p] * 10 + [i, i, p]),
+    "vt_head_fwd": (i, [p] * 10 + [i, i, i, p]),
+    "vt_metrics": (i, [p, p, i, i, p, p, p]),
+    "vt_head_bwd": (i, [p] * 11 + [i, i, i, p]),
+    "vt_fc_wgrad": (i, [p] * 5 + [i, i, i, p]),
+    "vt_bn_bwd_finalize": (i, [p, i, i, l, p, p, p, p, p, p, p]),
+    "vt_projector_bwd": (i, [p] * 14 + [i, i, p]),
+    "vt_dense_bwd_rows": (i, [p, p, p, p, p, p, i, p, l, i, i, i, p]),
+    "vt_tokenizer_bwd": (i, [p] * 10 + [i, i, p]),
+    "vt_conv3x3_wgrad": (i, [p, p, p, p, i, i, i, i, p]),
+    "vt_reduce_rows": (i, [p, l, i, i, p, p]),
+    "vt_sgd_update": (i, [p, p, i, f, f, i, p]),
+    "vt_adam_update": (i, [p, p, p, p, i, f, f, f, f, i, f, p]),
+    "vt_transformer_bwd": (i, [p] * 22 + [l, p]),
+    "vt_mha_bwd": (i, [p] * 8 + [i, i, p]),
+}
+del p, i, l, f, u
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "vit_amd: %s is missing. Build it with `make -C vit_amd/csrc` (hipcc, gfx950); "
+            "there is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        if os.environ.get("VT_DEV_PARTIAL") and not hasattr(lib, name):
+            continue
+        fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+class VtError(RuntimeError):
+    pass
+
+
+def check(code, what=""):
+    if code != 0:
+        raise VtError("%s failed: %s (code %d)" % (what or "libvtcnn_hip", lib.vt_error_string(code).decode(), code))

@@ -1,0 +1,130 @@
+// Shared device helpers for the gfx950 VTCNN kernels.  wave = 64 lanes everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+#include "../../include/vtcnn_hip.h"
+
+namespace vt {
+
+// The one compiled instantiation: the reference's hyper-parameters (main.cpp:66-78).
+constexpr int C1 = 8;    // conv / "in" channels = vt_channels / 2
+constexpr int C2 = 16;   // vt channels
+constexpr int L = 16;    // tokens
+constexpr int D = 32;    // token channels = attention dim
+constexpr int HEADS = 2;
+constexpr int HD = D / HEADS;
+constexpr int KMAX = 16; // classes supported by the fused head
+constexpr int TPB = 256; // threads per workgroup (4 waves)
+constexpr int NW = TPB / 64;
+constexpr int PPT = 4;   // pixels per thread: up to 1024 pixels per sample
+constexpr int RB = 64;   // token rows per workgroup in the row-matrix kernels
+constexpr int PK_STRIDE = C1 * L + L * C2 + L * D; // per-sample projector token block (Mq, v, k)
+constexpr float BN_EPS = 1e-5f;
+constexpr float BN_MOM = 0.1f;
+
+__device__ __forceinline__ float wave_sum(float x) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+  return x;
+}
+__device__ __forceinline__ float wave_max(float x) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x = fmaxf(x, __shfl_xor(x, o));
+  return x;
+}
+
+// Sum of NV per-thread values over the whole workgroup; every thread receives the totals.
+// red: LDS scratch of NW*NV floats.  Fixed summation order => bitwise reproducible.
+template <int NV>
+__device__ __forceinline__ void block_sum(float (&v)[NV], float *red) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = wave_sum(v[i]);
+  __syncthreads();
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) red[wave * NV + i] = v[i];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) s += red[w * NV + i];
+    v[i] = s;
+  }
+}
+
+template <int NV>
+__device__ __forceinline__ void block_max(float (&v)[NV], float *red) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = wave_max(v[i]);
+  __syncthreads();
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) red[wave * NV + i] = v[i];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    float s = red[i];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) s = fmaxf(s, red[w * NV + i]);
+    v[i] = s;
+  }
+}
+
+// Transposing butterfly reduction inside one wave: every lane contributes NV values (NV = 64*m);
+// afterwards lane l holds in v[0..m) the wave-wide sums of elements l*m .. l*m+m-1.
+// Costs NV-m shuffles instead of 6*NV.
+template <int NV>
+__device__ __forceinline__ void wave_xreduce(float (&v)[NV]) {
+  static_assert(NV % 64 == 0, "NV must be a multiple of the wave size");
+  const int lane = threadIdx.x & 63;
+  int n = NV / 2;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const bool up = (lane & off) != 0;
+#pragma unroll
+    for (int i = 0; i < n; ++i) {
+      const float keep = up ? v[n + i] : v[i];
+      const float send = up ? v[i] : v[n + i];
+      v[i] = keep + __shfl_xor(send, off);
+    }
+    n >>= 1;
+  }
+}
+
+// Workgroup version: out[NV] (LDS) receives the totals of NV per-thread values.
+// red: LDS scratch of NW*NV floats.  Ends with a barrier.
+template <int NV>
+__device__ __forceinline__ void block_xreduce(float (&v)[NV], float *red, float *out) {
+  constexpr int m = NV / 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  wave_xreduce<NV>(v);
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < m; ++k) red[wave * NV + lane * m + k] = v[k];
+  __syncthreads();
+  for (int i = threadIdx.x; i < NV; i += TPB) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) s += red[w * NV + i];
+    out[i] = s;
+  }
+  __syncthreads();
+}
+
+struct BnCoef {
+  float mean, inv, g, b;
+};
+
+}  // namespace vt
+
+#define VT_CHECK_LAUNCH()                      \
+  do {                                         \
+    hipError_t e__ = hipGetLastError();        \
+    if (e__ != hipSuccess) return (int)e__;    \
+  } while (0)

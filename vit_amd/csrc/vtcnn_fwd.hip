@@ -1,0 +1,679 @@
+// Forward kernels of the VTCNN hot path for gfx950 (MI355X).
+//
+// Structure: the forward pass is cut at the four mini-batch-wide BatchNorm statistics (after the
+// conv, before/inside the transformer FFN, after the projector).  Between two cuts all work is
+// per sample (one 256-thread workgroup per image: 784 pixels = 3.06 pixels per lane) or per
+// token row; per-sample operands that every lane needs (folded projector matrices, weights) are
+// read through wave-uniform addresses so they live in SGPRs, not in LDS.
+// HBM layout: feature maps [N,P,C] channel-innermost (one 32-byte / 64-byte record per pixel,
+// fully coalesced per wave), token matrices [N*L, D].
+#include "vtcnn_common.h"
+
+namespace vt {
+
+// ---------------------------------------------------------------------------------------------
+// Conv2DLayer::forward 3x3/s1/p1 (reference layers/conv2d_layer.hpp:35-87) + per-sample partial
+// statistics for BatchNorm2D (reference layers/batch_normalization_layer.hpp:274-276).
+// One workgroup per image; the zero-padded image tile is staged in LDS.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void k_conv_fwd(const float *__restrict__ X, const float *__restrict__ Wc,
+                                                  const float *__restrict__ bc, float *__restrict__ conv,
+                                                  float *__restrict__ part, int Ci, int H, int W) {
+  extern __shared__ float sm[];
+  const int P = H * W, TH = H + 2, TW = W + 2;
+  const int tile_n = Ci * TH * TW;
+  float *tile = sm;
+  float *red = sm + ((tile_n + 3) & ~3);
+  const int n = blockIdx.x, tid = threadIdx.x;
+  for (int i = tid; i < tile_n; i += TPB) {
+    const int ci = i / (TH * TW), r = i % (TH * TW), hh = r / TW - 1, ww = r % TW - 1;
+    float v = 0.f;
+    if (hh >= 0 && hh < H && ww >= 0 && ww < W) v = X[((size_t)(n * Ci + ci) * H + hh) * W + ww];
+    tile[i] = v;
+  }
+  __syncthreads();
+  float vals[PPT][C1];
+  float s[C1];
+#pragma unroll
+  for (int co = 0; co < C1; ++co) s[co] = 0.f;
+#pragma unroll
+  for (int it = 0; it < PPT; ++it) {
+    const int p = tid + it * TPB;
+    const bool ok = p < P;
+    const int h = ok ? p / W : 0, w = ok ? p % W : 0;
+    float acc[C1];
+#pragma unroll
+    for (int co = 0; co < C1; ++co) acc[co] = bc[co];
+    for (int ci = 0; ci < Ci; ++ci) {
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const float v = tile[(ci * TH + h + kh) * TW + w + kw];
+#pragma unroll
+          for (int co = 0; co < C1; ++co) acc[co] += v * Wc[((co * Ci + ci) * 3 + kh) * 3 + kw];
+        }
+    }
+#pragma unroll
+    for (int co = 0; co < C1; ++co) {
+      vals[it][co] = ok ? acc[co] : 0.f;
+      s[co] += vals[it][co];
+    }
+    if (ok) {
+      float4 *dst = reinterpret_cast<float4 *>(conv + ((size_t)n * P + p) * C1);
+      dst[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+      dst[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    }
+  }
+  if (part == nullptr) return;
+  block_sum<C1>(s, red);
+  float m2[C1];
+  const float invP = 1.0f / (float)P;
+#pragma unroll
+  for (int co = 0; co < C1; ++co) {
+    const float mu = s[co] * invP;
+    float q = 0.f;
+#pragma unroll
+    for (int it = 0; it < PPT; ++it) {
+      const float dlt = vals[it][co] - mu;
+      q += (tid + it * TPB < P) ? dlt * dlt : 0.f;
+    }
+    m2[co] = q;
+  }
+  block_sum<C1>(m2, red);
+  if (tid < C1) {
+    part[(size_t)n * 2 * C1 + tid] = s[tid];
+    part[(size_t)n * 2 * C1 + C1 + tid] = m2[tid];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// BatchNorm statistics finalisation (reference batch_normalization_layer.hpp:152-159, 274-283):
+// merges per-block (sum, centred M2) partials with Chan's formula in double precision, writes
+// stat = (mean, 1/sqrt(var+eps)) and updates running = 0.1*batch + 0.9*running (biased var).
+// One workgroup.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void k_bn_stats_finalize(const float *__restrict__ part, int nb, int C,
+                                                           long rows_per_block, long rows_total,
+                                                           float *__restrict__ run_mean, float *__restrict__ run_var,
+                                                           float *__restrict__ stat) {
+  __shared__ double sh[TPB];
+  __shared__ double smean[64];
+  const int tid = threadIdx.x;
+  const int c = tid % C, j = tid / C, ns = TPB / C;
+  double s = 0.0;
+  for (int b = j; b < nb; b += ns) s += (double)part[(size_t)b * 2 * C + c];
+  sh[tid] = s;
+  __syncthreads();
+  if (tid < C) {
+    double t = 0.0;
+    for (int k = 0; k < ns; ++k) t += sh[k * C + tid];
+    smean[tid] = t / (double)rows_total;
+  }
+  __syncthreads();
+  const double mu = smean[c];
+  double q = 0.0;
+  for (int b = j; b < nb; b += ns) {
+    const long cnt = (b == nb - 1) ? rows_total - (long)(nb - 1) * rows_per_block : rows_per_block;
+    const double mb = (double)part[(size_t)b * 2 * C + c] / (double)cnt;
+    q += (double)part[(size_t)b * 2 * C + C + c] + (double)cnt * (mb - mu) * (mb - mu);
+  }
+  __syncthreads();
+  sh[tid] = q;
+  __syncthreads();
+  if (tid < C) {
+    double t = 0.0;
+    for (int k = 0; k < ns; ++k) t += sh[k * C + tid];
+    const float mean = (float)smean[tid];
+    const float var = (float)(t / (double)rows_total);
+    stat[tid] = mean;
+    stat[C + tid] = 1.0f / sqrtf(var + BN_EPS);
+    run_mean[tid] = mean * BN_MOM + run_mean[tid] * (1 - BN_MOM);
+    run_var[tid] = var * BN_MOM + run_var[tid] * (1 - BN_MOM);
+  }
+}
+
+// Eval-mode statistics from the running buffers (batch_normalization_layer.hpp:287-291).
+__global__ void k_bn_stats_eval(const float *__restrict__ run_mean, const float *__restrict__ run_var, int C,
+                                float *__restrict__ stat) {
+  const int c = threadIdx.x;
+  if (c < C) {
+    stat[c] = run_mean[c];
+    stat[C + c] = 1.0f / sqrtf(run_var[c] + BN_EPS);
+  }
+}
+
+// BatchNorm2D apply for one pixel record (x_norm * gamma + beta, batch_normalization_layer.hpp:279,296).
+__device__ __forceinline__ void load_x(const float *__restrict__ conv, size_t rec, const float *__restrict__ st,
+                                       const float *__restrict__ g, const float *__restrict__ b, float (&x)[C1]) {
+  const float4 *src = reinterpret_cast<const float4 *>(conv + rec * C1);
+  const float4 a = src[0], c = src[1];
+  const float raw[C1] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+#pragma unroll
+  for (int ch = 0; ch < C1; ++ch) x[ch] = ((raw[ch] - st[ch]) * st[C1 + ch]) * g[ch] + b[ch];
+}
+
+// ---------------------------------------------------------------------------------------------
+// FilterTokenizer::forward (reference layers/tokenizer.hpp:22-48) fused with the BatchNorm2D apply
+// and the NCHW->[N,P,C] transpose (model/vit_cnn.hpp:127-134).  One workgroup per image.
+//   S = x.W1 + b1;  A = softmax over the P pixels per token;  T0 = A^T.x;  t = T0.W2 + b2
+// The softmax reductions over pixels are wave shuffles + one LDS hop; T0 (16x8 sums over 784
+// pixels) uses the transposing butterfly reduction.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void k_tokenizer_fwd(const float *__restrict__ conv, const float *__restrict__ st,
+                                                       const float *__restrict__ g, const float *__restrict__ b,
+                                                       const float *__restrict__ W1, const float *__restrict__ b1,
+                                                       const float *__restrict__ W2, const float *__restrict__ b2,
+                                                       float *__restrict__ tokA, float *__restrict__ tok,
+                                                       float *__restrict__ part_n1, int P) {
+  __shared__ float red[NW * 64];
+  __shared__ float sT0[L * C1];
+  __shared__ float st_[L * D];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  float x[PPT][C1], e[PPT][L];
+  float cm[L];
+#pragma unroll
+  for (int l = 0; l < L; ++l) cm[l] = -INFINITY;
+#pragma unroll
+  for (int it = 0; it < PPT; ++it) {
+    const int p = tid + it * TPB;
+    const bool ok = p < P;
+    if (ok) {
+      load_x(conv, (size_t)n * P + p, st, g, b, x[it]);
+    } else {
+#pragma unroll
+      for (int ch = 0; ch < C1; ++ch) x[it][ch] = 0.f;
+    }
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      float s = 0.f;
+#pragma unroll
+      for (int ch = 0; ch < C1; ++ch) s += x[it][ch] * W1[ch * L + l];
+      s += b1[l];
+      e[it][l] = s;
+      cm[l] = ok ? fmaxf(cm[l], s) : cm[l];
+    }
+  }
+  block_max<L>(cm, red);
+  float cs[L];
+#pragma unroll
+  for (int l = 0; l < L; ++l) cs[l] = 0.f;
+#pragma unroll
+  for (int it = 0; it < PPT; ++it) {
+    const bool ok = tid + it * TPB < P;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      const float v = ok ? expf(e[it][l] - cm[l]) : 0.f;
+      e[it][l] = v;
+      cs[l] += v;
+    }
+  }
+  block_sum<L>(cs, red);
+#pragma unroll
+  for (int it = 0; it < PPT; ++it) {
+    const int p = tid + it * TPB;
+#pragma unroll
+    for (int l = 0; l < L; ++l) e[it][l] = e[it][l] / cs[l];
+    if (p < P) {
+      float4 *dst = reinterpret_cast<float4 *>(tokA + ((size_t)n * P + p) * L);
+#pragma unroll
+      for (int q = 0; q < L / 4; ++q) dst[q] = make_float4(e[it][4 * q], e[it][4 * q + 1], e[it][4 * q + 2], e[it][4 * q + 3]);
+    }
+  }
+  // T0[l][c] = sum_p A[p][l] * x[p][c]  (a^T . x, tokenizer.hpp:39-40), two halves of 8 tokens
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    float acc[64];
+#pragma unroll
+    for (int lh = 0; lh < 8; ++lh)
+#pragma unroll
+      for (int ch = 0; ch < C1; ++ch) {
+        float s = 0.f;
+#pragma unroll
+        for (int it = 0; it < PPT; ++it) s += e[it][half * 8 + lh] * x[it][ch];
+        acc[lh * C1 + ch] = s;
+      }
+    block_xreduce<64>(acc, red, sT0 + half * 64);
+  }
+  // t = T0 . W2 + b2  (linear2, tokenizer.hpp:42-44)
+  for (int o = tid; o < L * D; o += TPB) {
+    const int l = o / D, d = o % D;
+    float s = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < C1; ++ch) s += sT0[l * C1 + ch] * W2[ch * D + d];
+    s += b2[d];
+    st_[o] = s;
+    tok[(size_t)n * L * D + o] = s;
+  }
+  __syncthreads();
+  if (tid < D && part_n1 != nullptr) {  // per-sample partial statistics for the transformer's norm1
+    float s = 0.f;
+#pragma unroll
+    for (int l = 0; l < L; ++l) s += st_[l * D + tid];
+    const float mu = s * (1.0f / L);
+    float q = 0.f;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      const float dlt = st_[l * D + tid] - mu;
+      q += dlt * dlt;
+    }
+    part_n1[(size_t)n * 2 * D + tid] = s;
+    part_n1[(size_t)n * 2 * D + D + tid] = q;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// TransformerLayer::forward (reference layers/transformer_layer.hpp:43-120) over the flat
+// [N*L, D] token matrix (Tensor::permute does not move data, tensor_cpu.hpp:719-747).
+// The attention branch is identically zero in the reference (Tensor::concat returns zeros,
+// tensor_cpu.hpp:251; no bias on the output projection), so residual = tokens.
+//   a = BN1(tok);  hdn = a.W1 + b1;  s2 = a + relu(hdn).W2 + b2   (+ partial stats of s2)
+// RB rows per workgroup; thread = (row, group of 8 columns); weights in LDS.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void k_tr_ffn_fwd(const float *__restrict__ tok, const float *__restrict__ st,
+                                                    const float *__restrict__ g, const float *__restrict__ b,
+                                                    const float *__restrict__ W1, const float *__restrict__ b1,
+                                                    const float *__restrict__ W2, const float *__restrict__ b2,
+                                                    float *__restrict__ a_out, float *__restrict__ hdn_out,
+                                                    float *__restrict__ s2_out, float *__restrict__ part_n2,
+                                                    long rows) {
+  __shared__ float sW1[D * D], sW2[D * D];
+  __shared__ float sa[RB][D + 1], sr[RB][D + 1];
+  const int tid = threadIdx.x, r = tid >> 2, cg = (tid & 3) * 8;
+  const long row = (long)blockIdx.x * RB + r;
+  const bool ok = row < rows;
+  for (int i = tid; i < D * D; i += TPB) {
+    sW1[i] = W1[i];
+    sW2[i] = W2[i];
+  }
+  float av[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = cg + j;
+    const float tv = ok ? tok[row * D + c] : 0.f;
+    av[j] = ((tv - st[c]) * st[D + c]) * g[c] + b[c];
+    sa[r][c] = av[j];
+    if (ok) a_out[row * D + c] = av[j];
+  }
+  __syncthreads();
+  float h[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) h[j] = 0.f;
+#pragma unroll 8
+  for (int i = 0; i < D; ++i) {
+    const float ai = sa[r][i];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) h[j] += ai * sW1[i * D + cg + j];
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    h[j] += b1[cg + j];
+    if (ok) hdn_out[row * D + cg + j] = h[j];
+    sr[r][cg + j] = h[j] > 0.f ? h[j] : 0.f;
+  }
+  __syncthreads();
+  float o[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = 0.f;
+#pragma unroll 8
+  for (int i = 0; i < D; ++i) {
+    const float ri = sr[r][i];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] += ri * sW2[i * D + cg + j];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float v = av[j] + (o[j] + b2[cg + j]);
+    if (ok) s2_out[row * D + cg + j] = v;
+    sa[r][cg + j] = v;
+  }
+  __syncthreads();
+  if (tid < D && part_n2 != nullptr) {
+    const long left = rows - (long)blockIdx.x * RB;
+    const int cnt = left < RB ? (int)left : RB;
+    float s = 0.f;
+    for (int rr = 0; rr < cnt; ++rr) s += sa[rr][tid];
+    const float mu = s / (float)cnt;
+    float q = 0.f;
+    for (int rr = 0; rr < cnt; ++rr) {
+      const float dlt = sa[rr][tid] - mu;
+      q += dlt * dlt;
+    }
+    part_n2[(size_t)blockIdx.x * 2 * D + tid] = s;
+    part_n2[(size_t)blockIdx.x * 2 * D + D + tid] = q;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Transformer output o = BN2(s2) and the token side of ProjectorLayer::forward
+// (reference layers/projector_layer.hpp:72-88): k = o.Wk, v = o.Wv + bv, plus the folded score
+// matrix Mq[c][l] = sum_d Wq[c][d] k[l][d], so that the per-pixel score x.Wq.k^T becomes x.Mq
+// (8 MACs per token instead of 8*32 + 32).  One workgroup per image, everything in LDS.
+// pk record per image: Mq[C1][L] | v[L][C2] | k[L][D].
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void k_proj_tokens_fwd(const float *__restrict__ s2, const float *__restrict__ st,
+                                                         const float *__restrict__ g, const float *__restrict__ b,
+                                                         const float *__restrict__ Wq, const float *__restrict__ Wk,
+                                                         const float *__restrict__ Wv, const float *__restrict__ bv,
+                                                         float *__restrict__ o_out, float *__restrict__ pk) {
+  __shared__ float so[L][D + 1], sk[L][D + 1];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  for (int i = tid; i < L * D; i += TPB) {
+    const int l = i / D, d = i % D;
+    const float v = ((s2[(size_t)n * L * D + i] - st[d]) * st[D + d]) * g[d] + b[d];
+    so[l][d] = v;
+    o_out[(size_t)n * L * D + i] = v;
+  }
+  __syncthreads();
+  float *rec = pk + (size_t)n * PK_STRIDE;
+  for (int i = tid; i < L * D; i += TPB) {
+    const int l = i / D, e = i % D;
+    float s = 0.f;
+#pragma unroll 8
+    for (int d = 0; d < D; ++d) s += so[l][d] * Wk[d * D + e];
+    sk[l][e] = s;
+    rec[C1 * L + L * C2 + i] = s;
+  }
+  for (int i = tid; i < L * C2; i += TPB) {
+    const int l = i / C2, c = i % C2;
+    float s = 0.f;
+#pragma unroll 8
+    for (int d = 0; d < D; ++d) s += so[l][d] * Wv[d * C2 + c];
+    rec[C1 * L + i] = s + bv[c];
+  }
+  __syncthreads();
+  for (int i = tid; i < C1 * L; i += TPB) {
+    const int c = i / L, l = i % L;
+    float s = 0.f;
+#pragma unroll 8
+    for (int d = 0; d < D; ++d) s += Wq[c * D + d] * sk[l][d];
+    rec[i] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pixel side of ProjectorLayer::forward (reference layers/projector_layer.hpp:65-104).
+//   a = softmax_L(x.Mq);  z = (x.Wd + bd) + a.v    (+ per-sample partial stats of z)
+// One workgroup per image; Mq, v, Wd, bd are wave-uniform operands.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void k_proj_fwd(const float *__restrict__ conv, const float *__restrict__ st,
+                                                  const float *__restrict__ g, const float *__restrict__ b,
+                                                  const float *__restrict__ pk, const float *__restrict__ Wd,
+                                                  const float *__restrict__ bd, float *__restrict__ projA,
+                                                  float *__restrict__ z, float *__restrict__ part_pn, int P) {
+  __shared__ float red[NW * C2];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const float *__restrict__ mq = pk + (size_t)n * PK_STRIDE;
+  const float *__restrict__ vv = mq + C1 * L;
+  float zv[PPT][C2];
+  float s[C2];
+#pragma unroll
+  for (int c = 0; c < C2; ++c) s[c] = 0.f;
+#pragma unroll
+  for (int it = 0; it < PPT; ++it) {
+    const int p = tid + it * TPB;
+    const bool ok = p < P;
+    float x[C1];
+    if (ok) {
+      load_x(conv, (size_t)n * P + p, st, g, b, x);
+    } else {
+#pragma unroll
+      for (int ch = 0; ch < C1; ++ch) x[ch] = 0.f;
+    }
+    float a[L];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      float sc = 0.f;
+#pragma unroll
+      for (int ch = 0; ch < C1; ++ch) sc += x[ch] * mq[ch * L + l];
+      a[l] = sc;
+      mx = fmaxf(mx, sc);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      a[l] = expf(a[l] - mx);
+      sum += a[l];
+    }
+#pragma unroll
+    for (int l = 0; l < L; ++l) a[l] = a[l] / sum;
+#pragma unroll
+    for (int c = 0; c < C2; ++c) {
+      float ds = 0.f;
+#pragma unroll
+      for (int ch = 0; ch < C1; ++ch) ds += x[ch] * Wd[ch * C2 + c];
+      ds += bd[c];
+      float av = 0.f;
+#pragma unroll
+      for (int l = 0; l < L; ++l) av += a[l] * vv[l * C2 + c];
+      zv[it][c] = ok ? ds + av : 0.f;
+      s[c] += zv[it][c];
+    }
+    if (ok) {
+      float4 *da = reinterpret_cast<float4 *>(projA + ((size_t)n * P + p) * L);
+      float4 *dz = reinterpret_cast<float4 *>(z + ((size_t)n * P + p) * C2);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        da[q] = make_float4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
+        dz[q] = make_float4(zv[it][4 * q], zv[it][4 * q + 1], zv[it][4 * q + 2], zv[it][4 * q + 3]);
+      }
+    }
+  }
+  if (part_pn == nullptr) return;
+  block_sum<C2>(s, red);
+  float m2[C2];
+  const float invP = 1.0f / (float)P;
+#pragma unroll
+  for (int c = 0; c < C2; ++c) {
+    const float mu = s[c] * invP;
+    float q = 0.f;
+#pragma unroll
+    for (int it = 0; it < PPT; ++it) {
+      const float dlt = zv[it][c] - mu;
+      q += (tid + it * TPB < P) ? dlt * dlt : 0.f;
+    }
+    m2[c] = q;
+  }
+  block_sum<C2>(m2, red);
+  if (tid < C2) {
+    part_pn[(size_t)n * 2 * C2 + tid] = s[tid];
+    part_pn[(size_t)n * 2 * C2 + C2 + tid] = m2[tid];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Head: projector BatchNorm1D apply + ReLU (projector_layer.hpp:106-113), reinterpretation of the
+// [P,C2] record block as [C2,H,W] (model/vit_cnn.hpp:179), MaxPool2DLayer::forward (first strictly
+// greater element wins, layers/pooling_layer.hpp:40-59), Flatten + fc + softmax
+// (vit_cnn.hpp:191-203, tensor_cpu.hpp:894-944).  One workgroup per image; the activated block
+// (P*C2 floats) is staged in LDS because pooling windows straddle pixel records.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void k_head_fwd(const float *__restrict__ z, const float *__restrict__ st,
+                                                  const float *__restrict__ g, const float *__restrict__ b,
+                                                  const float *__restrict__ Wfc, const float *__restrict__ bfc,
+                                                  float *__restrict__ pooled, unsigned char *__restrict__ pool_idx,
+                                                  float *__restrict__ logits, float *__restrict__ probs, int H,
+                                                  int K) {
+  extern __shared__ float su[];  // P*C2 activated values, then NW*KMAX reduction scratch
+  const int W = H, P = H * W, pk = H / 14, Q = C2 * 196;
+  float *red = su + P * C2;
+  const int n = blockIdx.x, tid = threadIdx.x;
+  for (int p = tid; p < P; p += TPB) {
+    const float4 *src = reinterpret_cast<const float4 *>(z + ((size_t)n * P + p) * C2);
+    float4 *dst = reinterpret_cast<float4 *>(su + p * C2);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 v = src[q];
+      const int c = 4 * q;
+      float4 o;
+      o.x = fmaxf(((v.x - st[c]) * st[C2 + c]) * g[c] + b[c], 0.f);
+      o.y = fmaxf(((v.y - st[c + 1]) * st[C2 + c + 1]) * g[c + 1] + b[c + 1], 0.f);
+      o.z = fmaxf(((v.z - st[c + 2]) * st[C2 + c + 2]) * g[c + 2] + b[c + 2], 0.f);
+      o.w = fmaxf(((v.w - st[c + 3]) * st[C2 + c + 3]) * g[c + 3] + b[c + 3], 0.f);
+      dst[q] = o;
+    }
+  }
+  __syncthreads();
+  float acc[KMAX];
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) acc[k] = 0.f;
+  for (int f = tid; f < Q; f += TPB) {
+    const int ch = f / 196, ij = f % 196, i = ij / 14, j = ij % 14;
+    const int base = ch * P + (i * pk) * W + j * pk;
+    float mv = -INFINITY;
+    int mi = 0;
+    for (int ki = 0; ki < pk; ++ki)
+      for (int kj = 0; kj < pk; ++kj) {
+        const float val = su[base + ki * W + kj];
+        if (val > mv) {
+          mv = val;
+          mi = ki * pk + kj;
+        }
+      }
+    pooled[(size_t)n * Q + f] = mv;
+    pool_idx[(size_t)n * Q + f] = (unsigned char)mi;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+      if (k < K) acc[k] += mv * Wfc[(size_t)f * K + k];
+  }
+  block_sum<KMAX>(acc, red);
+  if (tid == 0) {
+    float lg[KMAX], mx = -INFINITY, sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+      if (k < K) {
+        lg[k] = acc[k] + bfc[k];
+        mx = fmaxf(mx, lg[k]);
+      }
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+      if (k < K) {
+        logits[(size_t)n * K + k] = lg[k];
+        lg[k] = expf(lg[k] - mx);
+        sum += lg[k];
+      }
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+      if (k < K) probs[(size_t)n * K + k] = lg[k] / sum;
+  }
+}
+
+// Tensor::argmax_batch (first maximum, tensor_cpu.hpp:1294-1307) and the cross-entropy terms of
+// Tensor::compute_loss (tensor_cpu.hpp:1155-1173).  One workgroup; fixed order => reproducible.
+__global__ __launch_bounds__(TPB) void k_metrics(const float *__restrict__ probs, const int *__restrict__ labels, int N,
+                                                 int K, float *__restrict__ loss_sum, int *__restrict__ argmax) {
+  __shared__ float red[NW];
+  float part[1] = {0.f};
+  for (int n = threadIdx.x; n < N; n += TPB) {
+    int best = 0;
+    float bv = probs[(size_t)n * K];
+    for (int k = 1; k < K; ++k) {
+      const float v = probs[(size_t)n * K + k];
+      if (v > bv) {
+        bv = v;
+        best = k;
+      }
+    }
+    if (argmax) argmax[n] = best;
+    if (labels) part[0] += -logf(probs[(size_t)n * K + labels[n]] + 1e-8f);
+  }
+  block_sum<1>(part, red);
+  if (threadIdx.x == 0 && loss_sum) loss_sum[0] = part[0];
+}
+
+}  // namespace vt
+
+// ---------------------------------------------------------------------------------------------
+// extern "C" launchers
+// ---------------------------------------------------------------------------------------------
+using namespace vt;
+
+extern "C" int vt_conv3x3_fwd(const float *x, const float *w, const float *b, float *conv_out, float *part, int N, int Ci,
+                              int H, int W, vt_stream s) {
+  if (N < 1 || Ci < 1 || H * W > PPT * TPB || H < 1 || W < 1) return VT_EUNSUPPORTED;
+  const size_t lds = (size_t)(((Ci * (H + 2) * (W + 2) + 3) & ~3) + NW * C1) * sizeof(float);
+  if (lds > 64 * 1024) return VT_EUNSUPPORTED;
+  hipLaunchKernelGGL(k_conv_fwd, dim3(N), dim3(TPB), lds, (hipStream_t)s, x, w, b, conv_out, part, Ci, H, W);
+  VT_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int vt_bn_stats_finalize(const float *part, int nblocks, int C, long rows_per_block, long rows_total,
+                                    float *running_mean, float *running_var, float *stat, vt_stream s) {
+  if (C < 1 || C > 64 || TPB % C != 0 || nblocks < 1) return VT_EUNSUPPORTED;
+  if ((long)(nblocks - 1) * rows_per_block >= rows_total || (long)nblocks * rows_per_block < rows_total) return VT_EINVAL;
+  hipLaunchKernelGGL(k_bn_stats_finalize, dim3(1), dim3(TPB), 0, (hipStream_t)s, part, nblocks, C, rows_per_block,
+                     rows_total, running_mean, running_var, stat);
+  VT_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int vt_bn_stats_eval(const float *running_mean, const float *running_var, int C, float *stat, vt_stream s) {
+  if (C < 1 || C > 64) return VT_EUNSUPPORTED;
+  hipLaunchKernelGGL(k_bn_stats_eval, dim3(1), dim3(64), 0, (hipStream_t)s, running_mean, running_var, C, stat);
+  VT_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int vt_tokenizer_fwd(const float *conv_out, const float *bn_stat, const float *bn_gamma, const float *bn_beta,
+                                const float *w1, const float *b1, const float *w2, const float *b2, float *tok_A,
+                                float *tokens, float *part_n1, int N, int P, vt_stream s) {
+  if (N < 1 || P < 1 || P > PPT * TPB) return VT_EUNSUPPORTED;
+  hipLaunchKernelGGL(k_tokenizer_fwd, dim3(N), dim3(TPB), 0, (hipStream_t)s, conv_out, bn_stat, bn_gamma, bn_beta, w1,
+                     b1, w2, b2, tok_A, tokens, part_n1, P);
+  VT_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int vt_transformer_ffn_fwd(const float *tokens, const float *n1_stat, const float *n1_gamma,
+                                      const float *n1_beta, const float *w1, const float *b1, const float *w2,
+                                      const float *b2, float *a, float *hdn, float *s2, float *part_n2, long rows,
+                                      vt_stream s) {
+  if (rows < 1) return VT_EINVAL;
+  const int nb = (int)((rows + RB - 1) / RB);
+  hipLaunchKernelGGL(k_tr_ffn_fwd, dim3(nb), dim3(TPB), 0, (hipStream_t)s, tokens, n1_stat, n1_gamma, n1_beta, w1, b1,
+                     w2, b2, a, hdn, s2, part_n2, rows);
+  VT_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int vt_projector_tokens_fwd(const float *s2, const float *n2_stat, const float *n2_gamma,
+                                       const float *n2_beta, const float *wq, const float *wk, const float *wv,
+                                       const float *bv, float *o, float *pk, int N, vt_stream s) {
+  if (N < 1) return VT_EINVAL;
+  hipLaunchKernelGGL(k_proj_tokens_fwd, dim3(N), dim3(TPB), 0, (hipStream_t)s, s2, n2_stat, n2_gamma, n2_beta, wq, wk,
+                     wv, bv, o, pk);
+  VT_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int vt_projector_fwd(const float *conv_out, const float *bn_stat, const float *bn_gamma, const float *bn_beta,
+                                const float *pk, const float *wd, const float *bd, float *proj_a, float *z,
+                                float *part_pn, int N, int P, vt_stream s) {
+  if (N < 1 || P < 1 || P > PPT * TPB) return VT_EUNSUPPORTED;
+  hipLaunchKernelGGL(k_proj_fwd, dim3(N), dim3(TPB), 0, (hipStream_t)s, conv_out, bn_stat, bn_gamma, bn_beta, pk, wd,
+                     bd, proj_a, z, part_pn, P);
+  VT_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int vt_head_fwd(const float *z, const float *pn_stat, const float *pn_gamma, const float *pn_beta,
+                           const float *wfc, const float *bfc, float *pooled, unsigned char *pool_idx, float *logits,
+                           float *probs, int N, int H, int K, vt_stream s) {
+  if (N < 1 || H < 14 || H % 14 != 0 || H * H > PPT * TPB || K < 1 || K > KMAX) return VT_EUNSUPPORTED;
+  const size_t lds = (size_t)(H * H * C2 + NW * KMAX) * sizeof(float);
+  hipLaunchKernelGGL(k_head_fwd, dim3(N), dim3(TPB), lds, (hipStream_t)s, z, pn_stat, pn_gamma, pn_beta, wfc, bfc,
+                     pooled, pool_idx, logits, probs, H, K);
+  VT_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int vt_metrics(const float *probs, const int *labels, int N, int K, float *loss_sum, int *argmax,
+                          vt_stream s) {
+  if (N < 1 || K < 1) return VT_EINVAL;
+  hipLaunchKernelGGL(k_metrics, dim3(1), dim3(TPB), 0, (hipStream_t)s, probs, labels, N, K, loss_sum, argmax);
+  VT_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,469 @@
+// Model handle: owns the parameter arena and the activation workspace, and chains the per-layer
+// launchers into VTCNN::forward / backward / update_weights (reference model/vit_cnn.hpp).
+// Host-side bit-exact pieces live here too: weight initialisation, .bin checkpoints, IDX files,
+// loader shuffling.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <numeric>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "vtcnn_common.h"
+
+using namespace vt;
+
+#define HIPCHK(x)                          \
+  do {                                     \
+    hipError_t e__ = (x);                  \
+    if (e__ != hipSuccess) return (int)e__; \
+  } while (0)
+#define VTCHK(x)            \
+  do {                      \
+    int r__ = (x);          \
+    if (r__ != 0) return r__; \
+  } while (0)
+
+struct vt_model {
+  vt_dims d;
+  vt_layout lo;
+  int maxN = 0, device = 0, lastN = 0, training = 1;
+  int P = 0, Q = 0, K = 0;
+  bool own_arena = false, own_grads = false;
+  float *arena = nullptr, *grads = nullptr;
+  std::vector<void *> allocs;
+  std::map<std::string, std::pair<float *, long>> named;  // name -> (device ptr, floats per sample or total)
+  // forward workspace
+  float *conv, *tokA, *tok, *a, *hdn, *s2, *o, *pk, *projA, *z, *pooled, *logits, *probs;
+  unsigned char *pool_idx;
+  float *part, *stat_bn, *stat_n1, *stat_n2, *stat_pn;
+  const float *last_images = nullptr;
+  // backward workspace
+  float *dlogits, *du, *pdx, *pdt, *dv, *dk, *d0, *ds2, *dh, *da, *dr, *dc, *dT0, *dy, *qkv, *gslab, *rowscratch;
+  float *coef_pn, *coef_n2, *coef_n1, *coef_bn;
+  float *loss_buf;
+
+  float *P_(const char *name) { return arena + lo.t[vt_find(&lo, name)].offset; }
+  float *G_(const char *name) { return grads + lo.t[vt_find(&lo, name)].offset; }
+};
+
+extern "C" const char *vt_error_string(int code) {
+  switch (code) {
+    case 0: return "ok";
+    case VT_EINVAL: return "invalid argument";
+    case VT_EUNSUPPORTED: return "configuration not supported by the compiled gfx950 kernels";
+    case VT_ENOMEM: return "out of memory";
+    case VT_EIO: return "file i/o error";
+    case VT_EFORMAT: return "checkpoint / file format mismatch";
+    default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
+  }
+}
+extern "C" int vt_version(void) { return 1; }
+
+static int dalloc(vt_model *m, float **p, size_t floats, const char *name = nullptr) {
+  void *q = nullptr;
+  if (hipMalloc(&q, std::max<size_t>(floats, 4) * sizeof(float)) != hipSuccess) return VT_ENOMEM;
+  m->allocs.push_back(q);
+  *p = (float *)q;
+  if (name) m->named[name] = {*p, (long)floats};
+  return 0;
+}
+
+extern "C" int vt_model_create(const vt_dims *dims, int max_batch, int device, float *ext_arena, float *ext_grads,
+                               vt_model **out) {
+  if (!dims || !out || max_batch < 1) return VT_EINVAL;
+  vt_layout lo;
+  if (vt_make_layout(dims, &lo) != 0) return VT_EINVAL;
+  if (dims->vt_channels != C2 || dims->tokens != L || dims->token_channels != D || dims->heads != HEADS ||
+      dims->input_dim * dims->input_dim > PPT * TPB || dims->num_classes > KMAX || dims->image_channels > 4)
+    return VT_EUNSUPPORTED;
+  HIPCHK(hipSetDevice(device));
+  vt_model *m = new vt_model();
+  m->d = *dims;
+  m->lo = lo;
+  m->maxN = max_batch;
+  m->device = device;
+  m->P = dims->input_dim * dims->input_dim;
+  m->Q = C2 * 196;
+  m->K = dims->num_classes;
+  const size_t N = max_batch, P = m->P, NL = N * L, Q = m->Q, K = m->K;
+  int rc = 0;
+  if (ext_arena) m->arena = ext_arena; else { rc |= dalloc(m, &m->arena, lo.n_total); m->own_arena = true; }
+  if (ext_grads) m->grads = ext_grads; else { rc |= dalloc(m, &m->grads, lo.n_trainable); m->own_grads = true; }
+  rc |= dalloc(m, &m->conv, N * P * C1, "fwd.conv_out");
+  rc |= dalloc(m, &m->tokA, N * P * L, "fwd.tok_A");
+  rc |= dalloc(m, &m->tok, NL * D, "fwd.tok_out");
+  rc |= dalloc(m, &m->a, NL * D, "fwd.tr_a");
+  rc |= dalloc(m, &m->hdn, NL * D, "fwd.tr_hdn");
+  rc |= dalloc(m, &m->s2, NL * D, "fwd.tr_s2");
+  rc |= dalloc(m, &m->o, NL * D, "fwd.tr_out");
+  rc |= dalloc(m, &m->pk, N * PK_STRIDE, "fwd.proj_pk");
+  rc |= dalloc(m, &m->projA, N * P * L, "fwd.proj_a");
+  rc |= dalloc(m, &m->z, N * P * C2, "fwd.proj_z");
+  rc |= dalloc(m, &m->pooled, N * Q, "fwd.pooled");
+  rc |= dalloc(m, &m->logits, N * K, "fwd.logits");
+  rc |= dalloc(m, &m->probs, N * K, "fwd.preds");
+  float *pi = nullptr;
+  rc |= dalloc(m, &pi, (N * Q + 3) / 4);
+  m->pool_idx = (unsigned char *)pi;
+  const size_t nrb = (NL + RB - 1) / RB;
+  rc |= dalloc(m, &m->part, std::max(N, nrb) * 64);
+  rc |= dalloc(m, &m->stat_bn, 2 * C1, "stat.bn");
+  rc |= dalloc(m, &m->stat_n1, 2 * D, "stat.norm1");
+  rc |= dalloc(m, &m->stat_n2, 2 * D, "stat.norm2");
+  rc |= dalloc(m, &m->stat_pn, 2 * C2, "stat.proj.norm");
+  rc |= dalloc(m, &m->dlogits, N * K, "bwd.d_logits");
+  rc |= dalloc(m, &m->du, N * P * C2, "bwd.du");
+  rc |= dalloc(m, &m->pdx, N * P * C1, "bwd.proj_dx");
+  rc |= dalloc(m, &m->pdt, NL * D, "bwd.proj_dt");
+  rc |= dalloc(m, &m->dv, NL * C2, "bwd.proj_dv");
+  rc |= dalloc(m, &m->dk, NL * D, "bwd.proj_dk");
+  rc |= dalloc(m, &m->d0, NL * D, "bwd.tr_d0");
+  rc |= dalloc(m, &m->ds2, NL * D, "bwd.tr_ds2");
+  rc |= dalloc(m, &m->dh, NL * D, "bwd.tr_dh");
+  rc |= dalloc(m, &m->da, NL * D, "bwd.tr_da");
+  rc |= dalloc(m, &m->dr, NL * D, "bwd.tr_dr");
+  rc |= dalloc(m, &m->dc, NL * D, "bwd.tr_dc");
+  rc |= dalloc(m, &m->dT0, NL * C1, "bwd.tok_dT0");
+  rc |= dalloc(m, &m->dy, N * P * C1, "bwd.tok_dx");
+  rc |= dalloc(m, &m->qkv, 3 * NL * D, "bwd.mha_qkv");
+  rc |= dalloc(m, &m->gslab, N * 512, "bwd.gslab");
+  rc |= dalloc(m, &m->rowscratch, std::max<size_t>(nrb, 64) * 2048 + Q * KMAX * 64);
+  rc |= dalloc(m, &m->coef_pn, 2 * C2, "coef.proj.norm");
+  rc |= dalloc(m, &m->coef_n2, 2 * D, "coef.norm2");
+  rc |= dalloc(m, &m->coef_n1, 2 * D, "coef.norm1");
+  rc |= dalloc(m, &m->coef_bn, 2 * C1, "coef.bn");
+  rc |= dalloc(m, &m->loss_buf, 4);
+  if (rc != 0) {
+    vt_model_destroy(m);
+    return VT_ENOMEM;
+  }
+  (void)hipMemset(m->arena, 0, lo.n_total * sizeof(float));
+  (void)hipMemset(m->grads, 0, lo.n_trainable * sizeof(float));
+  *out = m;
+  return 0;
+}
+
+extern "C" int vt_model_destroy(vt_model *m) {
+  if (!m) return 0;
+  (void)hipSetDevice(m->device);
+  (void)hipDeviceSynchronize();
+  for (void *p : m->allocs) (void)hipFree(p);
+  delete m;
+  return 0;
+}
+
+extern "C" int vt_model_layout(const vt_model *m, vt_layout *out) {
+  if (!m || !out) return VT_EINVAL;
+  *out = m->lo;
+  return 0;
+}
+
+extern "C" float *vt_model_arena_ptr(vt_model *m) { return m ? m->arena : nullptr; }
+extern "C" float *vt_model_grads_ptr(vt_model *m) { return m ? m->grads : nullptr; }
+
+extern "C" int vt_model_set_arena(vt_model *m, const float *host) {
+  if (!m || !host) return VT_EINVAL;
+  HIPCHK(hipSetDevice(m->device));
+  HIPCHK(hipMemcpy(m->arena, host, m->lo.n_total * sizeof(float), hipMemcpyHostToDevice));
+  return 0;
+}
+extern "C" int vt_model_get_arena(vt_model *m, float *host) {
+  if (!m || !host) return VT_EINVAL;
+  HIPCHK(hipSetDevice(m->device));
+  HIPCHK(hipMemcpy(host, m->arena, m->lo.n_total * sizeof(float), hipMemcpyDeviceToHost));
+  return 0;
+}
+extern "C" int vt_model_get_grads(vt_model *m, float *host) {
+  if (!m || !host) return VT_EINVAL;
+  HIPCHK(hipSetDevice(m->device));
+  HIPCHK(hipMemcpy(host, m->grads, m->lo.n_trainable * sizeof(float), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Weight initialisation: same generator, same distributions, same draw order as the reference.
+//   conv: Tensor::kaiming_normal, sigma = sqrt(2/fan_in)       (conv2d_layer.hpp:27-29, tensor_cpu.hpp:98-106)
+//   Dense: Tensor::rand_uniform(+-sqrt(6/(in+out)))            (dense_layer.hpp:22-23, tensor_cpu.hpp:69-76)
+// Construction order: conv; tokenizer linear1, linear2 (tokenizer.hpp:18-19); per head q,k,v then
+// the output projection (multi_head_attention.hpp:33-46); ffn linear1, linear2
+// (transformer_layer.hpp:21-23); projector linear1..3, downsample (projector_layer.hpp:23-34);
+// fc (vit_cnn.hpp:91).  BatchNorm: gamma 1, beta 0, running mean 0, running var 1.
+// Uses libstdc++'s std::normal_distribution / std::uniform_real_distribution<float>, the same
+// library code the reference is built against.
+// ---------------------------------------------------------------------------------------------
+static void init_arena_host(const vt_layout &lo, const vt_dims &d, unsigned seed, std::vector<float> &h) {
+  h.assign(lo.n_total, 0.f);
+  std::mt19937 gen(seed);
+  auto T = [&](const std::string &n) { return h.data() + lo.t[vt_find(&lo, n.c_str())].offset; };
+  auto SZ = [&](const std::string &n) { return lo.t[vt_find(&lo, n.c_str())].size; };
+  auto dense = [&](const std::string &n, int in, int out) {
+    const float limit = std::sqrt(6.0f / (in + out));
+    std::uniform_real_distribution<float> dist(-limit, limit);
+    float *p = T(n);
+    for (int i = 0; i < in * out; ++i) p[i] = dist(gen);
+  };
+  auto fill = [&](const std::string &n, float v) { std::fill(T(n), T(n) + SZ(n), v); };
+  const int Ci = d.image_channels, c1 = d.vt_channels / 2, c2 = d.vt_channels, l = d.tokens, dd = d.token_channels;
+  const int hd = dd / d.heads;
+  {
+    const int fan_in = Ci * 3 * 3;
+    const float scale = std::sqrt(2.0f / fan_in);
+    std::normal_distribution<float> dist(0.0f, scale);
+    float *p = T("conv.W");
+    for (int i = 0; i < c1 * Ci * 9; ++i) p[i] = dist(gen);
+  }
+  dense("tok.linear1.W", c1, l);
+  dense("tok.linear2.W", c1, dd);
+  for (int i = 0; i < d.heads; ++i) {
+    const std::string s = std::to_string(i);
+    dense("mha.q" + s + ".W", dd, hd);
+    dense("mha.k" + s + ".W", dd, hd);
+    dense("mha.v" + s + ".W", dd, hd);
+  }
+  dense("mha.o.W", dd, dd);
+  dense("ffn.linear1.W", dd, dd);
+  dense("ffn.linear2.W", dd, dd);
+  dense("proj.linear1.W", c1, dd);
+  dense("proj.linear2.W", dd, dd);
+  dense("proj.linear3.W", dd, c2);
+  dense("proj.downsample.W", c1, c2);
+  dense("fc.W", c2 * 14 * 14, d.num_classes);
+  for (const char *n : {"bn.gamma", "norm1.gamma", "norm2.gamma", "proj.norm.gamma", "bn.running_var",
+                        "norm1.running_var", "norm2.running_var", "proj.norm.running_var"})
+    fill(n, 1.0f);
+}
+
+extern "C" int vt_model_init_seed(vt_model *m, unsigned seed) {
+  if (!m) return VT_EINVAL;
+  std::vector<float> h;
+  init_arena_host(m->lo, m->d, seed, h);
+  return vt_model_set_arena(m, h.data());
+}
+
+// ---------------------------------------------------------------------------------------------
+// .bin checkpoint v1 (reference model/vit_cnn.hpp:276-546, batch_normalization_layer.hpp:384-505,
+// visual_transformer.hpp:244-270): little-endian;
+//   i32 4
+//   i32 5 "Layer"             W[C1,Ci,3,3] b[C1]          (Conv2DLayer has no get_type override)
+//   i32 11 "BatchNorm2D"      gamma beta running_mean running_var
+//   i32 17 "VisualTransformer" i32 12, tokenizer (4 tensors) + projector (8 tensors)
+//   i32 5 "Dense"             fc.W fc.b
+// tensor record = i32 ndim, i32 dims[ndim], i32 count, f32 data[count].
+// The transformer block and the BatchNorm1D running statistics are not part of the file.
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct CkEntry {
+  const char *type;
+  int count_field;  // write the "number of tensors" field (VisualTransformer only)
+  std::vector<const char *> tensors;
+};
+const std::vector<CkEntry> &ck_entries() {
+  static const std::vector<CkEntry> e = {
+      {"Layer", 0, {"conv.W", "conv.b"}},
+      {"BatchNorm2D", 0, {"bn.gamma", "bn.beta", "bn.running_mean", "bn.running_var"}},
+      {"VisualTransformer", 1,
+       {"tok.linear1.W", "tok.linear1.b", "tok.linear2.W", "tok.linear2.b", "proj.linear1.W", "proj.linear2.W",
+        "proj.linear3.W", "proj.linear3.b", "proj.norm.gamma", "proj.norm.beta", "proj.downsample.W",
+        "proj.downsample.b"}},
+      {"Dense", 0, {"fc.W", "fc.b"}},
+  };
+  return e;
+}
+}  // namespace
+
+extern "C" int vt_model_save(vt_model *m, const char *path) {
+  if (!m || !path) return VT_EINVAL;
+  std::vector<float> h(m->lo.n_total);
+  VTCHK(vt_model_get_arena(m, h.data()));
+  FILE *f = std::fopen(path, "wb");
+  if (!f) return VT_EIO;
+  auto wi = [&](int v) { std::fwrite(&v, 4, 1, f); };
+  wi(4);
+  for (const CkEntry &e : ck_entries()) {
+    const int len = (int)std::strlen(e.type);
+    wi(len);
+    std::fwrite(e.type, 1, len, f);
+    if (e.count_field) wi((int)e.tensors.size());
+    for (const char *tn : e.tensors) {
+      const vt_tensor_info &ti = m->lo.t[vt_find(&m->lo, tn)];
+      wi(ti.ndim);
+      for (int k = 0; k < ti.ndim; ++k) wi(ti.shape[k]);
+      wi(ti.size);
+      std::fwrite(h.data() + ti.offset, 4, ti.size, f);
+    }
+  }
+  const bool ok = std::ferror(f) == 0;
+  std::fclose(f);
+  return ok ? 0 : VT_EIO;
+}
+
+extern "C" int vt_model_load(vt_model *m, const char *path) {
+  if (!m || !path) return VT_EINVAL;
+  FILE *f = std::fopen(path, "rb");
+  if (!f) return VT_EIO;
+  std::vector<float> h(m->lo.n_total);
+  int rc = vt_model_get_arena(m, h.data());
+  auto ri = [&](int *v) { return std::fread(v, 4, 1, f) == 1; };
+  int v = 0;
+  if (rc == 0 && (!ri(&v) || v != 4)) rc = VT_EFORMAT;  // "Cantidad de capas no coincide" (vit_cnn.hpp:405)
+  for (const CkEntry &e : ck_entries()) {
+    if (rc != 0) break;
+    int len = 0;
+    char buf[64] = {0};
+    if (!ri(&len) || len < 0 || len > 63 || std::fread(buf, 1, len, f) != (size_t)len || std::strcmp(buf, e.type) != 0) {
+      rc = VT_EFORMAT;
+      break;
+    }
+    if (e.count_field && (!ri(&v) || v != (int)e.tensors.size())) {
+      rc = VT_EFORMAT;
+      break;
+    }
+    for (const char *tn : e.tensors) {
+      const vt_tensor_info &ti = m->lo.t[vt_find(&m->lo, tn)];
+      int nd = 0, cnt = 0, dim = 0;
+      if (!ri(&nd) || nd != ti.ndim) { rc = VT_EFORMAT; break; }
+      for (int k = 0; k < nd && rc == 0; ++k)
+        if (!ri(&dim) || dim != ti.shape[k]) rc = VT_EFORMAT;  // shape mismatch (vit_cnn.hpp:444)
+      if (rc != 0) break;
+      if (!ri(&cnt) || cnt != ti.size || std::fread(h.data() + ti.offset, 4, cnt, f) != (size_t)cnt) { rc = VT_EFORMAT; break; }
+    }
+  }
+  std::fclose(f);
+  if (rc != 0) return rc;
+  return vt_model_set_arena(m, h.data());
+}
+
+// ---------------------------------------------------------------------------------------------
+// IDX reader and loader shuffling (reference utils/load_dataset.hpp).
+// ---------------------------------------------------------------------------------------------
+static bool read_be32(FILE *f, int *v) {
+  unsigned char b[4];
+  if (std::fread(b, 1, 4, f) != 4) return false;
+  *v = (int)((unsigned)b[0] << 24 | (unsigned)b[1] << 16 | (unsigned)b[2] << 8 | (unsigned)b[3]);
+  return true;
+}
+
+extern "C" int vt_idx_read_images(const char *path, int max_images, float *out, int *n, int *rows, int *cols) {
+  FILE *f = std::fopen(path, "rb");
+  if (!f) return VT_EIO;  // "No se pudo abrir el archivo de imágenes" (load_dataset.hpp:24)
+  int magic, num, r, c;
+  if (!read_be32(f, &magic) || !read_be32(f, &num) || !read_be32(f, &r) || !read_be32(f, &c)) {
+    std::fclose(f);
+    return VT_EFORMAT;
+  }
+  if (max_images > 0 && max_images < num) num = max_images;  // load_dataset.hpp:37-38
+  if (n) *n = num;
+  if (rows) *rows = r;
+  if (cols) *cols = c;
+  int rc = 0;
+  if (out) {
+    const size_t total = (size_t)num * r * c;
+    std::vector<unsigned char> raw(total);
+    const size_t got = std::fread(raw.data(), 1, total, f);
+    // a short file leaves the remaining pixels at 0, as the reference's failed reads do (:48-50)
+    for (size_t i = 0; i < total; ++i) out[i] = static_cast<float>(i < got ? raw[i] : 0) / 255.0f;
+  }
+  std::fclose(f);
+  return rc;
+}
+
+extern "C" int vt_idx_read_labels(const char *path, int max_labels, int *out, int *n) {
+  FILE *f = std::fopen(path, "rb");
+  if (!f) return VT_EIO;
+  int magic, num;
+  if (!read_be32(f, &magic) || !read_be32(f, &num)) {
+    std::fclose(f);
+    return VT_EFORMAT;
+  }
+  if (max_labels > 0 && max_labels < num) num = max_labels;
+  if (n) *n = num;
+  if (out) {
+    std::vector<unsigned char> raw(num);
+    const size_t got = std::fread(raw.data(), 1, num, f);
+    for (int i = 0; i < num; ++i) out[i] = (size_t)i < got ? (int)raw[i] : 0;
+  }
+  std::fclose(f);
+  return 0;
+}
+
+extern "C" int vt_loader_indices(int n, unsigned seed, int resets, int *out) {
+  if (n < 0 || resets < 0 || !out) return VT_EINVAL;
+  std::vector<size_t> idx(n);
+  std::iota(idx.begin(), idx.end(), 0);
+  std::mt19937 rng(seed);
+  std::shuffle(idx.begin(), idx.end(), rng);  // constructor (load_dataset.hpp:126)
+  for (int r = 0; r < resets; ++r) std::shuffle(idx.begin(), idx.end(), rng);  // reset() (:158)
+  for (int i = 0; i < n; ++i) out[i] = (int)idx[i];
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Forward / backward chains
+// ---------------------------------------------------------------------------------------------
+extern "C" int vt_model_set_training(vt_model *m, int training) {
+  if (!m) return VT_EINVAL;
+  m->training = training ? 1 : 0;
+  return 0;
+}
+
+extern "C" int vt_model_forward(vt_model *m, const float *d_images, int n, float *d_probs, vt_stream s) {
+  if (!m || !d_images || n < 1 || n > m->maxN) return VT_EINVAL;
+  const int H = m->d.input_dim, P = m->P, Ci = m->d.image_channels, K = m->K;
+  const long NL = (long)n * L;
+  const int nrb = (int)((NL + RB - 1) / RB);
+  m->lastN = n;
+  m->last_images = d_images;
+  // conv + BatchNorm2D statistics (training: batch stats; eval: running stats)
+  VTCHK(vt_conv3x3_fwd(d_images, m->P_("conv.W"), m->P_("conv.b"), m->conv, m->training ? m->part : nullptr, n, Ci, H, H, s));
+  if (m->training)
+    VTCHK(vt_bn_stats_finalize(m->part, n, C1, P, (long)n * P, m->P_("bn.running_mean"), m->P_("bn.running_var"), m->stat_bn, s));
+  else
+    VTCHK(vt_bn_stats_eval(m->P_("bn.running_mean"), m->P_("bn.running_var"), C1, m->stat_bn, s));
+  // tokenizer; the three BatchNorm1D layers always use batch statistics (visual_transformer.hpp:221)
+  VTCHK(vt_tokenizer_fwd(m->conv, m->stat_bn, m->P_("bn.gamma"), m->P_("bn.beta"), m->P_("tok.linear1.W"),
+                         m->P_("tok.linear1.b"), m->P_("tok.linear2.W"), m->P_("tok.linear2.b"), m->tokA, m->tok, m->part,
+                         n, P, s));
+  VTCHK(vt_bn_stats_finalize(m->part, n, D, L, NL, m->P_("norm1.running_mean"), m->P_("norm1.running_var"), m->stat_n1, s));
+  VTCHK(vt_transformer_ffn_fwd(m->tok, m->stat_n1, m->P_("norm1.gamma"), m->P_("norm1.beta"), m->P_("ffn.linear1.W"),
+                               m->P_("ffn.linear1.b"), m->P_("ffn.linear2.W"), m->P_("ffn.linear2.b"), m->a, m->hdn, m->s2,
+                               m->part, NL, s));
+  VTCHK(vt_bn_stats_finalize(m->part, nrb, D, RB, NL, m->P_("norm2.running_mean"), m->P_("norm2.running_var"), m->stat_n2, s));
+  VTCHK(vt_projector_tokens_fwd(m->s2, m->stat_n2, m->P_("norm2.gamma"), m->P_("norm2.beta"), m->P_("proj.linear1.W"),
+                                m->P_("proj.linear2.W"), m->P_("proj.linear3.W"), m->P_("proj.linear3.b"), m->o, m->pk, n, s));
+  VTCHK(vt_projector_fwd(m->conv, m->stat_bn, m->P_("bn.gamma"), m->P_("bn.beta"), m->pk, m->P_("proj.downsample.W"),
+                         m->P_("proj.downsample.b"), m->projA, m->z, m->part, n, P, s));
+  VTCHK(vt_bn_stats_finalize(m->part, n, C2, P, (long)n * P, m->P_("proj.norm.running_mean"), m->P_("proj.norm.running_var"),
+                             m->stat_pn, s));
+  VTCHK(vt_head_fwd(m->z, m->stat_pn, m->P_("proj.norm.gamma"), m->P_("proj.norm.beta"), m->P_("fc.W"), m->P_("fc.b"),
+                    m->pooled, m->pool_idx, m->logits, m->probs, n, H, K, s));
+  if (d_probs && d_probs != m->probs)
+    HIPCHK(hipMemcpyAsync(d_probs, m->probs, (size_t)n * K * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)s));
+  return 0;
+}
+
+extern "C" int vt_model_metrics(vt_model *m, const int *d_labels, float *d_loss_sum, int *d_argmax, vt_stream s) {
+  if (!m || m->lastN < 1) return VT_EINVAL;
+  return vt_metrics(m->probs, d_labels, m->lastN, m->K, d_loss_sum, d_argmax, s);
+}
+
+extern "C" long vt_model_read(vt_model *m, const char *name, float *host, long capacity) {
+  if (!m || !name) return VT_EINVAL;
+  auto it = m->named.find(name);
+  if (it == m->named.end()) return VT_EINVAL;
+  const long per_max = it->second.second;
+  // buffers sized by max_batch hold lastN samples' worth of data at the front
+  long cnt = per_max;
+  if (m->lastN > 0 && per_max % m->maxN == 0 && std::string(name).rfind("stat.", 0) != 0 &&
+      std::string(name).rfind("coef.", 0) != 0)
+    cnt = per_max / m->maxN * m->lastN;
+  if (!host) return cnt;
+  if (capacity < cnt) return VT_EINVAL;
+  if (hipSetDevice(m->device) != hipSuccess) return VT_EINVAL;
+  if (hipDeviceSynchronize() != hipSuccess) return VT_EINVAL;
+  if (hipMemcpy(host, it->second.first, cnt * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return VT_EINVAL;
+  return cnt;
+}

@@ -1,0 +1,318 @@
+"""Host-side mirror of the reference's Model / Trainer / DataLoader interface on top of the C ABI.
+
+Names follow the reference: `VTCNN` (model/vit_cnn.hpp), `Trainer` (utils/trainer.hpp),
+`DataLoader` / `load_dataset` (utils/load_dataset.hpp).  PyTorch is used only for device memory,
+streams and (optionally) torch.distributed; every computation is a HIP kernel in libvtcnn_hip.so.
+"""
+import ctypes as C
+import math
+import time
+
+import numpy as np
+import torch
+
+from ._lib import VtDims, VtLayout, check, lib
+
+
+def Dims(num_classes=10, image_channels=1, input_dim=28, tokens=16, token_channels=32, vt_channels=16, heads=2):
+    """Hyper-parameters with the reference's defaults (main.cpp:66-78)."""
+    return VtDims(image_channels, input_dim, tokens, token_channels, vt_channels, heads, num_classes)
+
+
+def _stream_handle():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class Layout:
+    def __init__(self, lo):
+        self.n_trainable = lo.n_trainable
+        self.n_total = lo.n_total
+        self.n_trainable_exact = lo.n_trainable_exact
+        self.tensors = {}
+        self.order = []
+        for k in range(lo.n_tensors):
+            t = lo.t[k]
+            name = t.name.decode()
+            self.tensors[name] = (t.offset, t.size, tuple(t.shape[:t.ndim]), t.kind)
+            self.order.append(name)
+
+    def view(self, arena, name):
+        off, size, shape, _ = self.tensors[name]
+        return arena[off:off + size].reshape(shape)
+
+
+class VTCNN:
+    """VTCNN model on one MI355X (reference model/vit_cnn.hpp:14-557).
+
+    forward / backward / update_weights / zero_grad / set_training / save / load keep the
+    reference's meaning.  Inputs are torch CUDA tensors ([N,Ci,H,W] float32 images, int32 labels);
+    the parameter and gradient arenas are torch tensors so that torch.distributed (RCCL) can
+    all-reduce gradients in place.
+    """
+
+    def __init__(self, dims=None, max_batch=32, device=None, seed=42, lr=0.001):
+        if not torch.cuda.is_available():
+            raise RuntimeError("vit_amd.VTCNN needs a HIP device; there is no CPU path")
+        self.dims = dims or Dims()
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        self.max_batch = int(max_batch)
+        self.lr = float(lr)
+        lo = VtLayout()
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            # arenas are torch tensors so that collectives can address them in place
+            n_total, n_train = self._layout_sizes()
+            self.arena = torch.zeros(n_total, dtype=torch.float32, device=self.device)
+            self.grads = torch.zeros(n_train, dtype=torch.float32, device=self.device)
+            check(lib.vt_model_create(C.byref(self.dims), self.max_batch, self.device.index,
+                                      C.c_void_p(self.arena.data_ptr()), C.c_void_p(self.grads.data_ptr()),
+                                      C.byref(self._h)), "vt_model_create")
+        check(lib.vt_model_layout(self._h, C.byref(lo)), "vt_model_layout")
+        self.layout = Layout(lo)
+        self.training = True
+        self._probs = torch.zeros(self.max_batch, self.dims.num_classes, dtype=torch.float32, device=self.device)
+        self._n = 0
+        if seed is not None:
+            check(lib.vt_model_init_seed(self._h, int(seed)), "vt_model_init_seed")
+
+    def _layout_sizes(self):
+        # mirrors include/vtcnn_layout.h: every tensor padded to a multiple of 4 floats
+        d = self.dims
+        c2, c1, L, D, h, K, ci = d.vt_channels, d.vt_channels // 2, d.tokens, d.token_channels, d.heads, d.num_classes, d.image_channels
+        pad = lambda n: (n + 3) & ~3
+        hd = D // h
+        train = [c1 * ci * 9, c1, c1, c1] + [D * hd] * (3 * h) + [D * D, D * D, D, D * D, D, D, D, D, D,
+                                                                   c1 * D, D * D, D * c2, c2, c2, c2, c1 * c2, c2,
+                                                                   c2 * 196 * K, K]
+        rest = [c1 * L, L, c1 * D, D, c1, c1, D, D, D, D, c2, c2]
+        n_train = sum(pad(x) for x in train)
+        return n_train + sum(pad(x) for x in rest), n_train
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            lib.vt_model_destroy(h)
+            self._h = None
+
+    # ---- reference Model API -------------------------------------------------------------
+    def set_training(self, is_training):
+        self.training = bool(is_training)
+        check(lib.vt_model_set_training(self._h, int(self.training)))
+
+    def forward(self, x):
+        """VTCNN::forward: x [N,Ci,H,W] float32 CUDA tensor -> softmax probabilities [N,K]."""
+        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+        n = x.shape[0]
+        d = self.dims
+        if tuple(x.shape[1:]) != (d.image_channels, d.input_dim, d.input_dim):
+            raise ValueError("input shape %s does not match the model" % (tuple(x.shape),))
+        if n < 1 or n > self.max_batch:
+            raise ValueError("batch %d outside [1, max_batch=%d]" % (n, self.max_batch))
+        self._n = n
+        self._x = x  # keep alive: backward re-reads the images
+        check(lib.vt_model_forward(self._h, C.c_void_p(x.data_ptr()), n, C.c_void_p(self._probs.data_ptr()),
+                                   _stream_handle()), "vt_model_forward")
+        return self._probs[:n]
+
+    def backward(self, labels):
+        """VTCNN::backward for the last forward; labels int32 CUDA tensor [N] (class indices; the
+        reference passes the one-hot matrix, utils/trainer.hpp:47-52)."""
+        assert labels.is_cuda and labels.dtype == torch.int32 and labels.numel() == self._n
+        check(lib.vt_model_backward(self._h, C.c_void_p(labels.data_ptr()), _stream_handle()), "vt_model_backward")
+
+    def update_weights(self, batch_size=32.0):
+        """VTCNN::update_weights + zero_grad with the reference's constant divisor (trainer.hpp:53)."""
+        check(lib.vt_model_sgd_step(self._h, self.lr, float(batch_size), _stream_handle()), "vt_model_sgd_step")
+
+    def zero_grad(self):
+        self.grads.zero_()
+
+    def metrics(self, labels=None):
+        """(sum of cross-entropy terms, argmax labels) of the last forward, computed on the device."""
+        loss = torch.zeros(1, dtype=torch.float32, device=self.device)
+        am = torch.zeros(self._n, dtype=torch.int32, device=self.device)
+        lp = C.c_void_p(labels.data_ptr()) if labels is not None else None
+        check(lib.vt_model_metrics(self._h, lp, C.c_void_p(loss.data_ptr()), C.c_void_p(am.data_ptr()),
+                                   _stream_handle()), "vt_model_metrics")
+        return loss, am
+
+    def save(self, path):
+        check(lib.vt_model_save(self._h, str(path).encode()), "vt_model_save(%s)" % path)
+
+    def load(self, path):
+        check(lib.vt_model_load(self._h, str(path).encode()), "vt_model_load(%s)" % path)
+
+    # ---- tooling -------------------------------------------------------------------------
+    def read(self, name):
+        n = lib.vt_model_read(self._h, name.encode(), None, 0)
+        if n < 0:
+            raise KeyError(name)
+        out = np.zeros(n, dtype=np.float32)
+        got = lib.vt_model_read(self._h, name.encode(), C.c_void_p(out.ctypes.data), n)
+        if got != n:
+            raise RuntimeError("vt_model_read(%s) -> %d" % (name, got))
+        return out
+
+    def get_arena(self):
+        return self.arena.detach().cpu().numpy()
+
+    def set_arena(self, host):
+        host = np.ascontiguousarray(host, dtype=np.float32)
+        assert host.size == self.layout.n_total
+        self.arena.copy_(torch.from_numpy(host))
+
+    def get_grads(self):
+        return self.grads.detach().cpu().numpy()
+
+
+# ---------------------------------------------------------------------------------------------
+# Data path (reference utils/load_dataset.hpp)
+# ---------------------------------------------------------------------------------------------
+class Dataset:
+    def __init__(self, images, labels):
+        self.images = images  # float32 [S, rows*cols]
+        self.labels = labels  # int32 [S]
+
+
+def load_dataset(image_path, label_path, max_samples=9999999):
+    """load_dataset (load_dataset.hpp:87-96): IDX images (u8/255.0f) and labels."""
+    n, r, c = C.c_int(), C.c_int(), C.c_int()
+    check(lib.vt_idx_read_images(str(image_path).encode(), max_samples, None, C.byref(n), C.byref(r), C.byref(c)),
+          "No se pudo abrir el archivo de imágenes")
+    imgs = np.zeros((n.value, r.value * c.value), dtype=np.float32)
+    check(lib.vt_idx_read_images(str(image_path).encode(), max_samples, C.c_void_p(imgs.ctypes.data), C.byref(n),
+                                 C.byref(r), C.byref(c)))
+    m = C.c_int()
+    check(lib.vt_idx_read_labels(str(label_path).encode(), max_samples, None, C.byref(m)),
+          "No se pudo abrir el archivo de etiquetas")
+    lbl = np.zeros(m.value, dtype=np.int32)
+    check(lib.vt_idx_read_labels(str(label_path).encode(), max_samples, C.c_void_p(lbl.ctypes.data), C.byref(m)))
+    if imgs.shape[0] != lbl.shape[0]:
+        raise RuntimeError("El número de imágenes y etiquetas no coincide")
+    return Dataset(imgs, lbl)
+
+
+def loader_indices(n, seed=42, resets=0):
+    out = np.zeros(n, dtype=np.int32)
+    check(lib.vt_loader_indices(n, seed, resets, C.c_void_p(out.ctypes.data)))
+    return out
+
+
+class DataLoader:
+    """DataLoader (load_dataset.hpp:99-165): shuffles in the constructor and at every reset()
+    with one mt19937(seed); the last batch may be short.  The dataset is kept resident on the
+    device; a batch is an index gather on the GPU."""
+
+    def __init__(self, images, labels, batch_size, channels=1, height=28, width=28, num_classes=10, seed=42,
+                 device=None):
+        if len(images) != len(labels):
+            raise RuntimeError("Mismatch entre imágenes y etiquetas")
+        self.n = len(images)
+        self.batch_size = int(batch_size)
+        self.shape = (channels, height, width)
+        self.seed = seed
+        self._resets = 0
+        self.index = 0
+        self.indices = loader_indices(self.n, seed, 0)
+        dev = device or torch.device("cuda", torch.cuda.current_device())
+        self._images = torch.from_numpy(np.ascontiguousarray(images, dtype=np.float32)).to(dev)
+        self._labels = torch.from_numpy(np.ascontiguousarray(labels, dtype=np.int32)).to(dev)
+        self._idx_dev = torch.from_numpy(self.indices.astype(np.int64)).to(dev)
+
+    def reset(self):
+        self.index = 0
+        self._resets += 1
+        self.indices = loader_indices(self.n, self.seed, self._resets)
+        self._idx_dev = torch.from_numpy(self.indices.astype(np.int64)).to(self._images.device)
+
+    def has_next(self):
+        return self.index < self.n
+
+    def total_batches(self):
+        return (self.n + self.batch_size - 1) // self.batch_size
+
+    def next_batch(self):
+        end = min(self.index + self.batch_size, self.n)
+        sel = self._idx_dev[self.index:end]
+        self.index = end
+        x = self._images.index_select(0, sel).reshape(-1, *self.shape).contiguous()
+        y = self._labels.index_select(0, sel).contiguous()
+        return x, y
+
+
+class Trainer:
+    """Trainer (utils/trainer.hpp:9-243): train / evaluate / evaluate_test / predict."""
+
+    def __init__(self, model, train_loader, val_loader, num_classes, batch_size, test_loader=None, out=print):
+        self.model, self.train_loader, self.val_loader, self.test_loader = model, train_loader, val_loader, test_loader
+        self.num_classes, self.batch_size, self.out = num_classes, batch_size, out
+
+    def _epoch_eval(self, loader):
+        loss_sum, acc_sum, batches = 0.0, 0.0, 0
+        preds, truth = [], []
+        self.model.set_training(False)
+        while loader.has_next():
+            x, y = loader.next_batch()
+            self.model.forward(x)
+            ls, am = self.model.metrics(y)
+            n = y.numel()
+            loss_sum += float(ls.item()) / n
+            acc_sum += float((am == y).sum().item()) / n
+            batches += 1
+            preds.append(am.cpu().numpy())
+            truth.append(y.cpu().numpy())
+        self.model.set_training(True)
+        return loss_sum / batches, acc_sum / batches, np.concatenate(preds), np.concatenate(truth)
+
+    def train(self, epochs, log_every=100, device="hip"):
+        for epoch in range(epochs):
+            t0 = time.time()
+            self.out("Epoch %d/%d" % (epoch + 1, epochs))
+            self.train_loader.reset()
+            losses, accs = [], []
+            while self.train_loader.has_next():
+                x, y = self.train_loader.next_batch()
+                self.model.forward(x)
+                self.model.backward(y)
+                ls, am = self.model.metrics(y)
+                self.model.update_weights(self.batch_size)
+                losses.append(ls / y.numel())
+                accs.append((am == y).float().mean())
+            torch.cuda.synchronize()
+            dt = time.time() - t0
+            self.out("Train Loss: %.4f | Accuracy: %.4f%% | Time: %.4f s" % (
+                float(torch.stack(losses).mean().item()), 100.0 * float(torch.stack(accs).mean().item()), dt))
+            self.evaluate()
+        if self.test_loader is not None:
+            self.out("\n=== Evaluación final sobre conjunto de test ===")
+            self.evaluate_test()
+
+    def evaluate(self):
+        self.val_loader.reset()
+        loss, acc, _, _ = self._epoch_eval(self.val_loader)
+        self.out("Val Loss: %.4f | Accuracy: %.4f%%" % (loss, acc * 100.0))
+        return loss, acc
+
+    def evaluate_test(self):
+        if self.test_loader is None:
+            self.out("[WARN] No se proporcionó test_loader")
+            return None
+        self.test_loader.reset()
+        loss, acc, pred, truth = self._epoch_eval(self.test_loader)
+        self.out("[TEST] Final Evaluation — Loss: %.4f | Accuracy: %.4f%%" % (loss, acc * 100.0))
+        k = self.num_classes
+        cm = np.zeros((k, k), dtype=np.int64)
+        np.add.at(cm, (truth, pred), 1)
+        self.out("\n🧩 Matriz de Confusión:\n    " + "".join("%4d" % j for j in range(k)))
+        for i_ in range(k):
+            self.out("%2d: " % i_ + "".join("%4d" % cm[i_, j] for j in range(k)))
+        return loss, acc, pred, truth, cm
+
+    def predict(self, image_data):
+        img = np.asarray(image_data, dtype=np.float32)
+        if img.size != 28 * 28:
+            raise RuntimeError("La imagen debe ser de tamaño 28x28")
+        x = torch.from_numpy(img.reshape(1, 1, 28, 28)).to(self.model.device)
+        self.model.set_training(False)
+        p = self.model.forward(x)
+        return int(torch.argmax(p[0]).item())
