@@ -88,6 +88,15 @@ int vt_model_sgd_step(vt_model *m, float lr, float divisor, vt_stream s);
  * Either may be NULL. */
 int vt_model_metrics(vt_model *m, const int *d_labels, float *d_loss_sum, int *d_argmax, vt_stream s);
 
+/* Per-launcher timing with HIP events recorded on the caller's stream around the launchers that
+ * vt_model_forward / backward / sgd_step issue.  filter: NULL or "" = off, "*" = every launcher,
+ * otherwise one launcher name without the vt_ prefix (e.g. "projector_bwd").
+ * vt_model_profile_read synchronises the device, returns the number of distinct names seen and,
+ * for 0 <= idx < that number, the name, the summed milliseconds and the launch count since the
+ * last vt_model_profile call.  No counterpart in the reference (it has no profiler hooks). */
+int vt_model_profile(vt_model *m, const char *filter);
+int vt_model_profile_read(vt_model *m, int idx, char *name_out, int name_cap, float *total_ms, int *count);
+
 /* Test / tooling access to the workspace: copies the named intermediate of the last
  * forward/backward to host.  Returns the number of floats, or a negative error. */
 long vt_model_read(vt_model *m, const char *name, float *host, long capacity);
@@ -95,6 +104,14 @@ long vt_model_read(vt_model *m, const char *name, float *host, long capacity);
 /* ---------------------------------------------------------------------------------------------
  * Host-side data path (bit-exact integer / byte work; no GPU involved).
  * ------------------------------------------------------------------------------------------- */
+
+/* Host-only forms of weight initialisation and checkpoint I/O on a host arena of
+ * vt_layout.n_total floats (same code the vt_model_* entry points use).  vt_checkpoint_read
+ * leaves tensors that the v1 file does not contain (transformer block, BatchNorm1D running
+ * statistics) untouched, as VTCNN::load does (model/vit_cnn.hpp:396-546). */
+int vt_host_init_arena(const vt_dims *dims, unsigned seed, float *arena_host);
+int vt_checkpoint_write(const vt_dims *dims, const float *arena_host, const char *path);
+int vt_checkpoint_read(const vt_dims *dims, float *arena_host, const char *path);
 
 /* loadImages2D / loadLabels (utils/load_dataset.hpp:20-85): big-endian IDX headers, pixel
  * u8 / 255.0f, label u8 -> int.  Query sizes with out == NULL. */
@@ -175,6 +192,35 @@ int vt_projector_bwd(const float *du, const float *pn_coef, const float *conv_ou
                      const float *bn_gamma, const float *bn_beta, const float *proj_a, const float *pk,
                      const float *wq, const float *wd, float *pdx, float *dv, float *dk, float *gslab, int N,
                      int P, vt_stream s);
+/* ProjectorLayer::backward, token side (projector_layer.hpp:186-202): Dense backward of linear3
+ * (values) and linear2 (keys) over the N*L token rows.  g_wk_wv_bv receives the contiguous
+ * gradient block [proj.linear2.W | proj.linear3.W | proj.linear3.b]; pdt the token delta.
+ * scratch >= ceil(rows/64) * 1552 floats. */
+int vt_projector_tokens_bwd(const float *o, const float *dv, const float *dk, const float *wv, const float *wk,
+                            float *pdt, float *g_wk_wv_bv, float *scratch, long rows, vt_stream s);
+/* TransformerLayer::backward (layers/transformer_layer.hpp:133-207) in three steps separated by
+ * the two BatchNorm1D backward reductions.
+ *  a: d0 = out - token_delta (:145), partial sums for norm2, and the tokenizer's linear2 input
+ *     delta dT0 = token_delta . W2tok^T (layers/tokenizer.hpp:73-75).
+ *  b: norm2 backward apply, ffn linear2 / linear1 backward (no ReLU derivative, :174-181),
+ *     da = dh.W1^T + ds2, partial sums for norm1.  g_ffn = [gW1 | gb1 | gW2 | gb2].
+ *  c: norm1 backward apply, delta of the (zero) concat dc = dr.Wo^T
+ *     (layers/multi_head_attention.hpp:131-135) and the per-head q,k,v recomputation (:144-152). */
+int vt_transformer_bwd_a(const float *o, const float *pdt, const float *s2, const float *n2_stat,
+                         const float *tok_w2, float *part, float *dT0, long rows, vt_stream s);
+int vt_transformer_bwd_b(const float *o, const float *pdt, const float *n2_coef, const float *hdn, const float *a,
+                         const float *tok, const float *n1_stat, const float *w1, const float *w2, float *ds2,
+                         float *da, float *g_ffn, float *scratch, float *part, long rows, vt_stream s);
+int vt_transformer_bwd_c(const float *da, const float *n1_coef, const float *wo, const float *tok, const float *wqkv,
+                         float *dr, float *dc, float *qkv, long rows, vt_stream s);
+/* MultiHeadAttention::backward per-head part (multi_head_attention.hpp:139-181): gradients of the
+ * per-head query / key / value Dense layers, g_qkv = [q0 | k0 | v0 | q1 | k1 | v1].  Attention
+ * groups are `groups` chunks of N consecutive token rows.  The output projection's gradient is
+ * identically zero in the reference (its cached input is the zero concat, :133) and the layer's
+ * input delta is never used (layers/visual_transformer.hpp:160); neither is computed.
+ * scratch >= groups * heads * ceil(N/64) * 1536 floats. */
+int vt_mha_bwd(const float *qkv, const float *dc, const float *tok, const float *wqkv, float *g_qkv, float *scratch,
+               int N, int groups, vt_stream s);
 /* DenseLayer::backward over a row matrix (dense_layer.hpp:79-100): gW = X^T dY, gb = sum dY,
  * dX = dY W^T (optionally accumulated into dX).  in,out <= 32. */
 int vt_dense_bwd_rows(const float *X, const float *W, const float *dY, float *gW, float *gb, float *dX,

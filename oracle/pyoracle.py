@@ -36,26 +36,28 @@ def build():
     subprocess.check_call(["make", "-s", "-C", _HERE])
 
 
-def _load():
-    if not os.path.exists(_LIB):
+def _load(path=_LIB):
+    if not os.path.exists(path):
         build()
-    lib = C.CDLL(_LIB)
+    lib = C.CDLL(path)
     lib.vto_create.restype = C.c_void_p
     lib.vto_create.argtypes = [C.POINTER(VtDims), C.c_int]
     lib.vto_destroy.argtypes = [C.c_void_p]
     lib.vto_layout.argtypes = [C.POINTER(VtDims), C.POINTER(VtLayout)]
     lib.vto_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     lib.vto_backward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-    lib.vto_loss.restype = C.c_float
+    lib.vto_loss.restype = C.c_double if path.endswith("64.so") else C.c_float
     lib.vto_loss.argtypes = [C.c_void_p, C.c_void_p]
     lib.vto_argmax.argtypes = [C.c_void_p, C.c_void_p]
-    lib.vto_get.restype = C.POINTER(C.c_float)
+    lib.vto_get.restype = C.POINTER(C.c_double if path.endswith("64.so") else C.c_float)
     lib.vto_get.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_long)]
-    lib.vto_sgd.argtypes = [C.POINTER(VtDims), C.c_void_p, C.c_void_p, C.c_float, C.c_float]
+    real = C.c_double if path.endswith("64.so") else C.c_float
+    lib.vto_sgd.argtypes = [C.POINTER(VtDims), C.c_void_p, C.c_void_p, real, real]
     return lib
 
 
 _lib = None
+_lib64 = None
 
 
 def lib():
@@ -63,6 +65,13 @@ def lib():
     if _lib is None:
         _lib = _load()
     return _lib
+
+
+def lib64():
+    global _lib64
+    if _lib64 is None:
+        _lib64 = _load(os.path.join(_HERE, "libvtcnn_oracle64.so"))
+    return _lib64
 
 
 def make_dims(num_classes=10, image_channels=1, input_dim=28, tokens=16, token_channels=32, vt_channels=16, heads=2):
@@ -104,48 +113,70 @@ class Layout:
 
 
 class Oracle:
-    def __init__(self, dims, n):
+    """One VTCNN step on the CPU.  f64=True runs the double-precision build (arena, inputs and
+    outputs are float64 arrays then)."""
+
+    def __init__(self, dims, n, f64=False):
         self.dims = dims
         self.n = n
         self.layout = Layout(dims)
-        self.ctx = lib().vto_create(C.byref(dims), n)
+        self.lib = lib64() if f64 else lib()
+        self.dtype = np.float64 if f64 else np.float32
+        self.ctx = self.lib.vto_create(C.byref(dims), n)
         if not self.ctx:
             raise ValueError("vto_create failed")
 
     def __del__(self):
         if getattr(self, "ctx", None):
-            lib().vto_destroy(self.ctx)
+            self.lib.vto_destroy(self.ctx)
             self.ctx = None
 
     def forward(self, arena, x, training=True):
-        assert arena.dtype == np.float32 and arena.size == self.layout.n_total and arena.flags.c_contiguous
-        x = np.ascontiguousarray(x, dtype=np.float32)
+        assert arena.dtype == self.dtype and arena.size == self.layout.n_total and arena.flags.c_contiguous
+        x = np.ascontiguousarray(x, dtype=self.dtype)
         assert x.size == self.n * self.dims.image_channels * self.dims.input_dim ** 2
         self._x = x
-        lib().vto_forward(self.ctx, arena.ctypes.data, x.ctypes.data, int(training))
+        self.lib.vto_forward(self.ctx, arena.ctypes.data, x.ctypes.data, int(training))
         return self.get("fwd.preds").reshape(self.n, self.dims.num_classes)
 
     def loss(self, labels):
         labels = np.ascontiguousarray(labels, dtype=np.int32)
-        return float(lib().vto_loss(self.ctx, labels.ctypes.data))
+        return float(self.lib.vto_loss(self.ctx, labels.ctypes.data))
 
     def argmax(self):
         out = np.zeros(self.n, dtype=np.int32)
-        lib().vto_argmax(self.ctx, out.ctypes.data)
+        self.lib.vto_argmax(self.ctx, out.ctypes.data)
         return out
 
     def backward(self, arena, labels):
         labels = np.ascontiguousarray(labels, dtype=np.int32)
-        grads = np.zeros(self.layout.n_trainable, dtype=np.float32)
-        lib().vto_backward(self.ctx, arena.ctypes.data, self._x.ctypes.data, labels.ctypes.data, grads.ctypes.data)
+        grads = np.zeros(self.layout.n_trainable, dtype=self.dtype)
+        self.lib.vto_backward(self.ctx, arena.ctypes.data, self._x.ctypes.data, labels.ctypes.data, grads.ctypes.data)
         return grads
 
+    def set_routing(self, pool_slot=None, relu_mask=None):
+        """Imposes another evaluation's max-pool slots / ReLU mask (uint8 arrays), or clears them."""
+        self._slot = None if pool_slot is None else np.ascontiguousarray(pool_slot, dtype=np.uint8)
+        self._mask = None if relu_mask is None else np.ascontiguousarray(relu_mask, dtype=np.uint8)
+        self.lib.vto_set_routing.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        self.lib.vto_set_routing(self.ctx, None if self._slot is None else self._slot.ctypes.data,
+                                 None if self._mask is None else self._mask.ctypes.data)
+
+    def pool_decisions(self):
+        """(slot uint8 [N*Q], gap [N*Q]) of the oracle's own max-pool decisions in the last forward."""
+        q = self.n * self.dims.vt_channels * 196
+        slot = np.zeros(q, dtype=np.uint8)
+        gap = np.zeros(q, dtype=self.dtype)
+        self.lib.vto_pool_decisions.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        self.lib.vto_pool_decisions(self.ctx, slot.ctypes.data, gap.ctypes.data)
+        return slot, gap
+
     def sgd(self, arena, grads, lr=0.001, divisor=32.0):
-        lib().vto_sgd(C.byref(self.dims), arena.ctypes.data, grads.ctypes.data, lr, divisor)
+        self.lib.vto_sgd(C.byref(self.dims), arena.ctypes.data, grads.ctypes.data, lr, divisor)
 
     def get(self, name):
         cnt = C.c_long(0)
-        p = lib().vto_get(self.ctx, name.encode(), C.byref(cnt))
+        p = self.lib.vto_get(self.ctx, name.encode(), C.byref(cnt))
         if not p:
             raise KeyError(name)
         return np.ctypeslib.as_array(p, shape=(cnt.value,)).copy()

@@ -1,0 +1,163 @@
+"""GPU parity of one full training step (forward, backward, SGD) through the C ABI against the
+reference's own tensors (tests/golden/) and, at larger batches, against the CPU oracle.
+
+Tolerances (max|a-b|/max|b| per tensor): 1e-4 for activations, deltas and gradients; the few
+gradients that are plain sums over N*784 rows get 5e-4 because the reference's own sequential
+fp32 sum carries ~2e-4 of rounding noise there (measured against an fp64 restatement).
+Updated weights: 1e-6.  Frozen tokenizer tensors and the zero attention output-projection
+gradient: exact."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+LOOSE = {"proj.downsample.b": 5e-4, "proj.norm.beta": 5e-4, "conv.b": 5e-4, "bn.beta": 5e-4, "proj.linear3.b": 5e-4}
+
+
+def _setup(fx, k):
+    import torch
+    from vit_amd import VTCNN, Dims
+    from oracle.pyoracle import Layout, make_dims
+    g = load_golden(fx)
+    if "p0.conv.W" not in g:
+        g.update({kk: v for kk, v in load_golden("step_n2_k8_full.npz").items() if kk.startswith("p0.")})
+    m = VTCNN(Dims(num_classes=k), max_batch=32, seed=None)
+    lo = Layout(make_dims(num_classes=k))
+    m.set_arena(lo.pack(g, "p0."))
+    x = torch.from_numpy(g["in.X"]).cuda()
+    y = torch.from_numpy(g["in.labels"].astype(np.int32)).cuda()
+    return g, m, x, y, torch
+
+
+def _check_grads(m, g):
+    grads = m.get_grads()
+    bad = []
+    for name, (off, size, shape, kind) in m.layout.tensors.items():
+        if kind != 0:
+            continue
+        e = rel_err(grads[off:off + size], g["g." + name])
+        if not e < LOOSE.get(name, TOL):
+            bad.append((name, e))
+    assert not bad, bad
+    assert np.all(m.layout.view(grads, "mha.o.W") == 0.0)
+
+
+def test_backward_intermediates_n2():
+    g, m, x, y, torch = _setup("step_n2_k8_full.npz", 8)
+    m.forward(x)
+    m.backward(y)
+    n, P = 2, 784
+    checks = {
+        "bwd.d_logits": g["bwd.d_logits"],
+        "bwd.proj_dx": g["bwd.proj_dx"], "bwd.proj_dt": g["bwd.proj_dt"], "bwd.tr_ds2": g["bwd.tr_ds2"],
+        "bwd.tr_dr": g["bwd.tr_dr"], "bwd.tok_dx": g["bwd.tok_dx"],
+    }
+    bad = []
+    for name, ref in checks.items():
+        e = rel_err(m.read(name), ref)
+        if not e < TOL:
+            bad.append((name, e))
+    assert not bad, bad
+    _check_grads(m, g)
+
+
+@pytest.mark.parametrize("fx,n,k", [("step_n2_k8_full.npz", 2, 8), ("step_n32_k10.npz", 32, 10), ("step_n5_k8.npz", 5, 8)])
+def test_train_step_vs_reference(fx, n, k):
+    g, m, x, y, torch = _setup(fx, k)
+    p = m.forward(x).cpu().numpy()
+    assert rel_err(p, g["fwd.preds"]) < TOL
+    m.backward(y)
+    _check_grads(m, g)
+    m.update_weights(32.0)
+    arena = m.get_arena()
+    for name, (off, size, shape, kind) in m.layout.tensors.items():
+        if "p1." + name not in g:
+            continue
+        ref = g["p1." + name].ravel().astype(np.float64)
+        err = np.abs(arena[off:off + size].astype(np.float64) - ref).max()
+        if kind == 0:
+            # w1 = w0 - g/32*lr: fp32 storage rounding of w plus the gradient's own tolerance
+            bound = 1e-6 * np.abs(ref).max() + (0.001 / 32.0) * LOOSE.get(name, TOL) * np.abs(g["g." + name]).max()
+        elif kind == 2:
+            bound = 1e-5 * np.abs(ref).max() + 1e-6
+        else:
+            bound = 0.0
+        assert err <= bound, (name, err, bound)
+    for nm in ("tok.linear1.W", "tok.linear1.b", "tok.linear2.W", "tok.linear2.b"):
+        assert np.array_equal(m.layout.view(arena, nm), g["p0." + nm].reshape(m.layout.tensors[nm][2])), nm
+    assert np.all(m.get_grads() == 0.0)  # zero_grad
+    # second training forward with the updated weights, then eval-mode forward
+    p2 = m.forward(x).cpu().numpy()
+    assert rel_err(p2, g["fwd2.preds"]) < TOL
+    m.set_training(False)
+    pe = m.forward(x).cpu().numpy()
+    assert rel_err(pe, g["eval.preds"]) < TOL
+    _, am = m.metrics()
+    assert np.array_equal(am.cpu().numpy(), g["eval.argmax"])
+
+
+def _routing_from_gpu(m, n):
+    """Max-pool slots and the effective ReLU mask the HIP path used in its last backward."""
+    slots = m.read("fwd.pool_idx").view(np.uint8)[:n * 3136].copy()
+    mask = (m.read("bwd.du") != 0.0).astype(np.uint8)  # only positions that received a delta matter
+    return slots, mask
+
+
+@pytest.mark.parametrize("n,k", [(64, 8), (200, 10), (1024, 8)])
+def test_train_step_vs_oracle_larger_batch(n, k):
+    """Batches beyond the committed reference fixtures, up to the benchmark's 1024.
+
+    Checker: the oracle (pinned bit-exactly to the reference at N=2/5/32) in its double-precision
+    build, because by N=200 the reference's own sequential fp32 sums over N*784 rows are ~2e-3
+    away from exact math (tools/diag_errors.py prints both distances).
+    The step has two discontinuous operations, the max-pool arg-max and the ReLU mask; two correct
+    evaluations may pick differently at near-ties, after which deltas differ by O(1) at those
+    pixels.  So parity is checked in two parts:
+      1. discrete decisions: every pooling window where the HIP path and the oracle disagree must
+         be a near-tie (gap between the two largest window values < 1e-5 of the largest pooled
+         value), and such windows must be rare (< 0.1 %); predicted labels are identical;
+      2. floats: with the HIP path's own decisions imposed on the fp64 oracle, every gradient
+         tensor is within 1e-4 (max|a-b|/max|b|); the forward needs no such care (continuous).
+    Exercises multi-tile attention groups (N > 64), ragged row blocks, the chunked fc gradient."""
+    import torch
+    from vit_amd import VTCNN, Dims
+    from oracle.pyoracle import Oracle, make_dims
+    rng = np.random.default_rng(n)
+    x = (rng.integers(0, 256, size=(n, 1, 28, 28)).astype(np.float32) / np.float32(255.0))
+    y = rng.integers(0, k, size=n).astype(np.int32)
+    m = VTCNN(Dims(num_classes=k), max_batch=n, seed=42)
+    arena32 = m.get_arena().copy()
+    pg = m.forward(torch.from_numpy(x).cuda()).cpu().numpy()
+    m.backward(torch.from_numpy(y).cuda())
+    gg = m.get_grads()
+    slots, mask = _routing_from_gpu(m, n)
+    # part 1: forward floats and discrete decisions vs exact math (fp64 oracle, its own decisions)
+    o = Oracle(make_dims(num_classes=k), n, f64=True)
+    arena64 = arena32.astype(np.float64)
+    p64 = o.forward(arena64.copy(), x, training=True)
+    assert rel_err(pg, p64) < TOL
+    top2 = np.sort(p64, axis=1)[:, -2:]
+    flips = np.nonzero(pg.argmax(1) != p64.argmax(1))[0]
+    assert np.all(top2[flips, 1] - top2[flips, 0] < 1e-5), flips  # labels equal except exact-tie samples
+    ref_slots, gap = o.pool_decisions()
+    diff = np.nonzero(ref_slots != slots)[0]
+    assert diff.size <= 1e-3 * slots.size, diff.size
+    assert np.all(gap[diff] < 1e-5 * np.abs(o.get("fwd.pooled")).max()), gap[diff].max()
+    # part 2: floats vs exact math under identical decisions
+    o.set_routing(slots, mask)
+    po = o.forward(arena64.copy(), x, training=True)
+    go = o.backward(arena64, y)
+    assert rel_err(pg, po) < TOL
+    bad = []
+    for name in ("bwd.proj_dx", "bwd.proj_dt", "bwd.tr_ds2", "bwd.tr_dr", "bwd.tok_dx"):
+        e = rel_err(m.read(name), o.get(name))
+        if not e < TOL:
+            bad.append((name, e))
+    for name, (off, size, shape, kind) in m.layout.tensors.items():
+        if kind == 0:
+            e = rel_err(gg[off:off + size], go[off:off + size])
+            if not e < TOL:
+                bad.append((name, e))
+    assert not bad, bad

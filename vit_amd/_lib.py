@@ -46,6 +46,11 @@ SIGNATURES = {
     "vt_model_sgd_step": (i, [p, f, f, p]),
     "vt_model_metrics": (i, [p, p, p, p, p]),
     "vt_model_read": (l, [p, C.c_char_p, p, l]),
+    "vt_model_profile": (i, [p, C.c_char_p]),
+    "vt_model_profile_read": (i, [p, i, C.c_char_p, i, C.POINTER(f), C.POINTER(i)]),
+    "vt_host_init_arena": (i, [C.POINTER(VtDims), u, p]),
+    "vt_checkpoint_write": (i, [C.POINTER(VtDims), p, C.c_char_p]),
+    "vt_checkpoint_read": (i, [C.POINTER(VtDims), p, C.c_char_p]),
     "vt_idx_read_images": (i, [C.c_char_p, i, p, C.POINTER(i), C.POINTER(i), C.POINTER(i)]),
     "vt_idx_read_labels": (i, [C.c_char_p, i, p, C.POINTER(i)]),
     "vt_loader_indices": (i, [i, u, i, p]),
@@ -68,8 +73,11 @@ SIGNATURES = {
     "vt_reduce_rows": (i, [p, l, i, i, p, p]),
     "vt_sgd_update": (i, [p, p, i, f, f, i, p]),
     "vt_adam_update": (i, [p, p, p, p, i, f, f, f, f, i, f, p]),
-    "vt_transformer_bwd": (i, [p] * 22 + [l, p]),
-    "vt_mha_bwd": (i, [p] * 8 + [i, i, p]),
+    "vt_projector_tokens_bwd": (i, [p] * 8 + [l, p]),
+    "vt_transformer_bwd_a": (i, [p] * 7 + [l, p]),
+    "vt_transformer_bwd_b": (i, [p] * 14 + [l, p]),
+    "vt_transformer_bwd_c": (i, [p] * 8 + [l, p]),
+    "vt_mha_bwd": (i, [p] * 6 + [i, i, p]),
 }
 del p, i, l, f, u
 
@@ -81,8 +89,6 @@ def _load():
             "there is no CPU fallback." % LIB_PATH)
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
-        if os.environ.get("VT_DEV_PARTIAL") and not hasattr(lib, name):
-            continue
         fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
         fn.restype = res
         fn.argtypes = args

@@ -1,0 +1,1148 @@
+// Backward kernels of the VTCNN hot path for gfx950 (MI355X).
+//
+// The backward pass is cut at the four BatchNorm backward reductions (sum delta, sum delta*xhat
+// over the whole mini-batch) and at the weight-gradient reductions.  Every cross-workgroup sum
+// goes through a partial slab + fixed-order column reduction (no float atomics: results are
+// bitwise reproducible).  Each kernel names the reference code it restates, quirks included.
+#include "vtcnn_common.h"
+
+namespace vt {
+
+__device__ __forceinline__ void load_x_raw(const float *__restrict__ conv, size_t rec, const float *__restrict__ st,
+                                           const float *__restrict__ g, const float *__restrict__ b, float (&x)[C1],
+                                           float (&xh)[C1]) {
+  const float4 *src = reinterpret_cast<const float4 *>(conv + rec * C1);
+  const float4 a = src[0], c = src[1];
+  const float raw[C1] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+#pragma unroll
+  for (int ch = 0; ch < C1; ++ch) {
+    xh[ch] = (raw[ch] - st[ch]) * st[C1 + ch];
+    x[ch] = xh[ch] * g[ch] + b[ch];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Head backward.  SoftmaxLayer::backward with targets: delta = softmax - onehot, no 1/N
+// (reference layers/softmax_layer.hpp:29); fc input delta = delta . W^T (dense_layer.hpp:98-99);
+// MaxPool2DLayer::backward scatter to the arg-max slot (pooling_layer.hpp:88-92); ReLU mask on the
+// flat reinterpretation (relu_layer.hpp:20-33, projector_layer.hpp:121-131); partial sums of the
+// projector BatchNorm1D backward (batch_normalization_layer.hpp:187-188).
+// One workgroup per image; the scattered delta block lives in LDS.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void k_head_bwd(const float *__restrict__ probs, const int *__restrict__ labels,
+                                                  const float *__restrict__ Wfc, const unsigned char *__restrict__ pool_idx,
+                                                  const float *__restrict__ z, const float *__restrict__ st,
+                                                  const float *__restrict__ g, const float *__restrict__ b,
+                                                  float *__restrict__ dlogits, float *__restrict__ du,
+                                                  float *__restrict__ part, int H, int K) {
+  extern __shared__ float sdg[];  // P*C2 scattered deltas, then NW*2*C2 reduction scratch
+  const int W = H, P = H * W, pk = H / 14, Q = C2 * 196;
+  float *red = sdg + P * C2;
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const int label = labels[n];
+  float dl[KMAX];
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) dl[k] = (k < K) ? probs[(size_t)n * K + k] - (k == label ? 1.0f : 0.0f) : 0.f;
+  if (tid < K) dlogits[(size_t)n * K + tid] = probs[(size_t)n * K + tid] - (tid == label ? 1.0f : 0.0f);
+  for (int i = tid; i < P * C2 / 4; i += TPB) reinterpret_cast<float4 *>(sdg)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();
+  for (int f = tid; f < Q; f += TPB) {
+    float df = 0.f;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+      if (k < K) df += dl[k] * Wfc[(size_t)f * K + k];
+    const int ch = f / 196, ij = f % 196, i = ij / 14, j = ij % 14;
+    const int slot = pool_idx[(size_t)n * Q + f];
+    sdg[ch * P + (i * pk + slot / pk) * W + j * pk + slot % pk] = df;
+  }
+  __syncthreads();
+  float s[2 * C2];
+#pragma unroll
+  for (int c = 0; c < 2 * C2; ++c) s[c] = 0.f;
+  for (int p = tid; p < P; p += TPB) {
+    const float4 *src = reinterpret_cast<const float4 *>(z + ((size_t)n * P + p) * C2);
+    const float4 *dsrc = reinterpret_cast<const float4 *>(sdg + p * C2);
+    float4 *dst = reinterpret_cast<float4 *>(du + ((size_t)n * P + p) * C2);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 v = src[q], d = dsrc[q];
+      const float zv[4] = {v.x, v.y, v.z, v.w}, dv[4] = {d.x, d.y, d.z, d.w};
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = 4 * q + e;
+        const float xh = (zv[e] - st[c]) * st[C2 + c];
+        const float y = xh * g[c] + b[c];
+        o[e] = y > 0.f ? dv[e] : 0.f;
+        s[c] += o[e];
+        s[C2 + c] += o[e] * xh;
+      }
+      dst[q] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+  }
+  block_sum<2 * C2>(s, red);
+  if (tid < 2 * C2) part[(size_t)n * 2 * C2 + tid] = s[tid];
+}
+
+// ---------------------------------------------------------------------------------------------
+// fc DenseLayer::backward weight / bias gradients (reference layers/dense_layer.hpp:92-96):
+// gW[f][k] = sum_n pooled[n][f] * delta[n][k], gb[k] = sum_n delta[n][k].  Thread = one input
+// feature f, loop over a chunk of samples; chunks are summed by k_reduce_rows.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void k_fc_wgrad(const float *__restrict__ pooled, const float *__restrict__ dl,
+                                                  float *__restrict__ out, int N, int Q, int K, int chunk, int ld) {
+  const int f = blockIdx.x * TPB + threadIdx.x;
+  const int n0 = blockIdx.y * chunk, n1 = min(N, n0 + chunk);
+  float *row = out + (size_t)blockIdx.y * ld;
+  if (f < Q) {
+    float acc[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) acc[k] = 0.f;
+    for (int n = n0; n < n1; ++n) {
+      const float pv = pooled[(size_t)n * Q + f];
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k)
+        if (k < K) acc[k] += pv * dl[(size_t)n * K + k];
+    }
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+      if (k < K) row[(size_t)f * K + k] = acc[k];
+  }
+  if (blockIdx.x == 0 && threadIdx.x < K) {
+    float s = 0.f;
+    for (int n = n0; n < n1; ++n) s += dl[(size_t)n * K + threadIdx.x];
+    row[(size_t)Q * K + threadIdx.x] = s;
+  }
+}
+
+// Column sums of a [rows][ld] slab: out[c] = sum_r slab[r][c], c < cols.  1024 threads =
+// 64 columns x 16 row lanes; fixed order => reproducible.
+__global__ __launch_bounds__(1024) void k_reduce_rows(const float *__restrict__ slab, long rows, int cols, int ld,
+                                                      float *__restrict__ out) {
+  __shared__ float sh[16][65];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  float s = 0.f;
+  if (c < cols)
+    for (long r = rl; r < rows; r += 16) s += slab[r * ld + c];
+  sh[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0 && c < cols) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += sh[k][cl];
+    out[c] = t;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// BatchNorm backward reduction step (reference layers/batch_normalization_layer.hpp:187-199 and
+// 316-326).  From S1 = sum delta, S2 = sum delta*xhat per channel:
+//   grad_gamma = S2, grad_beta = S1
+//   dvar  = sum (delta*gamma*(x-mean)) * -0.5 * inv^3 = -0.5 * gamma * inv^2 * S2
+//   dmean = sum delta*gamma*(-inv)                    = -gamma * inv * S1
+//           (the reference's extra term dvar*(-2/R)*sum(x-mean) is rounding noise around 0 and is
+//            dropped)
+//   delta_in = delta*gamma*inv + (dvar*2/R) * (x[row 0] - mean) + dmean/R
+// The middle term uses row 0 of the input for every row: in the reference the product is written
+// small[1,C] * big[R,C] and Tensor::operator* keeps the left operand's shape
+// (tensor_cpu.hpp:1050-1084).  coef = (scale, shift) with delta_in = delta*scale + shift.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void k_bn_bwd_finalize(const float *__restrict__ part, int nb, int C, long rows_total,
+                                                         const float *__restrict__ gamma, const float *__restrict__ stat,
+                                                         const float *__restrict__ in_row0, float *__restrict__ ggamma,
+                                                         float *__restrict__ gbeta, float *__restrict__ coef) {
+  __shared__ double sh[TPB];
+  const int tid = threadIdx.x;
+  const int C2x = 2 * C;  // (S1, S2) pairs
+  const int c = tid % C2x, j = tid / C2x, ns = TPB / C2x;
+  double s = 0.0;
+  if (j < ns)
+    for (int b = j; b < nb; b += ns) s += (double)part[(size_t)b * C2x + c];
+  sh[tid] = s;
+  __syncthreads();
+  if (tid < C) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < ns; ++k) {
+      s1 += sh[k * C2x + tid];
+      s2 += sh[k * C2x + C + tid];
+    }
+    const float S1 = (float)s1, S2 = (float)s2;
+    const float gm = gamma[tid], mean = stat[tid], inv = stat[C + tid];
+    const float R = (float)rows_total;
+    ggamma[tid] = S2;
+    gbeta[tid] = S1;
+    const float dvar = -0.5f * gm * inv * inv * S2;
+    const float dmean = -gm * inv * S1;
+    const float k1 = ((dvar * 2.0f) * (1.0f / R)) * (in_row0[tid] - mean);
+    const float k2 = dmean * (1.0f / R);
+    coef[tid] = gm * inv;
+    coef[C + tid] = k1 + k2;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// ProjectorLayer::backward, pixel side (reference layers/projector_layer.hpp:133-184, 204-213).
+// Per pixel (dz = BatchNorm1D input delta):
+//   dx  = dz . Wd^T                                   downsample Dense backward
+//   da  = dz . v^T;  ds = a * (da - sum_l da*a)       softmax_backward over tokens (tensor_cpu.hpp:946-950)
+//   dx += ds . Mq^T                                   (= x_q_delta . Wq^T with Mq = Wq k^T folded)
+// Per-sample sums over pixels (staged through LDS in chunks of 256 pixels):
+//   G[c][l]   = sum_p x[c] ds[l]      ->  dk = G^T Wq (token key delta),  gWq_n = G k
+//   dv[l][c2] = sum_p a[l] dz[c2]     (value delta)
+//   gWd_n     = sum_p x^T dz,  gbd_n = sum_p dz
+// gslab record per image: gWq_n[C1*D] | gWd_n[C1*C2] | gbd_n[C2]  (GS_STRIDE floats).
+// ---------------------------------------------------------------------------------------------
+constexpr int GS_STRIDE = C1 * D + C1 * C2 + C2;  // 400
+constexpr int SX = 12, SA = 20;                   // padded LDS row strides (conflict-free b128)
+__global__ __launch_bounds__(TPB) void k_proj_bwd(const float *__restrict__ du, const float *__restrict__ coef,
+                                                  const float *__restrict__ conv, const float *__restrict__ st,
+                                                  const float *__restrict__ g, const float *__restrict__ b,
+                                                  const float *__restrict__ projA, const float *__restrict__ pk,
+                                                  const float *__restrict__ Wq, const float *__restrict__ Wd,
+                                                  float *__restrict__ pdx, float *__restrict__ dv_out,
+                                                  float *__restrict__ dk_out, float *__restrict__ gslab, int P) {
+  extern __shared__ float sm[];
+  float *sx = sm;                  // [256][SX]
+  float *sa = sx + TPB * SX;       // [256][SA]
+  float *sdz = sa + TPB * SA;      // [256][SA]
+  float *sds = sdz + TPB * SA;     // [256][SA]
+  float *sred = sds + TPB * SA;    // [8][32][18] cross-group reduction
+  float *sG = sred + 8 * 32 * 18;  // [C1][L]
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const float *__restrict__ mq = pk + (size_t)n * PK_STRIDE;
+  const float *__restrict__ vv = mq + C1 * L;
+  const float *__restrict__ kk = vv + L * C2;
+  const int j = tid & 31, pg = tid >> 5, jj = j & 15;
+  const bool lo = j < 16;
+  float ax[C1], aa[8], ab = 0.f;
+#pragma unroll
+  for (int c = 0; c < C1; ++c) ax[c] = 0.f;
+#pragma unroll
+  for (int l = 0; l < 8; ++l) aa[l] = 0.f;
+
+  for (int it = 0; it < PPT; ++it) {
+    const int p = tid + it * TPB;
+    const bool ok = p < P;
+    float x[C1], a[L], dz[C2], ds[L];
+    if (ok) {
+      load_x(conv, (size_t)n * P + p, st, g, b, x);
+      const float4 *as = reinterpret_cast<const float4 *>(projA + ((size_t)n * P + p) * L);
+      const float4 *us = reinterpret_cast<const float4 *>(du + ((size_t)n * P + p) * C2);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 av = as[q], uv = us[q];
+        a[4 * q] = av.x; a[4 * q + 1] = av.y; a[4 * q + 2] = av.z; a[4 * q + 3] = av.w;
+        dz[4 * q] = uv.x * coef[4 * q] + coef[C2 + 4 * q];
+        dz[4 * q + 1] = uv.y * coef[4 * q + 1] + coef[C2 + 4 * q + 1];
+        dz[4 * q + 2] = uv.z * coef[4 * q + 2] + coef[C2 + 4 * q + 2];
+        dz[4 * q + 3] = uv.w * coef[4 * q + 3] + coef[C2 + 4 * q + 3];
+      }
+      float dx[C1];
+#pragma unroll
+      for (int c = 0; c < C1; ++c) {
+        float s = 0.f;
+#pragma unroll
+        for (int c2 = 0; c2 < C2; ++c2) s += dz[c2] * Wd[c * C2 + c2];
+        dx[c] = s;
+      }
+      float dot = 0.f;
+#pragma unroll
+      for (int l = 0; l < L; ++l) {
+        float s = 0.f;
+#pragma unroll
+        for (int c2 = 0; c2 < C2; ++c2) s += dz[c2] * vv[l * C2 + c2];
+        ds[l] = s;
+        dot += s * a[l];
+      }
+#pragma unroll
+      for (int l = 0; l < L; ++l) ds[l] = a[l] * (ds[l] - dot);
+#pragma unroll
+      for (int c = 0; c < C1; ++c) {
+        float s = 0.f;
+#pragma unroll
+        for (int l = 0; l < L; ++l) s += ds[l] * mq[c * L + l];
+        dx[c] += s;
+      }
+      float4 *dst = reinterpret_cast<float4 *>(pdx + ((size_t)n * P + p) * C1);
+      dst[0] = make_float4(dx[0], dx[1], dx[2], dx[3]);
+      dst[1] = make_float4(dx[4], dx[5], dx[6], dx[7]);
+    } else {
+#pragma unroll
+      for (int c = 0; c < C1; ++c) x[c] = 0.f;
+#pragma unroll
+      for (int l = 0; l < L; ++l) { a[l] = 0.f; dz[l] = 0.f; ds[l] = 0.f; }
+    }
+    __syncthreads();  // previous chunk fully consumed
+    {
+      float4 *d = reinterpret_cast<float4 *>(sx + tid * SX);
+      d[0] = make_float4(x[0], x[1], x[2], x[3]);
+      d[1] = make_float4(x[4], x[5], x[6], x[7]);
+      float4 *da = reinterpret_cast<float4 *>(sa + tid * SA);
+      float4 *dd = reinterpret_cast<float4 *>(sdz + tid * SA);
+      float4 *de = reinterpret_cast<float4 *>(sds + tid * SA);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        da[q] = make_float4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
+        dd[q] = make_float4(dz[4 * q], dz[4 * q + 1], dz[4 * q + 2], dz[4 * q + 3]);
+        de[q] = make_float4(ds[4 * q], ds[4 * q + 1], ds[4 * q + 2], ds[4 * q + 3]);
+      }
+    }
+    __syncthreads();
+    // lanes j<16 own column dz[j]: x (x) dz[j], a[0..7] (x) dz[j], sum dz[j]
+    // lanes j>=16 own column ds[j-16]: x (x) ds[j-16], and a[8..15] (x) dz[j-16]
+    const int aoff = lo ? 0 : 8;
+#pragma unroll 4
+    for (int m = 0; m < 32; ++m) {
+      const int q = pg + 8 * m;
+      const float wdz = sdz[q * SA + jj];
+      const float wds = sds[q * SA + jj];
+      const float w = lo ? wdz : wds;
+      const float4 x0 = *reinterpret_cast<const float4 *>(sx + q * SX);
+      const float4 x1 = *reinterpret_cast<const float4 *>(sx + q * SX + 4);
+      const float4 a0 = *reinterpret_cast<const float4 *>(sa + q * SA + aoff);
+      const float4 a1 = *reinterpret_cast<const float4 *>(sa + q * SA + aoff + 4);
+      ax[0] += x0.x * w; ax[1] += x0.y * w; ax[2] += x0.z * w; ax[3] += x0.w * w;
+      ax[4] += x1.x * w; ax[5] += x1.y * w; ax[6] += x1.z * w; ax[7] += x1.w * w;
+      aa[0] += a0.x * wdz; aa[1] += a0.y * wdz; aa[2] += a0.z * wdz; aa[3] += a0.w * wdz;
+      aa[4] += a1.x * wdz; aa[5] += a1.y * wdz; aa[6] += a1.z * wdz; aa[7] += a1.w * wdz;
+      ab += wdz;
+    }
+  }
+  // cross pixel-group reduction: 8 groups x 32 columns x 17 values
+  __syncthreads();
+  {
+    float *r = sred + (pg * 32 + j) * 18;
+#pragma unroll
+    for (int c = 0; c < C1; ++c) r[c] = ax[c];
+#pragma unroll
+    for (int l = 0; l < 8; ++l) r[8 + l] = aa[l];
+    r[16] = ab;
+  }
+  __syncthreads();
+  float *srow = gslab + (size_t)n * GS_STRIDE;
+  for (int o = tid; o < 32 * 17; o += TPB) {
+    const int col = o / 17, k = o % 17;
+    float s = 0.f;
+#pragma unroll
+    for (int gq = 0; gq < 8; ++gq) s += sred[(gq * 32 + col) * 18 + k];
+    const int cj = col & 15;
+    if (k < 8) {
+      if (col < 16) srow[C1 * D + k * C2 + cj] = s;  // gWd_n[c=k][c2=cj]
+      else sG[k * L + cj] = s;                       // G[c=k][l=cj]
+    } else if (k < 16) {
+      const int l = (col < 16 ? 0 : 8) + (k - 8);
+      dv_out[((size_t)n * L + l) * C2 + cj] = s;     // dv[l][c2=cj]
+    } else if (col < 16) {
+      srow[C1 * D + C1 * C2 + cj] = s;               // gbd_n[c2]
+    }
+  }
+  __syncthreads();
+  // token key delta dk[l][d] = sum_c G[c][l] Wq[c][d]  (t_q_delta = x_q^T . softmax_delta, :183-184)
+  for (int o = tid; o < L * D; o += TPB) {
+    const int l = o / D, d = o % D;
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < C1; ++c) s += sG[c * L + l] * Wq[c * D + d];
+    dk_out[(size_t)n * L * D + o] = s;
+  }
+  // gWq_n[c][d] = sum_l G[c][l] k[l][d]  (linear1 grad = x^T . (softmax_delta . t_q), :180, 205-206)
+  for (int o = tid; o < C1 * D; o += TPB) {
+    const int c = o / D, d = o % D;
+    float s = 0.f;
+#pragma unroll
+    for (int l = 0; l < L; ++l) s += sG[c * L + l] * kk[l * D + d];
+    srow[o] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// ProjectorLayer::backward, token side (reference projector_layer.hpp:186-202): Dense backward of
+// linear3 (values) and linear2 (keys) over the N*L token rows.
+//   gWv = o^T dv, gbv = sum dv, gWk = o^T dk, token delta = dv.Wv^T + dk.Wk^T
+// Per-workgroup partials: gWk[D*D] | gWv[D*C2] | gbv[C2]  (PT_STRIDE floats), summed afterwards.
+// ---------------------------------------------------------------------------------------------
+constexpr int PT_STRIDE = D * D + D * C2 + C2;  // 1552
+__global__ __launch_bounds__(TPB) void k_projtok_bwd(const float *__restrict__ o, const float *__restrict__ dv,
+                                                     const float *__restrict__ dk, const float *__restrict__ Wv,
+                                                     const float *__restrict__ Wk, float *__restrict__ pdt,
+                                                     float *__restrict__ scratch, long rows) {
+  __shared__ float so[RB][D + 1], sdk[RB][D + 1], sdv[RB][C2 + 1];
+  __shared__ float sWk[D * D], sWv[D * C2];
+  const int tid = threadIdx.x;
+  const long r0 = (long)blockIdx.x * RB;
+  const int cnt = (int)min((long)RB, rows - r0);
+  for (int i = tid; i < RB * D; i += TPB) {
+    const int r = i / D, d = i % D;
+    const bool ok = r < cnt;
+    so[r][d] = ok ? o[(r0 + r) * D + d] : 0.f;
+    sdk[r][d] = ok ? dk[(r0 + r) * D + d] : 0.f;
+  }
+  for (int i = tid; i < RB * C2; i += TPB) {
+    const int r = i / C2, c = i % C2;
+    sdv[r][c] = r < cnt ? dv[(r0 + r) * C2 + c] : 0.f;
+  }
+  for (int i = tid; i < D * D; i += TPB) sWk[i] = Wk[i];
+  for (int i = tid; i < D * C2; i += TPB) sWv[i] = Wv[i];
+  __syncthreads();
+  float *row = scratch + (size_t)blockIdx.x * PT_STRIDE;
+  for (int idx = tid; idx < D * D; idx += TPB) {
+    const int d = idx / D, e = idx % D;
+    float s = 0.f;
+    for (int r = 0; r < RB; ++r) s += so[r][d] * sdk[r][e];
+    row[idx] = s;
+  }
+  for (int idx = tid; idx < D * C2; idx += TPB) {
+    const int d = idx / C2, c = idx % C2;
+    float s = 0.f;
+    for (int r = 0; r < RB; ++r) s += so[r][d] * sdv[r][c];
+    row[D * D + idx] = s;
+  }
+  if (tid < C2) {
+    float s = 0.f;
+    for (int r = 0; r < RB; ++r) s += sdv[r][tid];
+    row[D * D + D * C2 + tid] = s;
+  }
+  for (int idx = tid; idx < RB * D; idx += TPB) {
+    const int r = idx / D, d = idx % D;
+    if (r < cnt) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int c = 0; c < C2; ++c) s1 += sdv[r][c] * sWv[d * C2 + c];
+#pragma unroll 8
+      for (int e = 0; e < D; ++e) s2 += sdk[r][e] * sWk[d * D + e];
+      pdt[(r0 + r) * D + d] = s1 + s2;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// TransformerLayer::backward, step A (reference layers/transformer_layer.hpp:142-161):
+//   d0 = last_output - targets  with targets = projector token delta (visual_transformer.hpp:156-157)
+//   partial sums of the second BatchNorm1D backward.
+// Also the tokenizer's linear2 input delta dT0 = token_delta . W2tok^T (tokenizer.hpp:73-75), which
+// reads the same rows.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void k_tr_bwd_a(const float *__restrict__ o, const float *__restrict__ pdt,
+                                                  const float *__restrict__ s2, const float *__restrict__ st2,
+                                                  const float *__restrict__ W2tok, float *__restrict__ part,
+                                                  float *__restrict__ dT0, long rows) {
+  __shared__ float sd[RB][D + 1], sxh[RB][D + 1], sp[RB][D + 1];
+  const int tid = threadIdx.x;
+  const long r0 = (long)blockIdx.x * RB;
+  const int cnt = (int)min((long)RB, rows - r0);
+  for (int i = tid; i < RB * D; i += TPB) {
+    const int r = i / D, d = i % D;
+    const bool ok = r < cnt;
+    const float pv = ok ? pdt[(r0 + r) * D + d] : 0.f;
+    sp[r][d] = pv;
+    sd[r][d] = ok ? o[(r0 + r) * D + d] - pv : 0.f;
+    sxh[r][d] = ok ? (s2[(r0 + r) * D + d] - st2[d]) * st2[D + d] : 0.f;
+  }
+  __syncthreads();
+  if (tid < 2 * D) {
+    const int d = tid % D;
+    float s = 0.f;
+    if (tid < D) for (int r = 0; r < RB; ++r) s += sd[r][d];
+    else for (int r = 0; r < RB; ++r) s += sd[r][d] * sxh[r][d];
+    part[(size_t)blockIdx.x * 2 * D + tid] = s;
+  }
+  for (int idx = tid; idx < RB * C1; idx += TPB) {
+    const int r = idx / C1, c = idx % C1;
+    if (r < cnt) {
+      float s = 0.f;
+#pragma unroll 8
+      for (int d = 0; d < D; ++d) s += sp[r][d] * W2tok[c * D + d];
+      dT0[(r0 + r) * C1 + c] = s;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// TransformerLayer::backward, step B (reference transformer_layer.hpp:161-189):
+//   ds2 = BN2.backward(d0);  linear2 backward (its cached input is relu(hdn));
+//   linear1 backward WITHOUT the ReLU derivative (:174-181);  da = dh.W1^T + ds2;
+//   partial sums of the first BatchNorm1D backward.
+// Per-workgroup partials: gW1[D*D] | gb1[D] | gW2[D*D] | gb2[D]  (FF_STRIDE, arena order).
+// ---------------------------------------------------------------------------------------------
+constexpr int FF_STRIDE = 2 * (D * D + D);  // 2112
+__global__ __launch_bounds__(TPB) void k_tr_bwd_b(const float *__restrict__ o, const float *__restrict__ pdt,
+                                                  const float *__restrict__ coef2, const float *__restrict__ hdn,
+                                                  const float *__restrict__ a, const float *__restrict__ tok,
+                                                  const float *__restrict__ st1, const float *__restrict__ W1,
+                                                  const float *__restrict__ W2, float *__restrict__ ds2_out,
+                                                  float *__restrict__ da_out, float *__restrict__ scratch,
+                                                  float *__restrict__ part, long rows) {
+  __shared__ float sds2[RB][D + 1], srl[RB][D + 1], sa[RB][D + 1], sdh[RB][D + 1];
+  __shared__ float sW1[D * D], sW2[D * D];
+  const int tid = threadIdx.x;
+  const long r0 = (long)blockIdx.x * RB;
+  const int cnt = (int)min((long)RB, rows - r0);
+  for (int i = tid; i < RB * D; i += TPB) {
+    const int r = i / D, d = i % D;
+    const bool ok = r < cnt;
+    const float d0 = ok ? o[(r0 + r) * D + d] - pdt[(r0 + r) * D + d] : 0.f;
+    const float v = ok ? d0 * coef2[d] + coef2[D + d] : 0.f;
+    sds2[r][d] = v;
+    if (ok) ds2_out[(r0 + r) * D + d] = v;
+    const float hv = ok ? hdn[(r0 + r) * D + d] : 0.f;
+    srl[r][d] = hv > 0.f ? hv : 0.f;
+    sa[r][d] = ok ? a[(r0 + r) * D + d] : 0.f;
+  }
+  for (int i = tid; i < D * D; i += TPB) {
+    sW1[i] = W1[i];
+    sW2[i] = W2[i];
+  }
+  __syncthreads();
+  float *row = scratch + (size_t)blockIdx.x * FF_STRIDE;
+  // dh = ds2 . W2^T
+  for (int idx = tid; idx < RB * D; idx += TPB) {
+    const int r = idx / D, i = idx % D;
+    float s = 0.f;
+#pragma unroll 8
+    for (int e = 0; e < D; ++e) s += sds2[r][e] * sW2[i * D + e];
+    sdh[r][i] = s;
+  }
+  // gW2 = relu(hdn)^T ds2 ; gb2 = sum ds2
+  for (int idx = tid; idx < D * D; idx += TPB) {
+    const int i = idx / D, e = idx % D;
+    float s = 0.f;
+    for (int r = 0; r < RB; ++r) s += srl[r][i] * sds2[r][e];
+    row[D * D + D + idx] = s;
+  }
+  if (tid < D) {
+    float s = 0.f;
+    for (int r = 0; r < RB; ++r) s += sds2[r][tid];
+    row[2 * D * D + D + tid] = s;
+  }
+  __syncthreads();
+  // gW1 = a^T dh ; gb1 = sum dh
+  for (int idx = tid; idx < D * D; idx += TPB) {
+    const int i = idx / D, e = idx % D;
+    float s = 0.f;
+    for (int r = 0; r < RB; ++r) s += sa[r][i] * sdh[r][e];
+    row[idx] = s;
+  }
+  if (tid < D) {
+    float s = 0.f;
+    for (int r = 0; r < RB; ++r) s += sdh[r][tid];
+    row[D * D + tid] = s;
+  }
+  // da = dh . W1^T + ds2   (reuse srl for da)
+  __syncthreads();
+  for (int idx = tid; idx < RB * D; idx += TPB) {
+    const int r = idx / D, i = idx % D;
+    float s = 0.f;
+#pragma unroll 8
+    for (int e = 0; e < D; ++e) s += sdh[r][e] * sW1[i * D + e];
+    s += sds2[r][i];
+    srl[r][i] = (r < cnt) ? s : 0.f;
+    if (r < cnt) da_out[(r0 + r) * D + i] = s;
+  }
+  __syncthreads();
+  if (tid < 2 * D) {
+    const int d = tid % D;
+    float s = 0.f;
+    if (tid < D) {
+      for (int r = 0; r < cnt; ++r) s += srl[r][d];
+    } else {
+      for (int r = 0; r < cnt; ++r) s += srl[r][d] * ((tok[(r0 + r) * D + d] - st1[d]) * st1[D + d]);
+    }
+    part[(size_t)blockIdx.x * 2 * D + tid] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// TransformerLayer::backward, step C (reference transformer_layer.hpp:189-200 and the first part
+// of MultiHeadAttention::backward, multi_head_attention.hpp:131-152):
+//   dr = BN1.backward(da);  dc = dr . Wo^T  (delta of the zero "concat");
+//   per head q = X.Wq, k = X.Wk, v = X.Wv recomputed from the layer input X = token rows.
+// qkv layout: three [rows][D] matrices (q | k | v), head h in columns h*HD..h*HD+HD-1.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void k_tr_bwd_c(const float *__restrict__ da, const float *__restrict__ coef1,
+                                                  const float *__restrict__ Wo, const float *__restrict__ tok,
+                                                  const float *__restrict__ Wqkv, float *__restrict__ dr_out,
+                                                  float *__restrict__ dc, float *__restrict__ qkv, long rows) {
+  __shared__ float sdr[RB][D + 1], sx[RB][D + 1];
+  __shared__ float sWo[D * D], sW[3 * D * D];  // sW[m][i][h*HD+e] = W_{m,h}[i][e]
+  const int tid = threadIdx.x;
+  const long r0 = (long)blockIdx.x * RB;
+  const int cnt = (int)min((long)RB, rows - r0);
+  for (int i = tid; i < RB * D; i += TPB) {
+    const int r = i / D, d = i % D;
+    const bool ok = r < cnt;
+    const float v = ok ? da[(r0 + r) * D + d] * coef1[d] + coef1[D + d] : 0.f;
+    sdr[r][d] = v;
+    if (ok) dr_out[(r0 + r) * D + d] = v;
+    sx[r][d] = ok ? tok[(r0 + r) * D + d] : 0.f;
+  }
+  for (int i = tid; i < D * D; i += TPB) sWo[i] = Wo[i];
+  // arena order: q0,k0,v0,q1,k1,v1, each [D][HD]
+  for (int i = tid; i < 3 * D * D; i += TPB) {
+    const int m = i / (D * D), rem = i % (D * D), ii = rem / D, col = rem % D, h = col / HD, e = col % HD;
+    sW[i] = Wqkv[(size_t)(h * 3 + m) * D * HD + ii * HD + e];
+  }
+  __syncthreads();
+  for (int idx = tid; idx < RB * D; idx += TPB) {
+    const int r = idx / D, jx = idx % D;
+    if (r < cnt) {
+      float s = 0.f;
+#pragma unroll 8
+      for (int i = 0; i < D; ++i) s += sdr[r][i] * sWo[jx * D + i];
+      dc[(r0 + r) * D + jx] = s;
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        float t = 0.f;
+#pragma unroll 8
+        for (int i = 0; i < D; ++i) t += sx[r][i] * sW[m * D * D + i * D + jx];
+        qkv[(size_t)m * rows * D + (r0 + r) * D + jx] = t;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// MultiHeadAttention::backward, per-head part (reference layers/multi_head_attention.hpp:139-181).
+// The layer's "batch" axis is the token index and its "sequence" axis is the mini-batch
+// (permute is a relabel, tensor_cpu.hpp:719-747): group b = rows b*T .. b*T+T-1 of the flat token
+// matrix, T = N.  Only the weight gradients survive (the input delta is discarded,
+// visual_transformer.hpp:160), so the attention backward is restated row-wise:
+//   scores[i][j] = K_i.Q_j / sqrt(d);  attn = softmax_j;  dattn[i][j] = dhead_i . V_j
+//   dot_i = sum_j dattn*attn;  dsc = attn * (dattn - dot_i)      (no 1/sqrt(d) in backward, :165-170)
+//   Y_i = sum_j attn[i][j] X_j;  Z_i = sum_j dsc[i][j] X_j
+//   gWv = sum_i Y_i^T dhead_i;  gWq = sum_i Z_i^T K_i;  gWk = sum_i X_i^T (Z_i Wq)
+// which equals X^T dV, X^T dQ, X^T dK of the reference.  One workgroup = 64 rows i of one
+// (group, head); wave w sweeps the j range w*T/4..; partial sums are merged through LDS.
+// Partials per workgroup: gq[D*HD] | gk[D*HD] | gv[D*HD]  (MH_STRIDE floats).
+// ---------------------------------------------------------------------------------------------
+constexpr int MH_STRIDE = 3 * D * HD;  // 1536
+__global__ __launch_bounds__(TPB) void k_mha_bwd(const float *__restrict__ qkv, const float *__restrict__ dc,
+                                                 const float *__restrict__ tok, const float *__restrict__ Wqkv,
+                                                 float *__restrict__ scratch, int T, long rows) {
+  __shared__ float sred[NW - 1][64][2 * D + 3];  // waves 1..3, per row: Y~[D], W~[D], s, t
+  __shared__ float smax[NW][64];
+  __shared__ float sout[MH_STRIDE];
+  const int tiles = (T + 63) / 64;
+  const int tile = blockIdx.x % tiles, h = (blockIdx.x / tiles) % HEADS, bgrp = blockIdx.x / (tiles * HEADS);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = tile * 64 + lane;
+  const bool ok = i < T;
+  const long gbase = (long)bgrp * T;
+  const long ri = gbase + (ok ? i : 0);
+  const float *__restrict__ Qm = qkv, *__restrict__ Km = qkv + rows * D, *__restrict__ Vm = qkv + 2 * rows * D;
+  const float scale = 1.0f / sqrtf((float)HD);
+  float Ki[HD], dh[HD];
+#pragma unroll
+  for (int e = 0; e < HD; ++e) {
+    Ki[e] = Km[ri * D + h * HD + e];
+    dh[e] = dc[ri * D + h * HD + e];
+  }
+  const int jchunk = (T + NW - 1) / NW;
+  const int j0 = wave * jchunk, j1 = min(T, j0 + jchunk);
+  // pass 1: row maximum of the scaled scores over this wave's j range, merged across waves
+  float mx = -INFINITY;
+  for (int j = j0; j < j1; ++j) {
+    const float *__restrict__ qj = Qm + (gbase + j) * D + h * HD;
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < HD; ++e) s += Ki[e] * qj[e];
+    mx = fmaxf(mx, s * scale);
+  }
+  smax[wave][lane] = mx;
+  __syncthreads();
+#pragma unroll
+  for (int w = 0; w < NW; ++w) mx = fmaxf(mx, smax[w][lane]);
+  // pass 2: unnormalised sums
+  float Yt[D], Wt[D], ssum = 0.f, tsum = 0.f;
+#pragma unroll
+  for (int d = 0; d < D; ++d) { Yt[d] = 0.f; Wt[d] = 0.f; }
+  for (int j = j0; j < j1; ++j) {
+    const float *__restrict__ qj = Qm + (gbase + j) * D + h * HD;
+    const float *__restrict__ vj = Vm + (gbase + j) * D + h * HD;
+    const float *__restrict__ xj = tok + (gbase + j) * D;
+    float s = 0.f, da = 0.f;
+#pragma unroll
+    for (int e = 0; e < HD; ++e) {
+      s += Ki[e] * qj[e];
+      da += dh[e] * vj[e];
+    }
+    const float ev = expf(s * scale - mx);
+    const float ed = ev * da;
+    ssum += ev;
+    tsum += ed;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      Yt[d] += ev * xj[d];
+      Wt[d] += ed * xj[d];
+    }
+  }
+  if (wave > 0) {
+    float *r = sred[wave - 1][lane];
+#pragma unroll
+    for (int d = 0; d < D; ++d) { r[d] = Yt[d]; r[D + d] = Wt[d]; }
+    r[2 * D] = ssum;
+    r[2 * D + 1] = tsum;
+  }
+  __syncthreads();
+  // wave 0 merges the four j ranges and finishes its 64 rows (small epilogue)
+  if (wave == 0) {
+    float Y[D], Z[D];
+    float s = ssum, t = tsum;
+#pragma unroll
+    for (int d = 0; d < D; ++d) { Y[d] = Yt[d]; Z[d] = Wt[d]; }
+#pragma unroll
+    for (int w = 0; w < NW - 1; ++w) {
+      const float *r = sred[w][lane];
+#pragma unroll
+      for (int d = 0; d < D; ++d) { Y[d] += r[d]; Z[d] += r[D + d]; }
+      s += r[2 * D];
+      t += r[2 * D + 1];
+    }
+    const float invs = ok ? 1.0f / s : 0.f;
+    const float dot = t * invs;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      Y[d] = Y[d] * invs;
+      Z[d] = Z[d] * invs - dot * Y[d];
+    }
+    // dK_i = Z_i . Wq_h   (delta_scores . query with query = X.Wq)
+    const float *__restrict__ Wq_h = Wqkv + (size_t)(h * 3 + 0) * D * HD;
+    float dK[HD], Xi[D];
+#pragma unroll
+    for (int e = 0; e < HD; ++e) dK[e] = 0.f;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      Xi[d] = ok ? tok[ri * D + d] : 0.f;
+#pragma unroll
+      for (int e = 0; e < HD; ++e) dK[e] += Z[d] * Wq_h[d * HD + e];
+    }
+    if (!ok) {
+#pragma unroll
+      for (int e = 0; e < HD; ++e) { Ki[e] = 0.f; dh[e] = 0.f; dK[e] = 0.f; }
+    }
+    // outer products summed over the 64 rows with the transposing butterfly: 4 rows of the
+    // [D][HD] gradient (64 values) per call
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+#pragma unroll
+      for (int blk = 0; blk < D / 4; ++blk) {
+        float acc[64];
+#pragma unroll
+        for (int dd = 0; dd < 4; ++dd)
+#pragma unroll
+          for (int e = 0; e < HD; ++e) {
+            const int d = blk * 4 + dd;
+            acc[dd * HD + e] = (m == 0) ? Z[d] * Ki[e] : (m == 1) ? Xi[d] * dK[e] : Y[d] * dh[e];
+          }
+        wave_xreduce<64>(acc);
+        sout[m * D * HD + blk * 64 + lane] = acc[0];
+      }
+    }
+  }
+  __syncthreads();
+  float *row = scratch + (size_t)blockIdx.x * MH_STRIDE;
+  for (int idx = threadIdx.x; idx < MH_STRIDE; idx += TPB) row[idx] = sout[idx];
+}
+
+// Sums the per-workgroup attention partials into the six per-head gradient tensors
+// (arena order q0,k0,v0,q1,k1,v1).  blocks are ordered (group, head, tile).
+__global__ __launch_bounds__(TPB) void k_mha_reduce(const float *__restrict__ scratch, int groups, int tiles,
+                                                    float *__restrict__ gout) {
+  const int idx = blockIdx.x * TPB + threadIdx.x;  // over HEADS * MH_STRIDE
+  if (idx >= HEADS * MH_STRIDE) return;
+  const int h = idx / MH_STRIDE, k = idx % MH_STRIDE;
+  float s = 0.f;
+  for (int b = 0; b < groups; ++b)
+    for (int t = 0; t < tiles; ++t) s += scratch[(size_t)((b * HEADS + h) * tiles + t) * MH_STRIDE + k];
+  gout[idx] = s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// FilterTokenizer::backward2 (reference layers/tokenizer.hpp:50-107).  Per pixel:
+//   dA[l] = dT0[l] . x;  dx = A . dT0;  dS = A * (dA - sum_l dA*A)   (softmax_backward reduces over
+//   the token axis although the forward softmax ran over pixels, tokenizer.hpp:36,91)
+//   dx += dS . W1^T;  dx += projector input delta                         (tokenizer.hpp:97,105)
+// The tokenizer's own Dense gradients are never applied by the reference (no optimizer is ever
+// attached to them, tokenizer.hpp:18-19) and are not computed.  Fused: partial sums of the
+// BatchNorm2D backward over the result (vit_cnn.hpp:236-238).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void k_tokenizer_bwd(const float *__restrict__ conv, const float *__restrict__ st,
+                                                       const float *__restrict__ g, const float *__restrict__ b,
+                                                       const float *__restrict__ tokA, const float *__restrict__ dT0,
+                                                       const float *__restrict__ W1, const float *__restrict__ pdx,
+                                                       float *__restrict__ dy, float *__restrict__ part, int P) {
+  __shared__ float red[NW * 2 * C1];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const float *__restrict__ dt = dT0 + (size_t)n * L * C1;
+  float s[2 * C1];
+#pragma unroll
+  for (int c = 0; c < 2 * C1; ++c) s[c] = 0.f;
+  for (int p = tid; p < P; p += TPB) {
+    float x[C1], xh[C1], A[L];
+    load_x_raw(conv, (size_t)n * P + p, st, g, b, x, xh);
+    const float4 *as = reinterpret_cast<const float4 *>(tokA + ((size_t)n * P + p) * L);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 av = as[q];
+      A[4 * q] = av.x; A[4 * q + 1] = av.y; A[4 * q + 2] = av.z; A[4 * q + 3] = av.w;
+    }
+    float dA[L], dot = 0.f;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      float t = 0.f;
+#pragma unroll
+      for (int c = 0; c < C1; ++c) t += dt[l * C1 + c] * x[c];
+      dA[l] = t;
+      dot += t * A[l];
+    }
+    const float4 *ps = reinterpret_cast<const float4 *>(pdx + ((size_t)n * P + p) * C1);
+    const float4 p0 = ps[0], p1 = ps[1];
+    const float pin[C1] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+    float dx[C1];
+#pragma unroll
+    for (int c = 0; c < C1; ++c) {
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int l = 0; l < L; ++l) {
+        t1 += A[l] * dt[l * C1 + c];
+        t2 += (A[l] * (dA[l] - dot)) * W1[c * L + l];
+      }
+      dx[c] = (t1 + t2) + pin[c];
+      s[c] += dx[c];
+      s[C1 + c] += dx[c] * xh[c];
+    }
+    float4 *dst = reinterpret_cast<float4 *>(dy + ((size_t)n * P + p) * C1);
+    dst[0] = make_float4(dx[0], dx[1], dx[2], dx[3]);
+    dst[1] = make_float4(dx[4], dx[5], dx[6], dx[7]);
+  }
+  block_sum<2 * C1>(s, red);
+  if (tid < 2 * C1) part[(size_t)n * 2 * C1 + tid] = s[tid];
+}
+
+// ---------------------------------------------------------------------------------------------
+// BatchNorm2D backward apply + Conv2DLayer::backward gradients (reference
+// layers/conv2d_layer.hpp:115-147): gb[co] = sum delta, gW[co][ci][kh][kw] = sum xpad * delta.
+// The conv input delta (:150-190) is never consumed (first layer) and is not computed.
+// One workgroup per image and input channel pass; per-image partials [C1*Ci*9 | C1].
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void k_conv_wgrad(const float *__restrict__ X, const float *__restrict__ dy,
+                                                    const float *__restrict__ coef, float *__restrict__ gslab, int Ci,
+                                                    int H, int W, int ld) {
+  extern __shared__ float sm[];
+  const int P = H * W, TH = H + 2, TW = W + 2;
+  const int tile_n = Ci * TH * TW;
+  float *tile = sm;
+  float *red = sm + ((tile_n + 3) & ~3);  // NW*128
+  float *sout = red + NW * 128;           // 128
+  const int n = blockIdx.x, tid = threadIdx.x;
+  for (int i = tid; i < tile_n; i += TPB) {
+    const int ci = i / (TH * TW), r = i % (TH * TW), hh = r / TW - 1, ww = r % TW - 1;
+    float v = 0.f;
+    if (hh >= 0 && hh < H && ww >= 0 && ww < W) v = X[((size_t)(n * Ci + ci) * H + hh) * W + ww];
+    tile[i] = v;
+  }
+  __syncthreads();
+  float *row = gslab + (size_t)n * ld;
+  for (int ci = 0; ci < Ci; ++ci) {
+    float acc[128];
+#pragma unroll
+    for (int k = 0; k < 128; ++k) acc[k] = 0.f;
+    for (int p = tid; p < P; p += TPB) {
+      const int h = p / W, w = p % W;
+      const float4 *ds = reinterpret_cast<const float4 *>(dy + ((size_t)n * P + p) * C1);
+      const float4 d0 = ds[0], d1 = ds[1];
+      const float draw[C1] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+      float dcv[C1];
+#pragma unroll
+      for (int co = 0; co < C1; ++co) {
+        dcv[co] = draw[co] * coef[co] + coef[C1 + co];
+        acc[72 + co] += dcv[co];
+      }
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const float xv = tile[(ci * TH + h + kh) * TW + w + kw];
+#pragma unroll
+          for (int co = 0; co < C1; ++co) acc[co * 9 + kh * 3 + kw] += xv * dcv[co];
+        }
+    }
+    block_xreduce<128>(acc, red, sout);
+    if (tid < 72) {
+      const int co = tid / 9, k = tid % 9;
+      row[(co * Ci + ci) * 9 + k] = sout[tid];
+    }
+    if (ci == 0 && tid < C1) row[C1 * Ci * 9 + tid] = sout[72 + tid];
+    __syncthreads();
+  }
+}
+
+// update_weights + SGD::update (reference e.g. layers/dense_layer.hpp:102-112,
+// utils/optimizer.hpp:22-28):  g <- g * (1/divisor);  w <- w - g * lr.  Two roundings, as there.
+__global__ __launch_bounds__(TPB) void k_sgd(float *__restrict__ w, float *__restrict__ gr, int n, float lr,
+                                             float inv_div, int zero_grad) {
+  const int i = blockIdx.x * TPB + threadIdx.x;
+  if (i < n) {
+    const float gs = __fmul_rn(gr[i], inv_div);
+    w[i] = __fsub_rn(w[i], __fmul_rn(gs, lr));
+    if (zero_grad) gr[i] = 0.f;
+  }
+}
+
+// Textbook Adam (Kingma & Ba).  Not part of the reference: extension, parity unpinned.
+__global__ __launch_bounds__(TPB) void k_adam(float *__restrict__ w, float *__restrict__ gr, float *__restrict__ m1,
+                                              float *__restrict__ m2, int n, float lr, float b1, float b2, float eps,
+                                              float c1, float c2, float inv_div) {
+  const int i = blockIdx.x * TPB + threadIdx.x;
+  if (i < n) {
+    const float gq = gr[i] * inv_div;
+    const float a = b1 * m1[i] + (1.f - b1) * gq;
+    const float v = b2 * m2[i] + (1.f - b2) * gq * gq;
+    m1[i] = a;
+    m2[i] = v;
+    w[i] -= lr * (a / c1) / (sqrtf(v / c2) + eps);
+    gr[i] = 0.f;
+  }
+}
+
+// Generic DenseLayer::backward over a row matrix (reference layers/dense_layer.hpp:79-100) for
+// in, out <= 32: per-workgroup partial gW[in*out] | gb[out], and dX = dY W^T.
+__global__ __launch_bounds__(TPB) void k_dense_bwd_rows(const float *__restrict__ X, const float *__restrict__ Wm,
+                                                        const float *__restrict__ dY, float *__restrict__ dX,
+                                                        int accumulate, float *__restrict__ scratch, long rows, int in,
+                                                        int out, int relu_x, int ld) {
+  __shared__ float sx[RB][33], sdy[RB][33], sw[32 * 32];
+  const int tid = threadIdx.x;
+  const long r0 = (long)blockIdx.x * RB;
+  const int cnt = (int)min((long)RB, rows - r0);
+  for (int i = tid; i < RB * in; i += TPB) {
+    const int r = i / in, c = i % in;
+    float v = (r < cnt && X) ? X[(r0 + r) * in + c] : 0.f;
+    if (relu_x) v = v > 0.f ? v : 0.f;
+    sx[r][c] = v;
+  }
+  for (int i = tid; i < RB * out; i += TPB) {
+    const int r = i / out, c = i % out;
+    sdy[r][c] = r < cnt ? dY[(r0 + r) * out + c] : 0.f;
+  }
+  for (int i = tid; i < in * out; i += TPB) sw[i] = Wm[i];
+  __syncthreads();
+  if (scratch) {
+    float *row = scratch + (size_t)blockIdx.x * ld;
+    for (int idx = tid; idx < in * out; idx += TPB) {
+      const int i = idx / out, o = idx % out;
+      float s = 0.f;
+      for (int r = 0; r < RB; ++r) s += sx[r][i] * sdy[r][o];
+      row[idx] = s;
+    }
+    if (tid < out) {
+      float s = 0.f;
+      for (int r = 0; r < RB; ++r) s += sdy[r][tid];
+      row[in * out + tid] = s;
+    }
+  }
+  if (dX) {
+    for (int idx = tid; idx < RB * in; idx += TPB) {
+      const int r = idx / in, i = idx % in;
+      if (r < cnt) {
+        float s = 0.f;
+        for (int o = 0; o < out; ++o) s += sdy[r][o] * sw[i * out + o];
+        if (accumulate) dX[(r0 + r) * in + i] += s;
+        else dX[(r0 + r) * in + i] = s;
+      }
+    }
+  }
+}
+
+}  // namespace vt
+
+// ---------------------------------------------------------------------------------------------
+// extern "C" launchers
+// ---------------------------------------------------------------------------------------------
+using namespace vt;
+
+static int reduce_rows(const float *slab, long rows, int cols, int ld, float *out, hipStream_t s) {
+  hipLaunchKernelGGL(k_reduce_rows, dim3((cols + 63) / 64), dim3(1024), 0, s, slab, rows, cols, ld, out);
+  VT_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int vt_reduce_rows(const float *slab, long rows, int cols, int ld, float *out, vt_stream s) {
+  if (rows < 1 || cols < 1 || ld < cols) return VT_EINVAL;
+  return reduce_rows(slab, rows, cols, ld, out, (hipStream_t)s);
+}
+
+extern "C" int vt_head_bwd(const float *probs, const int *labels, const float *wfc, const unsigned char *pool_idx,
+                           const float *z, const float *pn_stat, const float *pn_gamma, const float *pn_beta,
+                           float *d_logits, float *du, float *part, int N, int H, int K, vt_stream s) {
+  if (N < 1 || H < 14 || H % 14 != 0 || H * H > PPT * TPB || K < 1 || K > KMAX) return VT_EUNSUPPORTED;
+  const size_t lds = (size_t)(H * H * C2 + NW * 2 * C2) * sizeof(float);
+  hipLaunchKernelGGL(k_head_bwd, dim3(N), dim3(TPB), lds, (hipStream_t)s, probs, labels, wfc, pool_idx, z, pn_stat,
+                     pn_gamma, pn_beta, d_logits, du, part, H, K);
+  VT_CHECK_LAUNCH();
+  return 0;
+}
+
+// scratch: at least ceil(N/32) * (Q*K + K) floats (unused when N <= 32).
+extern "C" int vt_fc_wgrad(const float *pooled, const float *d_logits, float *gw, float *gb, float *scratch, int N,
+                           int Q, int K, vt_stream s) {
+  if (N < 1 || Q < 1 || K < 1 || K > KMAX) return VT_EUNSUPPORTED;
+  const int chunk = 32, ns = (N + chunk - 1) / chunk, ld = Q * K + K;
+  const bool direct = (ns == 1 && gb == gw + (size_t)Q * K);
+  if (!direct && !scratch) return VT_EINVAL;
+  float *dst = direct ? gw : scratch;
+  hipLaunchKernelGGL(k_fc_wgrad, dim3((Q + TPB - 1) / TPB, ns), dim3(TPB), 0, (hipStream_t)s, pooled, d_logits, dst, N,
+                     Q, K, chunk, ld);
+  VT_CHECK_LAUNCH();
+  if (!direct) {
+    int rc = reduce_rows(scratch, ns, Q * K, ld, gw, (hipStream_t)s);
+    if (rc) return rc;
+    rc = reduce_rows(scratch + (size_t)Q * K, ns, K, ld, gb, (hipStream_t)s);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+extern "C" int vt_bn_bwd_finalize(const float *part, int nblocks, int C, long rows_total, const float *gamma,
+                                  const float *stat, const float *in_row0, float *ggamma, float *gbeta, float *coef,
+                                  vt_stream s) {
+  if (C < 1 || 2 * C > TPB || nblocks < 1 || rows_total < 1) return VT_EUNSUPPORTED;
+  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(1), dim3(TPB), 0, (hipStream_t)s, part, nblocks, C, rows_total, gamma,
+                     stat, in_row0, ggamma, gbeta, coef);
+  VT_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int vt_projector_bwd(const float *du, const float *pn_coef, const float *conv_out, const float *bn_stat,
+                                const float *bn_gamma, const float *bn_beta, const float *proj_a, const float *pk,
+                                const float *wq, const float *wd, float *pdx, float *dv, float *dk, float *gslab, int N,
+                                int P, vt_stream s) {
+  if (N < 1 || P < 1 || P > PPT * TPB) return VT_EUNSUPPORTED;
+  const size_t lds = (size_t)(TPB * SX + 3 * TPB * SA + 8 * 32 * 18 + C1 * L) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void *)k_proj_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_proj_bwd, dim3(N), dim3(TPB), lds, (hipStream_t)s, du, pn_coef, conv_out, bn_stat, bn_gamma,
+                     bn_beta, proj_a, pk, wq, wd, pdx, dv, dk, gslab, P);
+  VT_CHECK_LAUNCH();
+  return 0;
+}
+
+// Token side of the projector backward; scratch >= ceil(rows/64) * 1552 floats.
+extern "C" int vt_projector_tokens_bwd(const float *o, const float *dv, const float *dk, const float *wv,
+                                       const float *wk, float *pdt, float *g_wk_wv_bv, float *scratch, long rows,
+                                       vt_stream s) {
+  if (rows < 1) return VT_EINVAL;
+  const int nb = (int)((rows + RB - 1) / RB);
+  hipLaunchKernelGGL(k_projtok_bwd, dim3(nb), dim3(TPB), 0, (hipStream_t)s, o, dv, dk, wv, wk, pdt, scratch, rows);
+  VT_CHECK_LAUNCH();
+  return reduce_rows(scratch, nb, PT_STRIDE, PT_STRIDE, g_wk_wv_bv, (hipStream_t)s);
+}
+
+extern "C" int vt_transformer_bwd_a(const float *o, const float *pdt, const float *s2, const float *n2_stat,
+                                    const float *tok_w2, float *part, float *dT0, long rows, vt_stream s) {
+  if (rows < 1) return VT_EINVAL;
+  const int nb = (int)((rows + RB - 1) / RB);
+  hipLaunchKernelGGL(k_tr_bwd_a, dim3(nb), dim3(TPB), 0, (hipStream_t)s, o, pdt, s2, n2_stat, tok_w2, part, dT0, rows);
+  VT_CHECK_LAUNCH();
+  return 0;
+}
+
+// g_ffn: gradient block [gW1 | gb1 | gW2 | gb2] (2112 floats, arena order); scratch >= nb*2112.
+extern "C" int vt_transformer_bwd_b(const float *o, const float *pdt, const float *n2_coef, const float *hdn,
+                                    const float *a, const float *tok, const float *n1_stat, const float *w1,
+                                    const float *w2, float *ds2, float *da, float *g_ffn, float *scratch, float *part,
+                                    long rows, vt_stream s) {
+  if (rows < 1) return VT_EINVAL;
+  const int nb = (int)((rows + RB - 1) / RB);
+  hipLaunchKernelGGL(k_tr_bwd_b, dim3(nb), dim3(TPB), 0, (hipStream_t)s, o, pdt, n2_coef, hdn, a, tok, n1_stat, w1, w2,
+                     ds2, da, scratch, part, rows);
+  VT_CHECK_LAUNCH();
+  return reduce_rows(scratch, nb, FF_STRIDE, FF_STRIDE, g_ffn, (hipStream_t)s);
+}
+
+extern "C" int vt_transformer_bwd_c(const float *da, const float *n1_coef, const float *wo, const float *tok,
+                                    const float *wqkv, float *dr, float *dc, float *qkv, long rows, vt_stream s) {
+  if (rows < 1) return VT_EINVAL;
+  const int nb = (int)((rows + RB - 1) / RB);
+  hipLaunchKernelGGL(k_tr_bwd_c, dim3(nb), dim3(TPB), 0, (hipStream_t)s, da, n1_coef, wo, tok, wqkv, dr, dc, qkv, rows);
+  VT_CHECK_LAUNCH();
+  return 0;
+}
+
+// g_qkv: [q0 | k0 | v0 | q1 | k1 | v1] gradients (arena order); scratch >= L*HEADS*ceil(N/64)*1536.
+extern "C" int vt_mha_bwd(const float *qkv, const float *dc, const float *tok, const float *wqkv, float *g_qkv,
+                          float *scratch, int N, int groups, vt_stream s) {
+  if (N < 1 || groups < 1) return VT_EINVAL;
+  const int tiles = (N + 63) / 64;
+  const long rows = (long)N * groups;
+  hipLaunchKernelGGL(k_mha_bwd, dim3(groups * HEADS * tiles), dim3(TPB), 0, (hipStream_t)s, qkv, dc, tok, wqkv, scratch,
+                     N, rows);
+  VT_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_mha_reduce, dim3((HEADS * MH_STRIDE + TPB - 1) / TPB), dim3(TPB), 0, (hipStream_t)s, scratch,
+                     groups, tiles, g_qkv);
+  VT_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int vt_tokenizer_bwd(const float *conv_out, const float *bn_stat, const float *bn_gamma, const float *bn_beta,
+                                const float *tok_A, const float *dT0, const float *w1, const float *pdx, float *dy,
+                                float *part, int N, int P, vt_stream s) {
+  if (N < 1 || P < 1 || P > PPT * TPB) return VT_EUNSUPPORTED;
+  hipLaunchKernelGGL(k_tokenizer_bwd, dim3(N), dim3(TPB), 0, (hipStream_t)s, conv_out, bn_stat, bn_gamma, bn_beta,
+                     tok_A, dT0, w1, pdx, dy, part, P);
+  VT_CHECK_LAUNCH();
+  return 0;
+}
+
+// gslab: N rows of ld >= C1*Ci*9 + C1 floats.
+extern "C" int vt_conv3x3_wgrad(const float *x, const float *dy, const float *bn_coef, float *gslab, int N, int Ci,
+                                int H, int W, vt_stream s) {
+  if (N < 1 || Ci < 1 || H * W > PPT * TPB) return VT_EUNSUPPORTED;
+  const int ld = C1 * Ci * 9 + C1;
+  const size_t lds = (size_t)(((Ci * (H + 2) * (W + 2) + 3) & ~3) + NW * 128 + 128) * sizeof(float);
+  if (lds > 64 * 1024) return VT_EUNSUPPORTED;
+  hipLaunchKernelGGL(k_conv_wgrad, dim3(N), dim3(TPB), lds, (hipStream_t)s, x, dy, bn_coef, gslab, Ci, H, W, ld);
+  VT_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int vt_sgd_update(float *w, float *g, int n, float lr, float divisor, int zero_grad, vt_stream s) {
+  if (n < 1 || divisor == 0.f) return VT_EINVAL;
+  hipLaunchKernelGGL(k_sgd, dim3((n + TPB - 1) / TPB), dim3(TPB), 0, (hipStream_t)s, w, g, n, lr, 1.0f / divisor,
+                     zero_grad);
+  VT_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int vt_adam_update(float *w, float *g, float *m1, float *m2, int n, float lr, float beta1, float beta2,
+                              float eps, int step, float divisor, vt_stream s) {
+  if (n < 1 || step < 1 || divisor == 0.f) return VT_EINVAL;
+  const float c1 = 1.f - powf(beta1, (float)step), c2 = 1.f - powf(beta2, (float)step);
+  hipLaunchKernelGGL(k_adam, dim3((n + TPB - 1) / TPB), dim3(TPB), 0, (hipStream_t)s, w, g, m1, m2, n, lr, beta1, beta2,
+                     eps, c1, c2, 1.0f / divisor);
+  VT_CHECK_LAUNCH();
+  return 0;
+}
+
+// scratch >= ceil(rows/64) * (in*out + out) floats when gW is requested.
+extern "C" int vt_dense_bwd_rows(const float *X, const float *W, const float *dY, float *gW, float *gb, float *dX,
+                                 int accumulate_dx, float *scratch, long rows, int in, int out, int relu_x,
+                                 vt_stream s) {
+  if (rows < 1 || in < 1 || in > 32 || out < 1 || out > 32) return VT_EUNSUPPORTED;
+  if (gW && (!scratch || !X)) return VT_EINVAL;
+  const int nb = (int)((rows + RB - 1) / RB), ld = in * out + out;
+  hipLaunchKernelGGL(k_dense_bwd_rows, dim3(nb), dim3(TPB), 0, (hipStream_t)s, X, W, dY, dX, accumulate_dx,
+                     gW ? scratch : nullptr, rows, in, out, relu_x, ld);
+  VT_CHECK_LAUNCH();
+  if (gW) {
+    int rc = reduce_rows(scratch, nb, in * out, ld, gW, (hipStream_t)s);
+    if (rc) return rc;
+    if (gb) rc = reduce_rows(scratch + in * out, nb, out, ld, gb, (hipStream_t)s);
+    if (rc) return rc;
+  }
+  return 0;
+}

@@ -117,9 +117,16 @@ __device__ __forceinline__ void block_xreduce(float (&v)[NV], float *red, float 
   __syncthreads();
 }
 
-struct BnCoef {
-  float mean, inv, g, b;
-};
+// BatchNorm2D apply for one pixel record (x_norm * gamma + beta, batch_normalization_layer.hpp:279,296).
+__device__ __forceinline__ void load_x(const float *__restrict__ conv, size_t rec, const float *__restrict__ st,
+                                       const float *__restrict__ g, const float *__restrict__ b, float (&x)[C1]) {
+  const float4 *src = reinterpret_cast<const float4 *>(conv + rec * C1);
+  const float4 a = src[0], c = src[1];
+  const float raw[C1] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+#pragma unroll
+  for (int ch = 0; ch < C1; ++ch) x[ch] = ((raw[ch] - st[ch]) * st[C1 + ch]) * g[ch] + b[ch];
+}
+
 
 }  // namespace vt
 

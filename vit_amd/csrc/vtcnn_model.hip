@@ -45,6 +45,12 @@ struct vt_model {
   float *dlogits, *du, *pdx, *pdt, *dv, *dk, *d0, *ds2, *dh, *da, *dr, *dc, *dT0, *dy, *qkv, *gslab, *rowscratch;
   float *coef_pn, *coef_n2, *coef_n1, *coef_bn;
   float *loss_buf;
+  // optional per-launcher timing with HIP events on the caller's stream
+  std::string prof_filter;  // "" = off, "*" = every launcher, else one launcher name
+  std::vector<hipEvent_t> prof_ev;
+  std::vector<int> prof_name;  // name index per event pair
+  std::vector<std::string> prof_names;
+  size_t prof_used = 0;
 
   float *P_(const char *name) { return arena + lo.t[vt_find(&lo, name)].offset; }
   float *G_(const char *name) { return grads + lo.t[vt_find(&lo, name)].offset; }
@@ -107,7 +113,7 @@ extern "C" int vt_model_create(const vt_dims *dims, int max_batch, int device, f
   rc |= dalloc(m, &m->logits, N * K, "fwd.logits");
   rc |= dalloc(m, &m->probs, N * K, "fwd.preds");
   float *pi = nullptr;
-  rc |= dalloc(m, &pi, (N * Q + 3) / 4);
+  rc |= dalloc(m, &pi, (N * Q + 3) / 4, "fwd.pool_idx");  // raw bytes, 4 slots per float word
   m->pool_idx = (unsigned char *)pi;
   const size_t nrb = (NL + RB - 1) / RB;
   rc |= dalloc(m, &m->part, std::max(N, nrb) * 64);
@@ -131,7 +137,12 @@ extern "C" int vt_model_create(const vt_dims *dims, int max_batch, int device, f
   rc |= dalloc(m, &m->dy, N * P * C1, "bwd.tok_dx");
   rc |= dalloc(m, &m->qkv, 3 * NL * D, "bwd.mha_qkv");
   rc |= dalloc(m, &m->gslab, N * 512, "bwd.gslab");
-  rc |= dalloc(m, &m->rowscratch, std::max<size_t>(nrb, 64) * 2048 + Q * KMAX * 64);
+  {
+    // largest partial slab any backward launcher needs (see the scratch notes in vtcnn_hip.h)
+    const size_t need_ffn = nrb * 2112, need_fc = ((N + 31) / 32) * (Q * K + K);
+    const size_t need_mha = (size_t)L * HEADS * ((N + 63) / 64) * 1536;
+    rc |= dalloc(m, &m->rowscratch, std::max(need_ffn, std::max(need_fc, need_mha)));
+  }
   rc |= dalloc(m, &m->coef_pn, 2 * C2, "coef.proj.norm");
   rc |= dalloc(m, &m->coef_n2, 2 * D, "coef.norm2");
   rc |= dalloc(m, &m->coef_n1, 2 * D, "coef.norm1");
@@ -152,6 +163,7 @@ extern "C" int vt_model_destroy(vt_model *m) {
   (void)hipSetDevice(m->device);
   (void)hipDeviceSynchronize();
   for (void *p : m->allocs) (void)hipFree(p);
+  for (hipEvent_t e : m->prof_ev) (void)hipEventDestroy(e);
   delete m;
   return 0;
 }
@@ -275,12 +287,20 @@ const std::vector<CkEntry> &ck_entries() {
 }
 }  // namespace
 
-extern "C" int vt_model_save(vt_model *m, const char *path) {
-  if (!m || !path) return VT_EINVAL;
-  std::vector<float> h(m->lo.n_total);
-  VTCHK(vt_model_get_arena(m, h.data()));
+extern "C" int vt_host_init_arena(const vt_dims *dims, unsigned seed, float *arena_host) {
+  vt_layout lo;
+  if (!dims || !arena_host || vt_make_layout(dims, &lo) != 0) return VT_EINVAL;
+  std::vector<float> h;
+  init_arena_host(lo, *dims, seed, h);
+  std::memcpy(arena_host, h.data(), sizeof(float) * lo.n_total);
+  return 0;
+}
+
+extern "C" int vt_checkpoint_write(const vt_dims *dims, const float *arena_host, const char *path) {
+  vt_layout lo;
+  if (!dims || !arena_host || !path || vt_make_layout(dims, &lo) != 0) return VT_EINVAL;
   FILE *f = std::fopen(path, "wb");
-  if (!f) return VT_EIO;
+  if (!f) return VT_EIO;  // "No se pudo abrir el archivo para guardar el modelo" (vit_cnn.hpp:280)
   auto wi = [&](int v) { std::fwrite(&v, 4, 1, f); };
   wi(4);
   for (const CkEntry &e : ck_entries()) {
@@ -289,11 +309,11 @@ extern "C" int vt_model_save(vt_model *m, const char *path) {
     std::fwrite(e.type, 1, len, f);
     if (e.count_field) wi((int)e.tensors.size());
     for (const char *tn : e.tensors) {
-      const vt_tensor_info &ti = m->lo.t[vt_find(&m->lo, tn)];
+      const vt_tensor_info &ti = lo.t[vt_find(&lo, tn)];
       wi(ti.ndim);
       for (int k = 0; k < ti.ndim; ++k) wi(ti.shape[k]);
       wi(ti.size);
-      std::fwrite(h.data() + ti.offset, 4, ti.size, f);
+      std::fwrite(arena_host + ti.offset, 4, ti.size, f);
     }
   }
   const bool ok = std::ferror(f) == 0;
@@ -301,12 +321,39 @@ extern "C" int vt_model_save(vt_model *m, const char *path) {
   return ok ? 0 : VT_EIO;
 }
 
+extern "C" int vt_model_save(vt_model *m, const char *path) {
+  if (!m || !path) return VT_EINVAL;
+  std::vector<float> h(m->lo.n_total);
+  VTCHK(vt_model_get_arena(m, h.data()));
+  return vt_checkpoint_write(&m->d, h.data(), path);
+}
+
+static int checkpoint_read(const vt_layout &lo, std::vector<float> &h, const char *path);
+
+// Tensors absent from the file (transformer block, BatchNorm1D running statistics) keep the
+// values already in arena_host, exactly as a freshly constructed reference model keeps its
+// seed-42 initialisation for them after load().
+extern "C" int vt_checkpoint_read(const vt_dims *dims, float *arena_host, const char *path) {
+  vt_layout lo;
+  if (!dims || !arena_host || !path || vt_make_layout(dims, &lo) != 0) return VT_EINVAL;
+  std::vector<float> h(arena_host, arena_host + lo.n_total);
+  const int rc = checkpoint_read(lo, h, path);
+  if (rc == 0) std::memcpy(arena_host, h.data(), sizeof(float) * lo.n_total);
+  return rc;
+}
+
 extern "C" int vt_model_load(vt_model *m, const char *path) {
   if (!m || !path) return VT_EINVAL;
-  FILE *f = std::fopen(path, "rb");
-  if (!f) return VT_EIO;
   std::vector<float> h(m->lo.n_total);
-  int rc = vt_model_get_arena(m, h.data());
+  VTCHK(vt_model_get_arena(m, h.data()));
+  VTCHK(checkpoint_read(m->lo, h, path));
+  return vt_model_set_arena(m, h.data());
+}
+
+static int checkpoint_read(const vt_layout &lo, std::vector<float> &h, const char *path) {
+  FILE *f = std::fopen(path, "rb");
+  if (!f) return VT_EIO;  // "No se pudo abrir el archivo para cargar el modelo" (vit_cnn.hpp:400)
+  int rc = 0;
   auto ri = [&](int *v) { return std::fread(v, 4, 1, f) == 1; };
   int v = 0;
   if (rc == 0 && (!ri(&v) || v != 4)) rc = VT_EFORMAT;  // "Cantidad de capas no coincide" (vit_cnn.hpp:405)
@@ -323,7 +370,7 @@ extern "C" int vt_model_load(vt_model *m, const char *path) {
       break;
     }
     for (const char *tn : e.tensors) {
-      const vt_tensor_info &ti = m->lo.t[vt_find(&m->lo, tn)];
+      const vt_tensor_info &ti = lo.t[vt_find(&lo, tn)];
       int nd = 0, cnt = 0, dim = 0;
       if (!ri(&nd) || nd != ti.ndim) { rc = VT_EFORMAT; break; }
       for (int k = 0; k < nd && rc == 0; ++k)
@@ -333,8 +380,7 @@ extern "C" int vt_model_load(vt_model *m, const char *path) {
     }
   }
   std::fclose(f);
-  if (rc != 0) return rc;
-  return vt_model_set_arena(m, h.data());
+  return rc;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -404,6 +450,76 @@ extern "C" int vt_loader_indices(int n, unsigned seed, int resets, int *out) {
 // ---------------------------------------------------------------------------------------------
 // Forward / backward chains
 // ---------------------------------------------------------------------------------------------
+namespace {
+constexpr size_t kMaxProfPairs = 16384;
+// Records a start event; returns the pair slot or -1 when this launcher is not being timed.
+int prof_begin(vt_model *m, const char *name, hipStream_t hs) {
+  if (m->prof_filter.empty() || (m->prof_filter != "*" && m->prof_filter != name)) return -1;
+  if (m->prof_used >= kMaxProfPairs) return -1;
+  if (m->prof_ev.size() < 2 * (m->prof_used + 1)) {
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return -1;
+    m->prof_ev.push_back(a);
+    m->prof_ev.push_back(b);
+    m->prof_name.push_back(0);
+  }
+  int ni = -1;
+  for (size_t k = 0; k < m->prof_names.size(); ++k)
+    if (m->prof_names[k] == name) ni = (int)k;
+  if (ni < 0) {
+    m->prof_names.push_back(name);
+    ni = (int)m->prof_names.size() - 1;
+  }
+  const int slot = (int)m->prof_used++;
+  m->prof_name[slot] = ni;
+  (void)hipEventRecord(m->prof_ev[2 * slot], hs);
+  return slot;
+}
+void prof_end(vt_model *m, int slot, hipStream_t hs) {
+  if (slot >= 0) (void)hipEventRecord(m->prof_ev[2 * slot + 1], hs);
+}
+}  // namespace
+
+#define STEP(name, call)                                      \
+  do {                                                        \
+    const int slot__ = prof_begin(m, name, (hipStream_t)s);   \
+    const int r__ = (call);                                   \
+    prof_end(m, slot__, (hipStream_t)s);                      \
+    if (r__ != 0) return r__;                                 \
+  } while (0)
+
+extern "C" int vt_model_profile(vt_model *m, const char *filter) {
+  if (!m) return VT_EINVAL;
+  m->prof_filter = filter ? filter : "";
+  m->prof_used = 0;
+  return 0;
+}
+
+// Aggregated timings since the last call (synchronises the device).  Returns the number of
+// distinct launcher names; entry idx -> name, total milliseconds, number of launches.
+extern "C" int vt_model_profile_read(vt_model *m, int idx, char *name_out, int name_cap, float *total_ms, int *count) {
+  if (!m) return VT_EINVAL;
+  if (hipDeviceSynchronize() != hipSuccess) return VT_EINVAL;
+  if (idx >= 0 && idx < (int)m->prof_names.size()) {
+    float tot = 0.f;
+    int cnt = 0;
+    for (size_t k = 0; k < m->prof_used; ++k)
+      if (m->prof_name[k] == idx) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, m->prof_ev[2 * k], m->prof_ev[2 * k + 1]) == hipSuccess) {
+          tot += ms;
+          ++cnt;
+        }
+      }
+    if (name_out && name_cap > 0) {
+      std::strncpy(name_out, m->prof_names[idx].c_str(), name_cap - 1);
+      name_out[name_cap - 1] = 0;
+    }
+    if (total_ms) *total_ms = tot;
+    if (count) *count = cnt;
+  }
+  return (int)m->prof_names.size();
+}
 extern "C" int vt_model_set_training(vt_model *m, int training) {
   if (!m) return VT_EINVAL;
   m->training = training ? 1 : 0;
@@ -418,30 +534,80 @@ extern "C" int vt_model_forward(vt_model *m, const float *d_images, int n, float
   m->lastN = n;
   m->last_images = d_images;
   // conv + BatchNorm2D statistics (training: batch stats; eval: running stats)
-  VTCHK(vt_conv3x3_fwd(d_images, m->P_("conv.W"), m->P_("conv.b"), m->conv, m->training ? m->part : nullptr, n, Ci, H, H, s));
+  STEP("conv3x3_fwd", vt_conv3x3_fwd(d_images, m->P_("conv.W"), m->P_("conv.b"), m->conv, m->training ? m->part : nullptr, n, Ci, H, H, s));
   if (m->training)
-    VTCHK(vt_bn_stats_finalize(m->part, n, C1, P, (long)n * P, m->P_("bn.running_mean"), m->P_("bn.running_var"), m->stat_bn, s));
+    STEP("bn_stats_finalize", vt_bn_stats_finalize(m->part, n, C1, P, (long)n * P, m->P_("bn.running_mean"), m->P_("bn.running_var"), m->stat_bn, s));
   else
-    VTCHK(vt_bn_stats_eval(m->P_("bn.running_mean"), m->P_("bn.running_var"), C1, m->stat_bn, s));
+    STEP("bn_stats_eval", vt_bn_stats_eval(m->P_("bn.running_mean"), m->P_("bn.running_var"), C1, m->stat_bn, s));
   // tokenizer; the three BatchNorm1D layers always use batch statistics (visual_transformer.hpp:221)
-  VTCHK(vt_tokenizer_fwd(m->conv, m->stat_bn, m->P_("bn.gamma"), m->P_("bn.beta"), m->P_("tok.linear1.W"),
+  STEP("tokenizer_fwd", vt_tokenizer_fwd(m->conv, m->stat_bn, m->P_("bn.gamma"), m->P_("bn.beta"), m->P_("tok.linear1.W"),
                          m->P_("tok.linear1.b"), m->P_("tok.linear2.W"), m->P_("tok.linear2.b"), m->tokA, m->tok, m->part,
                          n, P, s));
-  VTCHK(vt_bn_stats_finalize(m->part, n, D, L, NL, m->P_("norm1.running_mean"), m->P_("norm1.running_var"), m->stat_n1, s));
-  VTCHK(vt_transformer_ffn_fwd(m->tok, m->stat_n1, m->P_("norm1.gamma"), m->P_("norm1.beta"), m->P_("ffn.linear1.W"),
+  STEP("bn_stats_finalize", vt_bn_stats_finalize(m->part, n, D, L, NL, m->P_("norm1.running_mean"), m->P_("norm1.running_var"), m->stat_n1, s));
+  STEP("transformer_ffn_fwd", vt_transformer_ffn_fwd(m->tok, m->stat_n1, m->P_("norm1.gamma"), m->P_("norm1.beta"), m->P_("ffn.linear1.W"),
                                m->P_("ffn.linear1.b"), m->P_("ffn.linear2.W"), m->P_("ffn.linear2.b"), m->a, m->hdn, m->s2,
                                m->part, NL, s));
-  VTCHK(vt_bn_stats_finalize(m->part, nrb, D, RB, NL, m->P_("norm2.running_mean"), m->P_("norm2.running_var"), m->stat_n2, s));
-  VTCHK(vt_projector_tokens_fwd(m->s2, m->stat_n2, m->P_("norm2.gamma"), m->P_("norm2.beta"), m->P_("proj.linear1.W"),
+  STEP("bn_stats_finalize", vt_bn_stats_finalize(m->part, nrb, D, RB, NL, m->P_("norm2.running_mean"), m->P_("norm2.running_var"), m->stat_n2, s));
+  STEP("projector_tokens_fwd", vt_projector_tokens_fwd(m->s2, m->stat_n2, m->P_("norm2.gamma"), m->P_("norm2.beta"), m->P_("proj.linear1.W"),
                                 m->P_("proj.linear2.W"), m->P_("proj.linear3.W"), m->P_("proj.linear3.b"), m->o, m->pk, n, s));
-  VTCHK(vt_projector_fwd(m->conv, m->stat_bn, m->P_("bn.gamma"), m->P_("bn.beta"), m->pk, m->P_("proj.downsample.W"),
+  STEP("projector_fwd", vt_projector_fwd(m->conv, m->stat_bn, m->P_("bn.gamma"), m->P_("bn.beta"), m->pk, m->P_("proj.downsample.W"),
                          m->P_("proj.downsample.b"), m->projA, m->z, m->part, n, P, s));
-  VTCHK(vt_bn_stats_finalize(m->part, n, C2, P, (long)n * P, m->P_("proj.norm.running_mean"), m->P_("proj.norm.running_var"),
+  STEP("bn_stats_finalize", vt_bn_stats_finalize(m->part, n, C2, P, (long)n * P, m->P_("proj.norm.running_mean"), m->P_("proj.norm.running_var"),
                              m->stat_pn, s));
-  VTCHK(vt_head_fwd(m->z, m->stat_pn, m->P_("proj.norm.gamma"), m->P_("proj.norm.beta"), m->P_("fc.W"), m->P_("fc.b"),
+  STEP("head_fwd", vt_head_fwd(m->z, m->stat_pn, m->P_("proj.norm.gamma"), m->P_("proj.norm.beta"), m->P_("fc.W"), m->P_("fc.b"),
                     m->pooled, m->pool_idx, m->logits, m->probs, n, H, K, s));
   if (d_probs && d_probs != m->probs)
     HIPCHK(hipMemcpyAsync(d_probs, m->probs, (size_t)n * K * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)s));
+  return 0;
+}
+
+// VTCNN::backward (reference model/vit_cnn.hpp:215-242): softmax -> fc -> flatten -> maxpool ->
+// VisualTransformer::backward (projector -> transformer -> tokenizer.backward2,
+// layers/visual_transformer.hpp:127-199) -> BatchNorm2D -> conv.
+extern "C" int vt_model_backward(vt_model *m, const int *d_labels, vt_stream s) {
+  if (!m || !d_labels || m->lastN < 1 || !m->last_images) return VT_EINVAL;
+  const int n = m->lastN, H = m->d.input_dim, P = m->P, Ci = m->d.image_channels, K = m->K, Q = m->Q;
+  const long NL = (long)n * L;
+  const int nrb = (int)((NL + RB - 1) / RB);
+  hipStream_t hs = (hipStream_t)s;
+  // head: softmax/fc/pool/relu backward + projector BatchNorm1D backward sums
+  STEP("head_bwd", vt_head_bwd(m->probs, d_labels, m->P_("fc.W"), m->pool_idx, m->z, m->stat_pn, m->P_("proj.norm.gamma"),
+                    m->P_("proj.norm.beta"), m->dlogits, m->du, m->part, n, H, K, s));
+  STEP("bn_bwd_finalize", vt_bn_bwd_finalize(m->part, n, C2, (long)n * P, m->P_("proj.norm.gamma"), m->stat_pn, m->z,
+                           m->G_("proj.norm.gamma"), m->G_("proj.norm.beta"), m->coef_pn, s));
+  STEP("fc_wgrad", vt_fc_wgrad(m->pooled, m->dlogits, m->G_("fc.W"), m->G_("fc.b"), m->rowscratch, n, Q, K, s));
+  // projector
+  STEP("projector_bwd", vt_projector_bwd(m->du, m->coef_pn, m->conv, m->stat_bn, m->P_("bn.gamma"), m->P_("bn.beta"), m->projA, m->pk,
+                         m->P_("proj.linear1.W"), m->P_("proj.downsample.W"), m->pdx, m->dv, m->dk, m->gslab, n, P, s));
+  STEP("reduce_rows", vt_reduce_rows(m->gslab, n, C1 * D, 400, m->G_("proj.linear1.W"), s));
+  STEP("reduce_rows", vt_reduce_rows(m->gslab + C1 * D, n, C1 * C2 + C2, 400, m->G_("proj.downsample.W"), s));
+  STEP("projector_tokens_bwd", vt_projector_tokens_bwd(m->o, m->dv, m->dk, m->P_("proj.linear3.W"), m->P_("proj.linear2.W"), m->pdt,
+                                m->G_("proj.linear2.W"), m->rowscratch, NL, s));
+  // transformer (targets = projector token delta, same bytes: visual_transformer.hpp:153-157)
+  STEP("transformer_bwd_a", vt_transformer_bwd_a(m->o, m->pdt, m->s2, m->stat_n2, m->P_("tok.linear2.W"), m->part, m->dT0, NL, s));
+  STEP("bn_bwd_finalize", vt_bn_bwd_finalize(m->part, nrb, D, NL, m->P_("norm2.gamma"), m->stat_n2, m->s2, m->G_("norm2.gamma"),
+                           m->G_("norm2.beta"), m->coef_n2, s));
+  STEP("transformer_bwd_b", vt_transformer_bwd_b(m->o, m->pdt, m->coef_n2, m->hdn, m->a, m->tok, m->stat_n1, m->P_("ffn.linear1.W"),
+                             m->P_("ffn.linear2.W"), m->ds2, m->da, m->G_("ffn.linear1.W"), m->rowscratch, m->part, NL, s));
+  STEP("bn_bwd_finalize", vt_bn_bwd_finalize(m->part, nrb, D, NL, m->P_("norm1.gamma"), m->stat_n1, m->tok, m->G_("norm1.gamma"),
+                           m->G_("norm1.beta"), m->coef_n1, s));
+  STEP("transformer_bwd_c", vt_transformer_bwd_c(m->da, m->coef_n1, m->P_("mha.o.W"), m->tok, m->P_("mha.q0.W"), m->dr, m->dc, m->qkv, NL, s));
+  STEP("mha_bwd", vt_mha_bwd(m->qkv, m->dc, m->tok, m->P_("mha.q0.W"), m->G_("mha.q0.W"), m->rowscratch, n, L, s));
+  // the output projection's cached input is the zero concat: its gradient is exactly zero
+  HIPCHK(hipMemsetAsync(m->G_("mha.o.W"), 0, sizeof(float) * D * D, hs));
+  // tokenizer.backward2(projector token delta, projector input delta) + BatchNorm2D + conv
+  STEP("tokenizer_bwd", vt_tokenizer_bwd(m->conv, m->stat_bn, m->P_("bn.gamma"), m->P_("bn.beta"), m->tokA, m->dT0,
+                         m->P_("tok.linear1.W"), m->pdx, m->dy, m->part, n, P, s));
+  STEP("bn_bwd_finalize", vt_bn_bwd_finalize(m->part, n, C1, (long)n * P, m->P_("bn.gamma"), m->stat_bn, m->conv, m->G_("bn.gamma"),
+                           m->G_("bn.beta"), m->coef_bn, s));
+  STEP("conv3x3_wgrad", vt_conv3x3_wgrad(m->last_images, m->dy, m->coef_bn, m->gslab, n, Ci, H, H, s));
+  STEP("reduce_rows", vt_reduce_rows(m->gslab, n, C1 * Ci * 9 + C1, C1 * Ci * 9 + C1, m->G_("conv.W"), s));
+  return 0;
+}
+
+extern "C" int vt_model_sgd_step(vt_model *m, float lr, float divisor, vt_stream s) {
+  if (!m) return VT_EINVAL;
+  STEP("sgd_update", vt_sgd_update(m->arena, m->grads, m->lo.n_trainable, lr, divisor, 1, s));
   return 0;
 }
 

@@ -143,6 +143,22 @@ class VTCNN:
         check(lib.vt_model_load(self._h, str(path).encode()), "vt_model_load(%s)" % path)
 
     # ---- tooling -------------------------------------------------------------------------
+    def profile(self, launcher=None):
+        """Time one launcher ("projector_bwd"), every launcher ("*") or none (None) with HIP events."""
+        check(lib.vt_model_profile(self._h, launcher.encode() if launcher else None))
+
+    def profile_read(self):
+        """{launcher: (total_ms, launches)} since the last profile() call (synchronises)."""
+        out = {}
+        n = lib.vt_model_profile_read(self._h, -1, None, 0, None, None)
+        for k in range(max(n, 0)):
+            name = C.create_string_buffer(64)
+            ms, cnt = C.c_float(), C.c_int()
+            lib.vt_model_profile_read(self._h, k, name, 64, C.byref(ms), C.byref(cnt))
+            if cnt.value:
+                out[name.value.decode()] = (ms.value, cnt.value)
+        return out
+
     def read(self, name):
         n = lib.vt_model_read(self._h, name.encode(), None, 0)
         if n < 0:
