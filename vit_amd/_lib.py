@@ -2,6 +2,11 @@
 import ctypes as C
 import os
 
+# PyTorch-ROCm wheels bundle their own HIP runtime.  It has to be the first (and only) HIP runtime
+# mapped into the process: loading libvtcnn_hip.so first would pull in the system libamdhip64 and
+# the two runtimes would then fight over the device ("no ROCm-capable device is detected").
+import torch  # noqa: F401,E402
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvtcnn_hip.so")
 

@@ -123,8 +123,16 @@ __global__ __launch_bounds__(1024) void k_reduce_rows(const float *__restrict__ 
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
   float s = 0.f;
-  if (c < cols)
-    for (long r = rl; r < rows; r += 16) s += slab[r * ld + c];
+  if (c < cols) {
+    long r = rl;
+    for (; r + 7 * 16 < rows; r += 8 * 16) {  // 8 independent loads in flight
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = slab[(r + 16 * k) * ld + c];
+      s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    }
+    for (; r < rows; r += 16) s += slab[r * ld + c];
+  }
   sh[rl][cl] = s;
   __syncthreads();
   if (rl == 0 && c < cols) {
@@ -148,17 +156,23 @@ __global__ __launch_bounds__(1024) void k_reduce_rows(const float *__restrict__ 
 // small[1,C] * big[R,C] and Tensor::operator* keeps the left operand's shape
 // (tensor_cpu.hpp:1050-1084).  coef = (scale, shift) with delta_in = delta*scale + shift.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(TPB) void k_bn_bwd_finalize(const float *__restrict__ part, int nb, int C, long rows_total,
-                                                         const float *__restrict__ gamma, const float *__restrict__ stat,
-                                                         const float *__restrict__ in_row0, float *__restrict__ ggamma,
-                                                         float *__restrict__ gbeta, float *__restrict__ coef) {
-  __shared__ double sh[TPB];
+constexpr int FIN_T = 1024;
+__global__ __launch_bounds__(FIN_T) void k_bn_bwd_finalize(const float *__restrict__ part, int nb, int C, long rows_total,
+                                                           const float *__restrict__ gamma, const float *__restrict__ stat,
+                                                           const float *__restrict__ in_row0, float *__restrict__ ggamma,
+                                                           float *__restrict__ gbeta, float *__restrict__ coef) {
+  __shared__ double sh[FIN_T];
   const int tid = threadIdx.x;
   const int C2x = 2 * C;  // (S1, S2) pairs
-  const int c = tid % C2x, j = tid / C2x, ns = TPB / C2x;
+  const int c = tid % C2x, j = tid / C2x, ns = FIN_T / C2x;
   double s = 0.0;
-  if (j < ns)
-    for (int b = j; b < nb; b += ns) s += (double)part[(size_t)b * C2x + c];
+  int b = j;
+  for (; b + 3 * ns < nb; b += 4 * ns) {  // 4 independent loads in flight
+    const float v0 = part[(size_t)b * C2x + c], v1 = part[(size_t)(b + ns) * C2x + c];
+    const float v2 = part[(size_t)(b + 2 * ns) * C2x + c], v3 = part[(size_t)(b + 3 * ns) * C2x + c];
+    s += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
+  }
+  for (; b < nb; b += ns) s += (double)part[(size_t)b * C2x + c];
   sh[tid] = s;
   __syncthreads();
   if (tid < C) {
@@ -602,162 +616,6 @@ __global__ __launch_bounds__(TPB) void k_tr_bwd_c(const float *__restrict__ da, 
 }
 
 // ---------------------------------------------------------------------------------------------
-// MultiHeadAttention::backward, per-head part (reference layers/multi_head_attention.hpp:139-181).
-// The layer's "batch" axis is the token index and its "sequence" axis is the mini-batch
-// (permute is a relabel, tensor_cpu.hpp:719-747): group b = rows b*T .. b*T+T-1 of the flat token
-// matrix, T = N.  Only the weight gradients survive (the input delta is discarded,
-// visual_transformer.hpp:160), so the attention backward is restated row-wise:
-//   scores[i][j] = K_i.Q_j / sqrt(d);  attn = softmax_j;  dattn[i][j] = dhead_i . V_j
-//   dot_i = sum_j dattn*attn;  dsc = attn * (dattn - dot_i)      (no 1/sqrt(d) in backward, :165-170)
-//   Y_i = sum_j attn[i][j] X_j;  Z_i = sum_j dsc[i][j] X_j
-//   gWv = sum_i Y_i^T dhead_i;  gWq = sum_i Z_i^T K_i;  gWk = sum_i X_i^T (Z_i Wq)
-// which equals X^T dV, X^T dQ, X^T dK of the reference.  One workgroup = 64 rows i of one
-// (group, head); wave w sweeps the j range w*T/4..; partial sums are merged through LDS.
-// Partials per workgroup: gq[D*HD] | gk[D*HD] | gv[D*HD]  (MH_STRIDE floats).
-// ---------------------------------------------------------------------------------------------
-constexpr int MH_STRIDE = 3 * D * HD;  // 1536
-__global__ __launch_bounds__(TPB) void k_mha_bwd(const float *__restrict__ qkv, const float *__restrict__ dc,
-                                                 const float *__restrict__ tok, const float *__restrict__ Wqkv,
-                                                 float *__restrict__ scratch, int T, long rows) {
-  __shared__ float sred[NW - 1][64][2 * D + 3];  // waves 1..3, per row: Y~[D], W~[D], s, t
-  __shared__ float smax[NW][64];
-  __shared__ float sout[MH_STRIDE];
-  const int tiles = (T + 63) / 64;
-  const int tile = blockIdx.x % tiles, h = (blockIdx.x / tiles) % HEADS, bgrp = blockIdx.x / (tiles * HEADS);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int i = tile * 64 + lane;
-  const bool ok = i < T;
-  const long gbase = (long)bgrp * T;
-  const long ri = gbase + (ok ? i : 0);
-  const float *__restrict__ Qm = qkv, *__restrict__ Km = qkv + rows * D, *__restrict__ Vm = qkv + 2 * rows * D;
-  const float scale = 1.0f / sqrtf((float)HD);
-  float Ki[HD], dh[HD];
-#pragma unroll
-  for (int e = 0; e < HD; ++e) {
-    Ki[e] = Km[ri * D + h * HD + e];
-    dh[e] = dc[ri * D + h * HD + e];
-  }
-  const int jchunk = (T + NW - 1) / NW;
-  const int j0 = wave * jchunk, j1 = min(T, j0 + jchunk);
-  // pass 1: row maximum of the scaled scores over this wave's j range, merged across waves
-  float mx = -INFINITY;
-  for (int j = j0; j < j1; ++j) {
-    const float *__restrict__ qj = Qm + (gbase + j) * D + h * HD;
-    float s = 0.f;
-#pragma unroll
-    for (int e = 0; e < HD; ++e) s += Ki[e] * qj[e];
-    mx = fmaxf(mx, s * scale);
-  }
-  smax[wave][lane] = mx;
-  __syncthreads();
-#pragma unroll
-  for (int w = 0; w < NW; ++w) mx = fmaxf(mx, smax[w][lane]);
-  // pass 2: unnormalised sums
-  float Yt[D], Wt[D], ssum = 0.f, tsum = 0.f;
-#pragma unroll
-  for (int d = 0; d < D; ++d) { Yt[d] = 0.f; Wt[d] = 0.f; }
-  for (int j = j0; j < j1; ++j) {
-    const float *__restrict__ qj = Qm + (gbase + j) * D + h * HD;
-    const float *__restrict__ vj = Vm + (gbase + j) * D + h * HD;
-    const float *__restrict__ xj = tok + (gbase + j) * D;
-    float s = 0.f, da = 0.f;
-#pragma unroll
-    for (int e = 0; e < HD; ++e) {
-      s += Ki[e] * qj[e];
-      da += dh[e] * vj[e];
-    }
-    const float ev = expf(s * scale - mx);
-    const float ed = ev * da;
-    ssum += ev;
-    tsum += ed;
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-      Yt[d] += ev * xj[d];
-      Wt[d] += ed * xj[d];
-    }
-  }
-  if (wave > 0) {
-    float *r = sred[wave - 1][lane];
-#pragma unroll
-    for (int d = 0; d < D; ++d) { r[d] = Yt[d]; r[D + d] = Wt[d]; }
-    r[2 * D] = ssum;
-    r[2 * D + 1] = tsum;
-  }
-  __syncthreads();
-  // wave 0 merges the four j ranges and finishes its 64 rows (small epilogue)
-  if (wave == 0) {
-    float Y[D], Z[D];
-    float s = ssum, t = tsum;
-#pragma unroll
-    for (int d = 0; d < D; ++d) { Y[d] = Yt[d]; Z[d] = Wt[d]; }
-#pragma unroll
-    for (int w = 0; w < NW - 1; ++w) {
-      const float *r = sred[w][lane];
-#pragma unroll
-      for (int d = 0; d < D; ++d) { Y[d] += r[d]; Z[d] += r[D + d]; }
-      s += r[2 * D];
-      t += r[2 * D + 1];
-    }
-    const float invs = ok ? 1.0f / s : 0.f;
-    const float dot = t * invs;
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-      Y[d] = Y[d] * invs;
-      Z[d] = Z[d] * invs - dot * Y[d];
-    }
-    // dK_i = Z_i . Wq_h   (delta_scores . query with query = X.Wq)
-    const float *__restrict__ Wq_h = Wqkv + (size_t)(h * 3 + 0) * D * HD;
-    float dK[HD], Xi[D];
-#pragma unroll
-    for (int e = 0; e < HD; ++e) dK[e] = 0.f;
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-      Xi[d] = ok ? tok[ri * D + d] : 0.f;
-#pragma unroll
-      for (int e = 0; e < HD; ++e) dK[e] += Z[d] * Wq_h[d * HD + e];
-    }
-    if (!ok) {
-#pragma unroll
-      for (int e = 0; e < HD; ++e) { Ki[e] = 0.f; dh[e] = 0.f; dK[e] = 0.f; }
-    }
-    // outer products summed over the 64 rows with the transposing butterfly: 4 rows of the
-    // [D][HD] gradient (64 values) per call
-#pragma unroll
-    for (int m = 0; m < 3; ++m) {
-#pragma unroll
-      for (int blk = 0; blk < D / 4; ++blk) {
-        float acc[64];
-#pragma unroll
-        for (int dd = 0; dd < 4; ++dd)
-#pragma unroll
-          for (int e = 0; e < HD; ++e) {
-            const int d = blk * 4 + dd;
-            acc[dd * HD + e] = (m == 0) ? Z[d] * Ki[e] : (m == 1) ? Xi[d] * dK[e] : Y[d] * dh[e];
-          }
-        wave_xreduce<64>(acc);
-        sout[m * D * HD + blk * 64 + lane] = acc[0];
-      }
-    }
-  }
-  __syncthreads();
-  float *row = scratch + (size_t)blockIdx.x * MH_STRIDE;
-  for (int idx = threadIdx.x; idx < MH_STRIDE; idx += TPB) row[idx] = sout[idx];
-}
-
-// Sums the per-workgroup attention partials into the six per-head gradient tensors
-// (arena order q0,k0,v0,q1,k1,v1).  blocks are ordered (group, head, tile).
-__global__ __launch_bounds__(TPB) void k_mha_reduce(const float *__restrict__ scratch, int groups, int tiles,
-                                                    float *__restrict__ gout) {
-  const int idx = blockIdx.x * TPB + threadIdx.x;  // over HEADS * MH_STRIDE
-  if (idx >= HEADS * MH_STRIDE) return;
-  const int h = idx / MH_STRIDE, k = idx % MH_STRIDE;
-  float s = 0.f;
-  for (int b = 0; b < groups; ++b)
-    for (int t = 0; t < tiles; ++t) s += scratch[(size_t)((b * HEADS + h) * tiles + t) * MH_STRIDE + k];
-  gout[idx] = s;
-}
-
-// ---------------------------------------------------------------------------------------------
 // FilterTokenizer::backward2 (reference layers/tokenizer.hpp:50-107).  Per pixel:
 //   dA[l] = dT0[l] . x;  dx = A . dT0;  dS = A * (dA - sum_l dA*A)   (softmax_backward reduces over
 //   the token axis although the forward softmax ran over pixels, tokenizer.hpp:36,91)
@@ -1006,8 +864,8 @@ extern "C" int vt_fc_wgrad(const float *pooled, const float *d_logits, float *gw
 extern "C" int vt_bn_bwd_finalize(const float *part, int nblocks, int C, long rows_total, const float *gamma,
                                   const float *stat, const float *in_row0, float *ggamma, float *gbeta, float *coef,
                                   vt_stream s) {
-  if (C < 1 || 2 * C > TPB || nblocks < 1 || rows_total < 1) return VT_EUNSUPPORTED;
-  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(1), dim3(TPB), 0, (hipStream_t)s, part, nblocks, C, rows_total, gamma,
+  if (C < 1 || FIN_T % (2 * C) != 0 || nblocks < 1 || rows_total < 1) return VT_EUNSUPPORTED;
+  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(1), dim3(FIN_T), 0, (hipStream_t)s, part, nblocks, C, rows_total, gamma,
                      stat, in_row0, ggamma, gbeta, coef);
   VT_CHECK_LAUNCH();
   return 0;
@@ -1069,21 +927,6 @@ extern "C" int vt_transformer_bwd_c(const float *da, const float *n1_coef, const
   if (rows < 1) return VT_EINVAL;
   const int nb = (int)((rows + RB - 1) / RB);
   hipLaunchKernelGGL(k_tr_bwd_c, dim3(nb), dim3(TPB), 0, (hipStream_t)s, da, n1_coef, wo, tok, wqkv, dr, dc, qkv, rows);
-  VT_CHECK_LAUNCH();
-  return 0;
-}
-
-// g_qkv: [q0 | k0 | v0 | q1 | k1 | v1] gradients (arena order); scratch >= L*HEADS*ceil(N/64)*1536.
-extern "C" int vt_mha_bwd(const float *qkv, const float *dc, const float *tok, const float *wqkv, float *g_qkv,
-                          float *scratch, int N, int groups, vt_stream s) {
-  if (N < 1 || groups < 1) return VT_EINVAL;
-  const int tiles = (N + 63) / 64;
-  const long rows = (long)N * groups;
-  hipLaunchKernelGGL(k_mha_bwd, dim3(groups * HEADS * tiles), dim3(TPB), 0, (hipStream_t)s, qkv, dc, tok, wqkv, scratch,
-                     N, rows);
-  VT_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_mha_reduce, dim3((HEADS * MH_STRIDE + TPB - 1) / TPB), dim3(TPB), 0, (hipStream_t)s, scratch,
-                     groups, tiles, g_qkv);
   VT_CHECK_LAUNCH();
   return 0;
 }

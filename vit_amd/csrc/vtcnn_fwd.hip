@@ -93,39 +93,60 @@ __global__ __launch_bounds__(TPB) void k_conv_fwd(const float *__restrict__ X, c
 // stat = (mean, 1/sqrt(var+eps)) and updates running = 0.1*batch + 0.9*running (biased var).
 // One workgroup.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(TPB) void k_bn_stats_finalize(const float *__restrict__ part, int nb, int C,
-                                                           long rows_per_block, long rows_total,
-                                                           float *__restrict__ run_mean, float *__restrict__ run_var,
-                                                           float *__restrict__ stat) {
-  __shared__ double sh[TPB];
-  __shared__ double smean[64];
+constexpr int FIN_T = 1024;  // threads of the single finalisation workgroup
+__global__ __launch_bounds__(FIN_T) void k_bn_stats_finalize(const float *__restrict__ part, int nb, int C,
+                                                             long rows_per_block, long rows_total,
+                                                             float *__restrict__ run_mean, float *__restrict__ run_var,
+                                                             float *__restrict__ stat) {
+  // One pass: S = sum_b sum_b, Q = sum_b M2_b, U = sum_b sum_b^2/cnt_b; then
+  //   mean = S/R,  M2 = Q + U - S^2/R   (Chan's merge summed over all blocks; doubles absorb the
+  //   cancellation).  Thread = (channel, slice of blocks); independent loads are unrolled so the
+  //   global-load latency is paid once per 4 blocks, not once per block.
+  __shared__ double sh[3][FIN_T];
   const int tid = threadIdx.x;
-  const int c = tid % C, j = tid / C, ns = TPB / C;
-  double s = 0.0;
-  for (int b = j; b < nb; b += ns) s += (double)part[(size_t)b * 2 * C + c];
-  sh[tid] = s;
+  const int c = tid % C, j = tid / C, ns = FIN_T / C;
+  const long last_cnt = rows_total - (long)(nb - 1) * rows_per_block;
+  double S = 0.0, Q = 0.0, U = 0.0;
+  int b = j;
+  for (; b + 3 * ns < nb; b += 4 * ns) {
+    float sv[4], qv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      sv[k] = part[(size_t)(b + k * ns) * 2 * C + c];
+      qv[k] = part[(size_t)(b + k * ns) * 2 * C + C + c];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const double cnt = (double)((b + k * ns == nb - 1) ? last_cnt : rows_per_block);
+      S += (double)sv[k];
+      Q += (double)qv[k];
+      U += (double)sv[k] * (double)sv[k] / cnt;
+    }
+  }
+  for (; b < nb; b += ns) {
+    const double sv = (double)part[(size_t)b * 2 * C + c], qv = (double)part[(size_t)b * 2 * C + C + c];
+    const double cnt = (double)((b == nb - 1) ? last_cnt : rows_per_block);
+    S += sv;
+    Q += qv;
+    U += sv * sv / cnt;
+  }
+  sh[0][tid] = S;
+  sh[1][tid] = Q;
+  sh[2][tid] = U;
   __syncthreads();
   if (tid < C) {
-    double t = 0.0;
-    for (int k = 0; k < ns; ++k) t += sh[k * C + tid];
-    smean[tid] = t / (double)rows_total;
-  }
-  __syncthreads();
-  const double mu = smean[c];
-  double q = 0.0;
-  for (int b = j; b < nb; b += ns) {
-    const long cnt = (b == nb - 1) ? rows_total - (long)(nb - 1) * rows_per_block : rows_per_block;
-    const double mb = (double)part[(size_t)b * 2 * C + c] / (double)cnt;
-    q += (double)part[(size_t)b * 2 * C + C + c] + (double)cnt * (mb - mu) * (mb - mu);
-  }
-  __syncthreads();
-  sh[tid] = q;
-  __syncthreads();
-  if (tid < C) {
-    double t = 0.0;
-    for (int k = 0; k < ns; ++k) t += sh[k * C + tid];
-    const float mean = (float)smean[tid];
-    const float var = (float)(t / (double)rows_total);
+    double s = 0.0, q = 0.0, u = 0.0;
+    for (int k = 0; k < ns; ++k) {
+      s += sh[0][k * C + tid];
+      q += sh[1][k * C + tid];
+      u += sh[2][k * C + tid];
+    }
+    const double R = (double)rows_total;
+    const double mu = s / R;
+    double m2 = q + u - s * s / R;
+    if (m2 < 0.0) m2 = 0.0;
+    const float mean = (float)mu;
+    const float var = (float)(m2 / R);
     stat[tid] = mean;
     stat[C + tid] = 1.0f / sqrtf(var + BN_EPS);
     run_mean[tid] = mean * BN_MOM + run_mean[tid] * (1 - BN_MOM);
@@ -592,9 +613,9 @@ extern "C" int vt_conv3x3_fwd(const float *x, const float *w, const float *b, fl
 
 extern "C" int vt_bn_stats_finalize(const float *part, int nblocks, int C, long rows_per_block, long rows_total,
                                     float *running_mean, float *running_var, float *stat, vt_stream s) {
-  if (C < 1 || C > 64 || TPB % C != 0 || nblocks < 1) return VT_EUNSUPPORTED;
+  if (C < 1 || C > 64 || FIN_T % C != 0 || nblocks < 1) return VT_EUNSUPPORTED;
   if ((long)(nblocks - 1) * rows_per_block >= rows_total || (long)nblocks * rows_per_block < rows_total) return VT_EINVAL;
-  hipLaunchKernelGGL(k_bn_stats_finalize, dim3(1), dim3(TPB), 0, (hipStream_t)s, part, nblocks, C, rows_per_block,
+  hipLaunchKernelGGL(k_bn_stats_finalize, dim3(1), dim3(FIN_T), 0, (hipStream_t)s, part, nblocks, C, rows_per_block,
                      rows_total, running_mean, running_var, stat);
   VT_CHECK_LAUNCH();
   return 0;
