@@ -1,5 +1,5 @@
 // MultiHeadAttention::backward, per-head part (reference layers/multi_head_attention.hpp:139-181),
-// for gfx950.
+// for gfx950, on the matrix cores (exact-f32 MFMA, v_mfma_f32_32x32x2_f32).
 //
 // The layer's "batch" axis is the token index and its "sequence" axis is the mini-batch, because
 // Tensor::permute relabels the shape without moving data (utils/tensor/tensor_cpu.hpp:719-747):
@@ -12,55 +12,95 @@
 //   Y_i = sum_j attn[i][j] X_j;  Z_i = sum_j dsc[i][j] X_j
 //   gWv = sum_i Y_i^T dhead_i;  gWq = sum_i Z_i^T K_i;  gWk = sum_i X_i^T (Z_i Wq)
 // which equals X^T dV, X^T dQ, X^T dK of the reference without ever forming the T x T matrices
-// (flash-style: at T = 1024 they would be 4 MB per group and head).
+// in memory (flash-style: at T = 1024 they would be 4 MB per group and head).
 //
-// Mapping: one workgroup = 64 query-side rows i (lane = row) of one (head, group); its four waves
-// sweep disjoint quarters of the j range and merge their unnormalised sums through LDS.  Each
-// wave stages tiles of 32 rows j (Q_j, V_j, X_j: 64 floats per row) into its own LDS region with
-// coalesced 16-byte loads and consumes them with wave-uniform (broadcast) ds_read_b128.
+// Kernel 1 (k_mha_rows): one wave = 32 rows i of one (head, group), sweeping j in tiles of 32.
+// All five contractions are 32x32 MFMA tiles.  The score tile is computed TRANSPOSED,
+//   S^T[j][i] = sum_e Q[j][e] K[i][e],   dA^T[j][i] = sum_e V[j][e] dhead[i][e],
+// so that its accumulator layout (column i on the lane, rows j in the 16 registers) is directly
+// the B operand of the next product, which contracts over j:
+//   Y^T[d][i] += sum_j X[j][d] E^T[j][i],   W^T[d][i] += sum_j X[j][d] (E*dA)^T[j][i].
+// No LDS, no lane shuffles in the loop; per-row softmax quantities are per-lane scalars.
 // Softmax uses a per-row upper bound of the scores instead of the exact row maximum
-// (|K_i.Q_j| <= |K_i| max_j |Q_j|): softmax is shift invariant, so this changes nothing but the
-// rounding, and it removes a whole pass over j.
+// (|K_i.Q_j| <= |K_i| max_j |Q_j|): softmax is shift invariant, so only the rounding changes, and
+// a whole pass over j disappears.
+// Kernel 2 (k_mha_wgrad): the three [D x HD] gradient products over row blocks, slab + reduce.
 #include "vtcnn_common.h"
 
 namespace vt {
 
-constexpr int MH_STRIDE = 3 * D * HD;  // per-workgroup partials: gq[D*HD] | gk[D*HD] | gv[D*HD]
-constexpr int TJ = 32;                 // rows j per staged tile
-constexpr int ROWF = 2 * HD + D;       // floats per staged row: Q(16) V(16) X(32)
+typedef float floatx16 __attribute__((ext_vector_type(16)));
 
-__global__ __launch_bounds__(TPB) void k_mha_bwd(const float *__restrict__ qkv, const float *__restrict__ dc,
-                                                 const float *__restrict__ tok, const float *__restrict__ Wqkv,
-                                                 float *__restrict__ scratch, int T, long rows, int groups) {
-  // LDS: staging (4 waves x TJ x 64 floats = 32 KB) is dead once the j sweep ends and is reused
-  // for the cross-wave merge (3 x 64 x 67 floats = 51 KB).
-  __shared__ __align__(16) float smem[(NW - 1) * 64 * (2 * D + 3)];
-  __shared__ float sqmax[NW];
-  __shared__ float sout[MH_STRIDE];
-  const int tiles = (T + 63) / 64;
-  const int tile = blockIdx.x % tiles, bgrp = (blockIdx.x / tiles) % groups, h = blockIdx.x / (tiles * groups);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int i = tile * 64 + lane;
-  const bool ok = i < T;
+constexpr int MH_STRIDE = 3 * D * HD;  // per-workgroup partials: gq[D*HD] | gk[D*HD] | gv[D*HD]
+
+// accumulator register v of lane half hh holds row (v&3) + 8*(v>>2) + 4*hh of a 32x32 tile
+__device__ __forceinline__ int acc_row(int v, int hh) { return (v & 3) + 8 * (v >> 2) + 4 * hh; }
+
+// Partial, unnormalised row sums of one j range ("split"): because every split uses the same
+// per-row score bound, partials from different splits simply add.
+//   yz [head][split][2 (Y~, W~)][D][rows]      st [head][split][2 (sum e, sum e*dattn)][rows]
+// (row index fastest: coalesced for both kernels)
+struct TileRegs {
+  float4 q0, q1, v0, v1;
+  float xa[16];
+};
+
+__device__ __forceinline__ void load_tile(TileRegs &r, const float *__restrict__ Qm, const float *__restrict__ Vm,
+                                          const float *__restrict__ tok, long gbase, int jt, int T, int h, int c,
+                                          int hh) {
+  const int j = jt + c;
+  const long row_j = gbase + (j < T ? j : T - 1);
+  r.q0 = *reinterpret_cast<const float4 *>(Qm + row_j * D + h * HD + 8 * hh);
+  r.q1 = *reinterpret_cast<const float4 *>(Qm + row_j * D + h * HD + 8 * hh + 4);
+  r.v0 = *reinterpret_cast<const float4 *>(Vm + row_j * D + h * HD + 8 * hh);
+  r.v1 = *reinterpret_cast<const float4 *>(Vm + row_j * D + h * HD + 8 * hh + 4);
+#pragma unroll
+  for (int v = 0; v < 16; ++v) {
+    const int jr = jt + acc_row(v, hh);
+    r.xa[v] = tok[(gbase + (jr < T ? jr : T - 1)) * D + c];
+  }
+}
+
+__global__ __launch_bounds__(64) void k_mha_rows(const float *__restrict__ qkv, const float *__restrict__ dc,
+                                                 const float *__restrict__ tok, float *__restrict__ yz,
+                                                 float *__restrict__ st, int T, long rows, int groups, int nsplit) {
+  static_assert(HD == 16 && D == 32, "tile shapes are written for head_dim 16, token channels 32");
+  const int itiles = (T + 31) / 32;
+  int bi = blockIdx.x;
+  const int sp = bi % nsplit; bi /= nsplit;
+  const int itile = bi % itiles; bi /= itiles;
+  const int bgrp = bi % groups, h = bi / groups;
+  const int lane = threadIdx.x, c = lane & 31, hh = lane >> 5;
   const long gbase = (long)bgrp * T;
-  const long ri = gbase + (ok ? i : 0);
   const float *__restrict__ Qm = qkv, *__restrict__ Km = qkv + rows * D, *__restrict__ Vm = qkv + 2 * rows * D;
   const float scale = 1.0f / sqrtf((float)HD);
-  float Ki[HD], dh[HD];
+  const int i = itile * 32 + c;
+  const bool ok_i = i < T;
+  const long row_i = gbase + (ok_i ? i : T - 1);
+  // this split's j range, in whole tiles
+  const int tps = (itiles + nsplit - 1) / nsplit;
+  const int jbeg = sp * tps * 32, jend = min(T, (sp + 1) * tps * 32);
+
+  // B operands of the score products: element t of lane half hh is head column e = 8*hh + t
+  // (the order of the contraction index is free as long as A and B agree).
+  float kb[8], db[8];
+  {
+    const float4 k0 = *reinterpret_cast<const float4 *>(Km + row_i * D + h * HD + 8 * hh);
+    const float4 k1 = *reinterpret_cast<const float4 *>(Km + row_i * D + h * HD + 8 * hh + 4);
+    const float4 d0 = *reinterpret_cast<const float4 *>(dc + row_i * D + h * HD + 8 * hh);
+    const float4 d1 = *reinterpret_cast<const float4 *>(dc + row_i * D + h * HD + 8 * hh + 4);
+    kb[0] = k0.x; kb[1] = k0.y; kb[2] = k0.z; kb[3] = k0.w; kb[4] = k1.x; kb[5] = k1.y; kb[6] = k1.z; kb[7] = k1.w;
+    db[0] = d0.x; db[1] = d0.y; db[2] = d0.z; db[3] = d0.w; db[4] = d1.x; db[5] = d1.y; db[6] = d1.z; db[7] = d1.w;
+  }
+  TileRegs nxt;
+  if (jbeg < jend) load_tile(nxt, Qm, Vm, tok, gbase, jbeg, T, h, c, hh);
   float kn2 = 0.f;
 #pragma unroll
-  for (int q = 0; q < HD / 4; ++q) {
-    const float4 kv = *reinterpret_cast<const float4 *>(Km + ri * D + h * HD + 4 * q);
-    const float4 dv = *reinterpret_cast<const float4 *>(dc + ri * D + h * HD + 4 * q);
-    Ki[4 * q] = kv.x; Ki[4 * q + 1] = kv.y; Ki[4 * q + 2] = kv.z; Ki[4 * q + 3] = kv.w;
-    dh[4 * q] = dv.x; dh[4 * q + 1] = dv.y; dh[4 * q + 2] = dv.z; dh[4 * q + 3] = dv.w;
-    kn2 += kv.x * kv.x + kv.y * kv.y + kv.z * kv.z + kv.w * kv.w;
-  }
-  const int jchunk = (T + NW - 1) / NW;
-  const int j0 = wave * jchunk, j1 = min(T, j0 + jchunk);
-  // largest |Q_j|^2 of the group (all four waves together cover every j)
+  for (int t = 0; t < 8; ++t) kn2 += kb[t] * kb[t];
+  kn2 += __shfl_xor(kn2, 32);
+  // largest |Q_j|^2 of the whole group (identical in every split)
   float qn2 = 0.f;
-  for (int j = j0 + lane; j < j1; j += 64) {
+  for (int j = lane; j < T; j += 64) {
     float s = 0.f;
 #pragma unroll
     for (int q = 0; q < HD / 4; ++q) {
@@ -70,120 +110,131 @@ __global__ __launch_bounds__(TPB) void k_mha_bwd(const float *__restrict__ qkv, 
     qn2 = fmaxf(qn2, s);
   }
   qn2 = wave_max(qn2);
-  if (lane == 0) sqmax[wave] = qn2;
-  __syncthreads();
-  qn2 = fmaxf(fmaxf(sqmax[0], sqmax[1]), fmaxf(sqmax[2], sqmax[3]));
-  const float mx = scale * sqrtf(kn2) * sqrtf(qn2);  // >= every scaled score of this row
+  const float mx = scale * sqrtf(kn2) * sqrtf(qn2);  // >= every scaled score of row i
 
-  float Yt[D], Wt[D], ssum = 0.f, tsum = 0.f;
+  floatx16 accY, accW;
 #pragma unroll
-  for (int d = 0; d < D; ++d) { Yt[d] = 0.f; Wt[d] = 0.f; }
-  float *stage = smem + wave * (TJ * ROWF);
-  const int ntile = (jchunk + TJ - 1) / TJ;  // same trip count for every wave (barriers inside)
-  for (int t = 0; t < ntile; ++t) {
-    const int jt = j0 + t * TJ;
-    const int cnt = max(0, min(TJ, j1 - jt));
-    __syncthreads();  // previous tile fully consumed
-    // stage: row r of the tile = [Q(16) | V(16) | X(32)], 16 float4 per row, 512 float4 per tile
+  for (int v = 0; v < 16; ++v) { accY[v] = 0.f; accW[v] = 0.f; }
+  float ssum = 0.f, tsum = 0.f;
+
+  for (int jt = jbeg; jt < jend; jt += 32) {
+    const TileRegs cur = nxt;
+    if (jt + 32 < jend) load_tile(nxt, Qm, Vm, tok, gbase, jt + 32, T, h, c, hh);  // in flight during the MFMAs
+    const float qa[8] = {cur.q0.x, cur.q0.y, cur.q0.z, cur.q0.w, cur.q1.x, cur.q1.y, cur.q1.z, cur.q1.w};
+    const float va[8] = {cur.v0.x, cur.v0.y, cur.v0.z, cur.v0.w, cur.v1.x, cur.v1.y, cur.v1.z, cur.v1.w};
+    floatx16 accS, accD;
 #pragma unroll
-    for (int rep = 0; rep < TJ * ROWF / 4 / 64; ++rep) {
-      const int idx = rep * 64 + lane;
-      const int r = idx >> 4, part = idx & 15;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (r < cnt) {
-        const long row = gbase + jt + r;
-        const float *src = part < 4 ? Qm + row * D + h * HD + 4 * part
-                         : part < 8 ? Vm + row * D + h * HD + 4 * (part - 4)
-                                    : tok + row * D + 4 * (part - 8);
-        v = *reinterpret_cast<const float4 *>(src);
-      }
-      *reinterpret_cast<float4 *>(stage + r * ROWF + 4 * part) = v;
+    for (int v = 0; v < 16; ++v) { accS[v] = 0.f; accD[v] = 0.f; }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      accS = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[t], kb[t], accS, 0, 0, 0);
+      accD = __builtin_amdgcn_mfma_f32_32x32x2f32(va[t], db[t], accD, 0, 0, 0);
     }
-    __syncthreads();
-    for (int jj = 0; jj < cnt; ++jj) {
-      const float4 *rowp = reinterpret_cast<const float4 *>(stage + jj * ROWF);
-      float s = 0.f, da = 0.f;
 #pragma unroll
-      for (int q = 0; q < HD / 4; ++q) {
-        const float4 qv = rowp[q], vv = rowp[4 + q];
-        s += Ki[4 * q] * qv.x + Ki[4 * q + 1] * qv.y + Ki[4 * q + 2] * qv.z + Ki[4 * q + 3] * qv.w;
-        da += dh[4 * q] * vv.x + dh[4 * q + 1] * vv.y + dh[4 * q + 2] * vv.z + dh[4 * q + 3] * vv.w;
-      }
-      const float ev = __expf(s * scale - mx);
-      const float ed = ev * da;
+    for (int v = 0; v < 16; ++v) {
+      const bool ok_j = jt + acc_row(v, hh) < T;
+      const float ev = ok_j ? __expf(accS[v] * scale - mx) : 0.f;
+      const float ed = ev * accD[v];
       ssum += ev;
       tsum += ed;
+      accS[v] = ev;
+      accD[v] = ed;
+    }
 #pragma unroll
-      for (int q = 0; q < D / 4; ++q) {
-        const float4 xv = rowp[8 + q];
-        Yt[4 * q] += ev * xv.x; Yt[4 * q + 1] += ev * xv.y; Yt[4 * q + 2] += ev * xv.z; Yt[4 * q + 3] += ev * xv.w;
-        Wt[4 * q] += ed * xv.x; Wt[4 * q + 1] += ed * xv.y; Wt[4 * q + 2] += ed * xv.z; Wt[4 * q + 3] += ed * xv.w;
-      }
+    for (int v = 0; v < 16; ++v) {
+      accY = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.xa[v], accS[v], accY, 0, 0, 0);
+      accW = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.xa[v], accD[v], accW, 0, 0, 0);
     }
   }
-  __syncthreads();  // staging region is reused below
-  if (wave > 0) {
-    float *r = smem + ((wave - 1) * 64 + lane) * (2 * D + 3);
+  ssum += __shfl_xor(ssum, 32);
+  tsum += __shfl_xor(tsum, 32);
+  if (ok_i) {
+    const size_t hs = (size_t)h * nsplit + sp;
+    float *yb = yz + (hs * 2 + 0) * D * rows + gbase + i;
+    float *wb = yz + (hs * 2 + 1) * D * rows + gbase + i;
 #pragma unroll
-    for (int d = 0; d < D; ++d) { r[d] = Yt[d]; r[D + d] = Wt[d]; }
-    r[2 * D] = ssum;
-    r[2 * D + 1] = tsum;
+    for (int v = 0; v < 16; ++v) {
+      const int d = acc_row(v, hh);
+      yb[(size_t)d * rows] = accY[v];
+      wb[(size_t)d * rows] = accW[v];
+    }
+    if (hh == 0) {
+      st[(hs * 2 + 0) * rows + gbase + i] = ssum;
+      st[(hs * 2 + 1) * rows + gbase + i] = tsum;
+    }
+  }
+}
+
+// Merges the splits (Y = Y~/s, Z = W~/s - (t/s) Y) and forms, over a block of RB rows of one head,
+//   gq = Z^T K,  gk = X^T (Z Wq),  gv = Y^T dhead.
+__global__ __launch_bounds__(TPB) void k_mha_wgrad(const float *__restrict__ yz, const float *__restrict__ st,
+                                                   const float *__restrict__ qkv, const float *__restrict__ dc,
+                                                   const float *__restrict__ tok, const float *__restrict__ Wqkv,
+                                                   float *__restrict__ slab, long rows, int nsplit) {
+  __shared__ float sY[D][RB + 1], sZ[D][RB + 1], sX[RB][D + 1];
+  __shared__ float sK[RB][HD + 1], sdH[RB][HD + 1], sdK[RB][HD + 1], sWq[D * HD];
+  __shared__ float sInv[RB], sDot[RB];
+  const int tid = threadIdx.x, h = blockIdx.y;
+  const long r0 = (long)blockIdx.x * RB;
+  const int cnt = (int)min((long)RB, rows - r0);
+  const float *__restrict__ Km = qkv + rows * D;
+  if (tid < RB) {
+    float s = 0.f, t = 0.f;
+    if (tid < cnt)
+      for (int sp = 0; sp < nsplit; ++sp) {
+        s += st[(((size_t)h * nsplit + sp) * 2 + 0) * rows + r0 + tid];
+        t += st[(((size_t)h * nsplit + sp) * 2 + 1) * rows + r0 + tid];
+      }
+    const float inv = tid < cnt ? 1.0f / s : 0.f;
+    sInv[tid] = inv;
+    sDot[tid] = t * inv;
+  }
+  for (int idx = tid; idx < RB * D; idx += TPB) {
+    const int r = idx / D, d = idx % D;
+    sX[r][d] = r < cnt ? tok[(r0 + r) * D + d] : 0.f;
+  }
+  for (int idx = tid; idx < RB * HD; idx += TPB) {
+    const int r = idx / HD, e = idx % HD;
+    const bool ok = r < cnt;
+    sK[r][e] = ok ? Km[(r0 + r) * D + h * HD + e] : 0.f;
+    sdH[r][e] = ok ? dc[(r0 + r) * D + h * HD + e] : 0.f;
+  }
+  for (int idx = tid; idx < D * HD; idx += TPB) sWq[idx] = Wqkv[(size_t)(h * 3 + 0) * D * HD + idx];
+  __syncthreads();
+  for (int idx = tid; idx < D * RB; idx += TPB) {
+    const int d = idx / RB, r = idx % RB;
+    float y = 0.f, w = 0.f;
+    if (r < cnt)
+      for (int sp = 0; sp < nsplit; ++sp) {
+        y += yz[((((size_t)h * nsplit + sp) * 2 + 0) * D + d) * rows + r0 + r];
+        w += yz[((((size_t)h * nsplit + sp) * 2 + 1) * D + d) * rows + r0 + r];
+      }
+    y *= sInv[r];
+    sY[d][r] = y;
+    sZ[d][r] = w * sInv[r] - sDot[r] * y;
   }
   __syncthreads();
-  // wave 0 merges the four j ranges and finishes its 64 rows
-  if (wave == 0) {
-    float s = ssum, t = tsum;
-#pragma unroll
-    for (int w = 0; w < NW - 1; ++w) {
-      const float *r = smem + (w * 64 + lane) * (2 * D + 3);
-#pragma unroll
-      for (int d = 0; d < D; ++d) { Yt[d] += r[d]; Wt[d] += r[D + d]; }
-      s += r[2 * D];
-      t += r[2 * D + 1];
-    }
-    const float invs = ok ? 1.0f / s : 0.f;
-    const float dot = t * invs;
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-      Yt[d] = Yt[d] * invs;                // Y_i
-      Wt[d] = Wt[d] * invs - dot * Yt[d];  // Z_i
-    }
-    // dK_i = Z_i . Wq_h   (delta_scores . query with query = X.Wq)
-    const float *__restrict__ Wq_h = Wqkv + (size_t)(h * 3 + 0) * D * HD;
-    float dK[HD], Xi[D];
-#pragma unroll
-    for (int e = 0; e < HD; ++e) dK[e] = 0.f;
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-      Xi[d] = ok ? tok[ri * D + d] : 0.f;
-#pragma unroll
-      for (int e = 0; e < HD; ++e) dK[e] += Wt[d] * Wq_h[d * HD + e];
-    }
-    if (!ok) {
-#pragma unroll
-      for (int e = 0; e < HD; ++e) { Ki[e] = 0.f; dh[e] = 0.f; dK[e] = 0.f; }
-    }
-    // outer products summed over the 64 rows with the transposing butterfly, 64 outputs per call
-#pragma unroll
-    for (int m = 0; m < 3; ++m) {
-#pragma unroll
-      for (int blk = 0; blk < D / 4; ++blk) {
-        float acc[64];
-#pragma unroll
-        for (int dd = 0; dd < 4; ++dd)
-#pragma unroll
-          for (int e = 0; e < HD; ++e) {
-            const int d = blk * 4 + dd;
-            acc[dd * HD + e] = (m == 0) ? Wt[d] * Ki[e] : (m == 1) ? Xi[d] * dK[e] : Yt[d] * dh[e];
-          }
-        wave_xreduce<64>(acc);
-        sout[m * D * HD + blk * 64 + lane] = acc[0];
-      }
-    }
+  for (int idx = tid; idx < RB * HD; idx += TPB) {  // dK = Z . Wq_h
+    const int r = idx / HD, e = idx % HD;
+    float s = 0.f;
+#pragma unroll 8
+    for (int d = 0; d < D; ++d) s += sZ[d][r] * sWq[d * HD + e];
+    sdK[r][e] = s;
   }
   __syncthreads();
-  float *row = scratch + (size_t)blockIdx.x * MH_STRIDE;
-  for (int idx = threadIdx.x; idx < MH_STRIDE; idx += TPB) row[idx] = sout[idx];
+  float *row = slab + ((size_t)h * gridDim.x + blockIdx.x) * MH_STRIDE;
+  for (int idx = tid; idx < D * HD; idx += TPB) {
+    const int d = idx / HD, e = idx % HD;
+    float gq = 0.f, gk = 0.f, gv = 0.f;
+    for (int r = 0; r < RB; ++r) {
+      gq += sZ[d][r] * sK[r][e];
+      gk += sX[r][d] * sdK[r][e];
+      gv += sY[d][r] * sdH[r][e];
+    }
+    row[idx] = gq;
+    row[D * HD + idx] = gk;
+    row[2 * D * HD + idx] = gv;
+  }
 }
 
 }  // namespace vt
@@ -192,20 +243,36 @@ using namespace vt;
 
 extern "C" int vt_reduce_rows(const float *slab, long rows, int cols, int ld, float *out, vt_stream s);
 
+// How many j ranges each row tile is split into so that the launch has ~2 waves per SIMD.
+static int mha_splits(int N, int groups) {
+  const int itiles = (N + 31) / 32;
+  const long waves = (long)HEADS * groups * itiles;
+  int ns = (int)((2048 + waves - 1) / waves);
+  if (ns > 4) ns = 4;
+  if (ns > itiles) ns = itiles;
+  return ns < 1 ? 1 : ns;
+}
+
 // g_qkv: [q0 | k0 | v0 | q1 | k1 | v1] gradients (arena order);
-// scratch >= heads * groups * ceil(N/64) * 1536 floats.
+// scratch >= heads*4*(2*D + 2)*rows + heads*ceil(rows/64)*1536 floats with rows = N*groups.
 extern "C" int vt_mha_bwd(const float *qkv, const float *dc, const float *tok, const float *wqkv, float *g_qkv,
                           float *scratch, int N, int groups, vt_stream s) {
   if (N < 1 || groups < 1) return VT_EINVAL;
-  const int tiles = (N + 63) / 64;
+  const int itiles = (N + 31) / 32, ns = mha_splits(N, groups);
   const long rows = (long)N * groups;
-  hipLaunchKernelGGL(k_mha_bwd, dim3(HEADS * groups * tiles), dim3(TPB), 0, (hipStream_t)s, qkv, dc, tok, wqkv, scratch,
-                     N, rows, groups);
+  const int nrb = (int)((rows + RB - 1) / RB);
+  float *yz = scratch;
+  float *st = yz + (size_t)HEADS * ns * 2 * D * rows;
+  float *slab = st + (size_t)HEADS * ns * 2 * rows;
+  hipLaunchKernelGGL(k_mha_rows, dim3(HEADS * groups * itiles * ns), dim3(64), 0, (hipStream_t)s, qkv, dc, tok, yz, st,
+                     N, rows, groups, ns);
   VT_CHECK_LAUNCH();
-  // workgroups are ordered (head, group, tile): the partials of one head are contiguous rows
+  hipLaunchKernelGGL(k_mha_wgrad, dim3(nrb, HEADS), dim3(TPB), 0, (hipStream_t)s, yz, st, qkv, dc, tok, wqkv, slab, rows,
+                     ns);
+  VT_CHECK_LAUNCH();
   for (int h = 0; h < HEADS; ++h) {
-    const int rc = vt_reduce_rows(scratch + (size_t)h * groups * tiles * MH_STRIDE, (long)groups * tiles, MH_STRIDE,
-                                  MH_STRIDE, g_qkv + (size_t)h * MH_STRIDE, s);
+    const int rc = vt_reduce_rows(slab + (size_t)h * nrb * MH_STRIDE, nrb, MH_STRIDE, MH_STRIDE,
+                                  g_qkv + (size_t)h * MH_STRIDE, s);
     if (rc) return rc;
   }
   return 0;

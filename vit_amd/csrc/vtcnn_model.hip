@@ -140,7 +140,7 @@ extern "C" int vt_model_create(const vt_dims *dims, int max_batch, int device, f
   {
     // largest partial slab any backward launcher needs (see the scratch notes in vtcnn_hip.h)
     const size_t need_ffn = nrb * 2112, need_fc = ((N + 31) / 32) * (Q * K + K);
-    const size_t need_mha = (size_t)L * HEADS * ((N + 63) / 64) * 1536;
+    const size_t need_mha = (size_t)HEADS * 4 * (2 * D + 2) * NL + (size_t)HEADS * nrb * 1536;
     rc |= dalloc(m, &m->rowscratch, std::max(need_ffn, std::max(need_fc, need_mha)));
   }
   rc |= dalloc(m, &m->coef_pn, 2 * C2, "coef.proj.norm");
