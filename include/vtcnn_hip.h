@@ -158,10 +158,12 @@ int vt_projector_tokens_fwd(const float *s2, const float *n2_stat, const float *
                             const float *wq, const float *wk, const float *wv, const float *bv, float *o,
                             float *pk, int N, vt_stream s);
 /* Pixel side of ProjectorLayer::forward (projector_layer.hpp:65-104): attention over tokens,
- * downsample residual.  Writes proj_a [N,P,L], z [N,P,C2] (BatchNorm1D input) and its partial stats. */
+ * downsample residual.  Writes proj_a [N,P,L], z [N,P,C2] (BatchNorm1D input) and its partial stats.
+ * pivot [C2]: any per-channel value near the batch mean of z (the layer's running mean is used),
+ * around which the partial second moments are accumulated. */
 int vt_projector_fwd(const float *conv_out, const float *bn_stat, const float *bn_gamma, const float *bn_beta,
-                     const float *pk, const float *wd, const float *bd, float *proj_a, float *z, float *part_pn,
-                     int N, int P, vt_stream s);
+                     const float *pk, const float *wd, const float *bd, const float *pivot, float *proj_a, float *z,
+                     float *part_pn, int N, int P, vt_stream s);
 /* Projector BatchNorm1D apply + ReLU (projector_layer.hpp:106-113), the [N,P,C2]->[N,C2,H,W]
  * reinterpretation (model/vit_cnn.hpp:179), MaxPool2DLayer::forward (layers/pooling_layer.hpp:18-66),
  * Flatten, fc DenseLayer::forward and SoftmaxLayer::forward (vit_cnn.hpp:185-203).

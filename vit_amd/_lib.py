@@ -65,7 +65,7 @@ SIGNATURES = {
     "vt_tokenizer_fwd": (i, [p] * 11 + [i, i, p]),
     "vt_transformer_ffn_fwd": (i, [p] * 12 + [l, p]),
     "vt_projector_tokens_fwd": (i, [p] * 10 + [i, p]),
-    "vt_projector_fwd": (i, [p] * 10 + [i, i, p]),
+    "vt_projector_fwd": (i, [p] * 11 + [i, i, p]),
     "vt_head_fwd": (i, [p] * 10 + [i, i, i, p]),
     "vt_metrics": (i, [p, p, i, i, p, p, p]),
     "vt_head_bwd": (i, [p] * 11 + [i, i, i, p]),

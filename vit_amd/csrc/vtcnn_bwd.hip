@@ -22,69 +22,6 @@ __device__ __forceinline__ void load_x_raw(const float *__restrict__ conv, size_
 }
 
 // ---------------------------------------------------------------------------------------------
-// Head backward.  SoftmaxLayer::backward with targets: delta = softmax - onehot, no 1/N
-// (reference layers/softmax_layer.hpp:29); fc input delta = delta . W^T (dense_layer.hpp:98-99);
-// MaxPool2DLayer::backward scatter to the arg-max slot (pooling_layer.hpp:88-92); ReLU mask on the
-// flat reinterpretation (relu_layer.hpp:20-33, projector_layer.hpp:121-131); partial sums of the
-// projector BatchNorm1D backward (batch_normalization_layer.hpp:187-188).
-// One workgroup per image; the scattered delta block lives in LDS.
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(TPB) void k_head_bwd(const float *__restrict__ probs, const int *__restrict__ labels,
-                                                  const float *__restrict__ Wfc, const unsigned char *__restrict__ pool_idx,
-                                                  const float *__restrict__ z, const float *__restrict__ st,
-                                                  const float *__restrict__ g, const float *__restrict__ b,
-                                                  float *__restrict__ dlogits, float *__restrict__ du,
-                                                  float *__restrict__ part, int H, int K) {
-  extern __shared__ float sdg[];  // P*C2 scattered deltas, then NW*2*C2 reduction scratch
-  const int W = H, P = H * W, pk = H / 14, Q = C2 * 196;
-  float *red = sdg + P * C2;
-  const int n = blockIdx.x, tid = threadIdx.x;
-  const int label = labels[n];
-  float dl[KMAX];
-#pragma unroll
-  for (int k = 0; k < KMAX; ++k) dl[k] = (k < K) ? probs[(size_t)n * K + k] - (k == label ? 1.0f : 0.0f) : 0.f;
-  if (tid < K) dlogits[(size_t)n * K + tid] = probs[(size_t)n * K + tid] - (tid == label ? 1.0f : 0.0f);
-  for (int i = tid; i < P * C2 / 4; i += TPB) reinterpret_cast<float4 *>(sdg)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  __syncthreads();
-  for (int f = tid; f < Q; f += TPB) {
-    float df = 0.f;
-#pragma unroll
-    for (int k = 0; k < KMAX; ++k)
-      if (k < K) df += dl[k] * Wfc[(size_t)f * K + k];
-    const int ch = f / 196, ij = f % 196, i = ij / 14, j = ij % 14;
-    const int slot = pool_idx[(size_t)n * Q + f];
-    sdg[ch * P + (i * pk + slot / pk) * W + j * pk + slot % pk] = df;
-  }
-  __syncthreads();
-  float s[2 * C2];
-#pragma unroll
-  for (int c = 0; c < 2 * C2; ++c) s[c] = 0.f;
-  for (int p = tid; p < P; p += TPB) {
-    const float4 *src = reinterpret_cast<const float4 *>(z + ((size_t)n * P + p) * C2);
-    const float4 *dsrc = reinterpret_cast<const float4 *>(sdg + p * C2);
-    float4 *dst = reinterpret_cast<float4 *>(du + ((size_t)n * P + p) * C2);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float4 v = src[q], d = dsrc[q];
-      const float zv[4] = {v.x, v.y, v.z, v.w}, dv[4] = {d.x, d.y, d.z, d.w};
-      float o[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int c = 4 * q + e;
-        const float xh = (zv[e] - st[c]) * st[C2 + c];
-        const float y = xh * g[c] + b[c];
-        o[e] = y > 0.f ? dv[e] : 0.f;
-        s[c] += o[e];
-        s[C2 + c] += o[e] * xh;
-      }
-      dst[q] = make_float4(o[0], o[1], o[2], o[3]);
-    }
-  }
-  block_sum<2 * C2>(s, red);
-  if (tid < 2 * C2) part[(size_t)n * 2 * C2 + tid] = s[tid];
-}
-
-// ---------------------------------------------------------------------------------------------
 // fc DenseLayer::backward weight / bias gradients (reference layers/dense_layer.hpp:92-96):
 // gW[f][k] = sum_n pooled[n][f] * delta[n][k], gb[k] = sum_n delta[n][k].  Thread = one input
 // feature f, loop over a chunk of samples; chunks are summed by k_reduce_rows.
@@ -828,17 +765,6 @@ static int reduce_rows(const float *slab, long rows, int cols, int ld, float *ou
 extern "C" int vt_reduce_rows(const float *slab, long rows, int cols, int ld, float *out, vt_stream s) {
   if (rows < 1 || cols < 1 || ld < cols) return VT_EINVAL;
   return reduce_rows(slab, rows, cols, ld, out, (hipStream_t)s);
-}
-
-extern "C" int vt_head_bwd(const float *probs, const int *labels, const float *wfc, const unsigned char *pool_idx,
-                           const float *z, const float *pn_stat, const float *pn_gamma, const float *pn_beta,
-                           float *d_logits, float *du, float *part, int N, int H, int K, vt_stream s) {
-  if (N < 1 || H < 14 || H % 14 != 0 || H * H > PPT * TPB || K < 1 || K > KMAX) return VT_EUNSUPPORTED;
-  const size_t lds = (size_t)(H * H * C2 + NW * 2 * C2) * sizeof(float);
-  hipLaunchKernelGGL(k_head_bwd, dim3(N), dim3(TPB), lds, (hipStream_t)s, probs, labels, wfc, pool_idx, z, pn_stat,
-                     pn_gamma, pn_beta, d_logits, du, part, H, K);
-  VT_CHECK_LAUNCH();
-  return 0;
 }
 
 // scratch: at least ceil(N/32) * (Q*K + K) floats (unused when N <= 32).

@@ -406,42 +406,41 @@ __global__ __launch_bounds__(TPB) void k_proj_tokens_fwd(const float *__restrict
 // ---------------------------------------------------------------------------------------------
 // Pixel side of ProjectorLayer::forward (reference layers/projector_layer.hpp:65-104).
 //   a = softmax_L(x.Mq);  z = (x.Wd + bd) + a.v    (+ per-sample partial stats of z)
-// One workgroup per image; Mq, v, Wd, bd are wave-uniform operands.
+// One workgroup per image, one pixel per loop trip.  Mq, v, Wd, bd are wave-uniform operands read
+// through the scalar cache (the loop is deliberately not unrolled: with four pixels in flight the
+// compiler keeps every operand live at once and spills hundreds of SGPRs).
+// The partial statistics are accumulated around a pivot (the layer's running mean: any value
+// near the batch mean works) so no per-pixel value has to stay live after its trip:
+//   M2 = sum (z-piv)^2 - (sum (z-piv))^2 / P.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(TPB) void k_proj_fwd(const float *__restrict__ conv, const float *__restrict__ st,
                                                   const float *__restrict__ g, const float *__restrict__ b,
                                                   const float *__restrict__ pk, const float *__restrict__ Wd,
-                                                  const float *__restrict__ bd, float *__restrict__ projA,
-                                                  float *__restrict__ z, float *__restrict__ part_pn, int P) {
-  __shared__ float red[NW * C2];
+                                                  const float *__restrict__ bd, const float *__restrict__ piv,
+                                                  float *__restrict__ projA, float *__restrict__ z,
+                                                  float *__restrict__ part_pn, int P) {
+  __shared__ float red[NW * 2 * C2];
   const int n = blockIdx.x, tid = threadIdx.x;
   const float *__restrict__ mq = pk + (size_t)n * PK_STRIDE;
   const float *__restrict__ vv = mq + C1 * L;
-  float zv[PPT][C2];
-  float s[C2];
+  float s[2 * C2];
 #pragma unroll
-  for (int c = 0; c < C2; ++c) s[c] = 0.f;
-#pragma unroll
-  for (int it = 0; it < PPT; ++it) {
-    const int p = tid + it * TPB;
-    const bool ok = p < P;
+  for (int c = 0; c < 2 * C2; ++c) s[c] = 0.f;
+#pragma unroll 1
+  for (int p = tid; p < P; p += TPB) {
     float x[C1];
-    if (ok) {
-      load_x(conv, (size_t)n * P + p, st, g, b, x);
-    } else {
-#pragma unroll
-      for (int ch = 0; ch < C1; ++ch) x[ch] = 0.f;
-    }
+    load_x(conv, (size_t)n * P + p, st, g, b, x);
     float a[L];
-    float mx = -INFINITY;
 #pragma unroll
-    for (int l = 0; l < L; ++l) {
-      float sc = 0.f;
+    for (int l = 0; l < L; ++l) a[l] = 0.f;
 #pragma unroll
-      for (int ch = 0; ch < C1; ++ch) sc += x[ch] * mq[ch * L + l];
-      a[l] = sc;
-      mx = fmaxf(mx, sc);
+    for (int ch = 0; ch < C1; ++ch) {
+#pragma unroll
+      for (int l = 0; l < L; ++l) a[l] += x[ch] * mq[ch * L + l];
     }
+    float mx = a[0];
+#pragma unroll
+    for (int l = 1; l < L; ++l) mx = fmaxf(mx, a[l]);
     float sum = 0.f;
 #pragma unroll
     for (int l = 0; l < L; ++l) {
@@ -450,124 +449,41 @@ __global__ __launch_bounds__(TPB) void k_proj_fwd(const float *__restrict__ conv
     }
 #pragma unroll
     for (int l = 0; l < L; ++l) a[l] = a[l] / sum;
+    float ds[C2], av[C2];
+#pragma unroll
+    for (int c = 0; c < C2; ++c) { ds[c] = 0.f; av[c] = 0.f; }
+#pragma unroll
+    for (int ch = 0; ch < C1; ++ch) {
+#pragma unroll
+      for (int c = 0; c < C2; ++c) ds[c] += x[ch] * Wd[ch * C2 + c];
+    }
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+#pragma unroll
+      for (int c = 0; c < C2; ++c) av[c] += a[l] * vv[l * C2 + c];
+    }
+    float zv[C2];
 #pragma unroll
     for (int c = 0; c < C2; ++c) {
-      float ds = 0.f;
-#pragma unroll
-      for (int ch = 0; ch < C1; ++ch) ds += x[ch] * Wd[ch * C2 + c];
-      ds += bd[c];
-      float av = 0.f;
-#pragma unroll
-      for (int l = 0; l < L; ++l) av += a[l] * vv[l * C2 + c];
-      zv[it][c] = ok ? ds + av : 0.f;
-      s[c] += zv[it][c];
+      zv[c] = (ds[c] + bd[c]) + av[c];
+      const float dlt = zv[c] - piv[c];
+      s[c] += dlt;
+      s[C2 + c] += dlt * dlt;
     }
-    if (ok) {
-      float4 *da = reinterpret_cast<float4 *>(projA + ((size_t)n * P + p) * L);
-      float4 *dz = reinterpret_cast<float4 *>(z + ((size_t)n * P + p) * C2);
+    float4 *da = reinterpret_cast<float4 *>(projA + ((size_t)n * P + p) * L);
+    float4 *dz = reinterpret_cast<float4 *>(z + ((size_t)n * P + p) * C2);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        da[q] = make_float4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
-        dz[q] = make_float4(zv[it][4 * q], zv[it][4 * q + 1], zv[it][4 * q + 2], zv[it][4 * q + 3]);
-      }
+    for (int q = 0; q < 4; ++q) {
+      da[q] = make_float4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
+      dz[q] = make_float4(zv[4 * q], zv[4 * q + 1], zv[4 * q + 2], zv[4 * q + 3]);
     }
   }
   if (part_pn == nullptr) return;
-  block_sum<C2>(s, red);
-  float m2[C2];
-  const float invP = 1.0f / (float)P;
-#pragma unroll
-  for (int c = 0; c < C2; ++c) {
-    const float mu = s[c] * invP;
-    float q = 0.f;
-#pragma unroll
-    for (int it = 0; it < PPT; ++it) {
-      const float dlt = zv[it][c] - mu;
-      q += (tid + it * TPB < P) ? dlt * dlt : 0.f;
-    }
-    m2[c] = q;
-  }
-  block_sum<C2>(m2, red);
+  block_sum<2 * C2>(s, red);
   if (tid < C2) {
-    part_pn[(size_t)n * 2 * C2 + tid] = s[tid];
-    part_pn[(size_t)n * 2 * C2 + C2 + tid] = m2[tid];
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Head: projector BatchNorm1D apply + ReLU (projector_layer.hpp:106-113), reinterpretation of the
-// [P,C2] record block as [C2,H,W] (model/vit_cnn.hpp:179), MaxPool2DLayer::forward (first strictly
-// greater element wins, layers/pooling_layer.hpp:40-59), Flatten + fc + softmax
-// (vit_cnn.hpp:191-203, tensor_cpu.hpp:894-944).  One workgroup per image; the activated block
-// (P*C2 floats) is staged in LDS because pooling windows straddle pixel records.
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(TPB) void k_head_fwd(const float *__restrict__ z, const float *__restrict__ st,
-                                                  const float *__restrict__ g, const float *__restrict__ b,
-                                                  const float *__restrict__ Wfc, const float *__restrict__ bfc,
-                                                  float *__restrict__ pooled, unsigned char *__restrict__ pool_idx,
-                                                  float *__restrict__ logits, float *__restrict__ probs, int H,
-                                                  int K) {
-  extern __shared__ float su[];  // P*C2 activated values, then NW*KMAX reduction scratch
-  const int W = H, P = H * W, pk = H / 14, Q = C2 * 196;
-  float *red = su + P * C2;
-  const int n = blockIdx.x, tid = threadIdx.x;
-  for (int p = tid; p < P; p += TPB) {
-    const float4 *src = reinterpret_cast<const float4 *>(z + ((size_t)n * P + p) * C2);
-    float4 *dst = reinterpret_cast<float4 *>(su + p * C2);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float4 v = src[q];
-      const int c = 4 * q;
-      float4 o;
-      o.x = fmaxf(((v.x - st[c]) * st[C2 + c]) * g[c] + b[c], 0.f);
-      o.y = fmaxf(((v.y - st[c + 1]) * st[C2 + c + 1]) * g[c + 1] + b[c + 1], 0.f);
-      o.z = fmaxf(((v.z - st[c + 2]) * st[C2 + c + 2]) * g[c + 2] + b[c + 2], 0.f);
-      o.w = fmaxf(((v.w - st[c + 3]) * st[C2 + c + 3]) * g[c + 3] + b[c + 3], 0.f);
-      dst[q] = o;
-    }
-  }
-  __syncthreads();
-  float acc[KMAX];
-#pragma unroll
-  for (int k = 0; k < KMAX; ++k) acc[k] = 0.f;
-  for (int f = tid; f < Q; f += TPB) {
-    const int ch = f / 196, ij = f % 196, i = ij / 14, j = ij % 14;
-    const int base = ch * P + (i * pk) * W + j * pk;
-    float mv = -INFINITY;
-    int mi = 0;
-    for (int ki = 0; ki < pk; ++ki)
-      for (int kj = 0; kj < pk; ++kj) {
-        const float val = su[base + ki * W + kj];
-        if (val > mv) {
-          mv = val;
-          mi = ki * pk + kj;
-        }
-      }
-    pooled[(size_t)n * Q + f] = mv;
-    pool_idx[(size_t)n * Q + f] = (unsigned char)mi;
-#pragma unroll
-    for (int k = 0; k < KMAX; ++k)
-      if (k < K) acc[k] += mv * Wfc[(size_t)f * K + k];
-  }
-  block_sum<KMAX>(acc, red);
-  if (tid == 0) {
-    float lg[KMAX], mx = -INFINITY, sum = 0.f;
-#pragma unroll
-    for (int k = 0; k < KMAX; ++k)
-      if (k < K) {
-        lg[k] = acc[k] + bfc[k];
-        mx = fmaxf(mx, lg[k]);
-      }
-#pragma unroll
-    for (int k = 0; k < KMAX; ++k)
-      if (k < K) {
-        logits[(size_t)n * K + k] = lg[k];
-        lg[k] = expf(lg[k] - mx);
-        sum += lg[k];
-      }
-#pragma unroll
-    for (int k = 0; k < KMAX; ++k)
-      if (k < K) probs[(size_t)n * K + k] = lg[k] / sum;
+    const float d1 = s[tid], d2 = s[C2 + tid];
+    part_pn[(size_t)n * 2 * C2 + tid] = d1 + (float)P * piv[tid];
+    part_pn[(size_t)n * 2 * C2 + C2 + tid] = fmaxf(d2 - d1 * d1 / (float)P, 0.f);
   }
 }
 
@@ -661,22 +577,11 @@ extern "C" int vt_projector_tokens_fwd(const float *s2, const float *n2_stat, co
 }
 
 extern "C" int vt_projector_fwd(const float *conv_out, const float *bn_stat, const float *bn_gamma, const float *bn_beta,
-                                const float *pk, const float *wd, const float *bd, float *proj_a, float *z,
-                                float *part_pn, int N, int P, vt_stream s) {
-  if (N < 1 || P < 1 || P > PPT * TPB) return VT_EUNSUPPORTED;
+                                const float *pk, const float *wd, const float *bd, const float *pivot, float *proj_a,
+                                float *z, float *part_pn, int N, int P, vt_stream s) {
+  if (N < 1 || P < 1 || !pivot) return VT_EUNSUPPORTED;
   hipLaunchKernelGGL(k_proj_fwd, dim3(N), dim3(TPB), 0, (hipStream_t)s, conv_out, bn_stat, bn_gamma, bn_beta, pk, wd,
-                     bd, proj_a, z, part_pn, P);
-  VT_CHECK_LAUNCH();
-  return 0;
-}
-
-extern "C" int vt_head_fwd(const float *z, const float *pn_stat, const float *pn_gamma, const float *pn_beta,
-                           const float *wfc, const float *bfc, float *pooled, unsigned char *pool_idx, float *logits,
-                           float *probs, int N, int H, int K, vt_stream s) {
-  if (N < 1 || H < 14 || H % 14 != 0 || H * H > PPT * TPB || K < 1 || K > KMAX) return VT_EUNSUPPORTED;
-  const size_t lds = (size_t)(H * H * C2 + NW * KMAX) * sizeof(float);
-  hipLaunchKernelGGL(k_head_fwd, dim3(N), dim3(TPB), lds, (hipStream_t)s, z, pn_stat, pn_gamma, pn_beta, wfc, bfc,
-                     pooled, pool_idx, logits, probs, H, K);
+                     bd, pivot, proj_a, z, part_pn, P);
   VT_CHECK_LAUNCH();
   return 0;
 }

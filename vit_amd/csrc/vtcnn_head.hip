@@ -1,0 +1,245 @@
+// Classifier head of VTCNN for gfx950: projector BatchNorm1D apply + ReLU, the [N,P,C2] ->
+// [N,C2,H,W] reinterpretation, max-pool, fc, softmax, and their backward.
+//
+// The reinterpretation (reference model/vit_cnn.hpp:179) moves no data: the P*C2 floats of one
+// image are simply read as C2 planes of H*W.  A pooling window therefore touches flat offsets
+// base, base+1, ..., base+W, ... of the image's record block, and the BatchNorm channel of a flat
+// offset F is F mod C2.  Both kernels work straight from global memory (no LDS staging), so many
+// workgroups fit per CU and latency is hidden by occupancy.
+#include "vtcnn_common.h"
+
+namespace vt {
+
+// BatchNorm1D apply of one element (x_norm * gamma + beta, batch_normalization_layer.hpp:155,168)
+__device__ __forceinline__ float bn_apply(float v, const float *__restrict__ sbn, int c, float *xhat) {
+  const float xh = (v - sbn[c]) * sbn[C2 + c];
+  if (xhat) *xhat = xh;
+  return xh * sbn[2 * C2 + c] + sbn[3 * C2 + c];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Forward: ReLU(BN(z)) (projector_layer.hpp:106-113) -> MaxPool2DLayer::forward, first strictly
+// greater element wins (layers/pooling_layer.hpp:40-59) -> Flatten -> fc -> softmax
+// (vit_cnn.hpp:191-203, tensor_cpu.hpp:894-944).  One workgroup per image, one thread per pooled
+// output (12.25 per thread at 28x28).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void k_head_fwd(const float *__restrict__ z, const float *__restrict__ st,
+                                                  const float *__restrict__ g, const float *__restrict__ b,
+                                                  const float *__restrict__ Wfc, const float *__restrict__ bfc,
+                                                  float *__restrict__ pooled, unsigned char *__restrict__ pool_idx,
+                                                  float *__restrict__ logits, float *__restrict__ probs, int H,
+                                                  int K) {
+  __shared__ float sbn[4 * C2];
+  __shared__ float red[NW * KMAX];
+  const int W = H, P = H * W, pk = H / 14, Q = C2 * 196;
+  const int n = blockIdx.x, tid = threadIdx.x;
+  if (tid < C2) {
+    sbn[tid] = st[tid];
+    sbn[C2 + tid] = st[C2 + tid];
+    sbn[2 * C2 + tid] = g[tid];
+    sbn[3 * C2 + tid] = b[tid];
+  }
+  __syncthreads();
+  const float *__restrict__ zi = z + (size_t)n * P * C2;
+  float acc[KMAX];
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) acc[k] = 0.f;
+  for (int f = tid; f < Q; f += TPB) {
+    const int ch = f / 196, ij = f % 196, i = ij / 14, j = ij % 14;
+    const int base = ch * P + (i * pk) * W + j * pk;
+    float mv = -INFINITY;
+    int mi = 0;
+    if (pk == 2) {  // 28x28: two aligned 8-byte loads per window
+      const float2 r0 = *reinterpret_cast<const float2 *>(zi + base);
+      const float2 r1 = *reinterpret_cast<const float2 *>(zi + base + W);
+      const float v[4] = {r0.x, r0.y, r1.x, r1.y};
+      const int off[4] = {0, 1, W, W + 1};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float y = fmaxf(bn_apply(v[q], sbn, (base + off[q]) & (C2 - 1), nullptr), 0.f);
+        if (y > mv) {
+          mv = y;
+          mi = q;
+        }
+      }
+    } else {
+      for (int ki = 0; ki < pk; ++ki)
+        for (int kj = 0; kj < pk; ++kj) {
+          const int F = base + ki * W + kj;
+          const float y = fmaxf(bn_apply(zi[F], sbn, F & (C2 - 1), nullptr), 0.f);
+          if (y > mv) {
+            mv = y;
+            mi = ki * pk + kj;
+          }
+        }
+    }
+    pooled[(size_t)n * Q + f] = mv;
+    pool_idx[(size_t)n * Q + f] = (unsigned char)mi;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+      if (k < K) acc[k] += mv * Wfc[(size_t)f * K + k];
+  }
+  block_sum<KMAX>(acc, red);
+  if (tid == 0) {
+    float lg[KMAX], mx = -INFINITY, sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+      if (k < K) {
+        lg[k] = acc[k] + bfc[k];
+        mx = fmaxf(mx, lg[k]);
+      }
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+      if (k < K) {
+        logits[(size_t)n * K + k] = lg[k];
+        lg[k] = expf(lg[k] - mx);
+        sum += lg[k];
+      }
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+      if (k < K) probs[(size_t)n * K + k] = lg[k] / sum;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Backward.  SoftmaxLayer::backward with targets: delta = softmax - onehot, no 1/N
+// (reference layers/softmax_layer.hpp:29); fc input delta = delta . W^T (dense_layer.hpp:98-99);
+// MaxPool2DLayer::backward routes it to the arg-max slot (pooling_layer.hpp:88-92); ReLU mask on
+// the flat reinterpretation (relu_layer.hpp:20-33, projector_layer.hpp:121-131); partial sums of
+// the projector BatchNorm1D backward (batch_normalization_layer.hpp:187-188).
+// Phase 1 forms the fc delta of every pooling window (K MACs each) into a 12.5 KB LDS table.
+// Phase 2 is a gather: one thread per pixel record (C2 consecutive flat offsets); each element
+// looks up its window's arg-max slot and takes the window's delta if it is the winner and active.
+// Every element of du is written exactly once; no scatter, no zero fill, and the per-channel sums
+// fall out of the record layout.
+// ---------------------------------------------------------------------------------------------
+template <int PKC>  // PKC = compile-time pool kernel (2 for 28x28 inputs), 0 = use the runtime value
+__global__ __launch_bounds__(TPB) void k_head_bwd(const float *__restrict__ probs, const int *__restrict__ labels,
+                                                  const float *__restrict__ Wfc, const unsigned char *__restrict__ pool_idx,
+                                                  const float *__restrict__ z, const float *__restrict__ st,
+                                                  const float *__restrict__ g, const float *__restrict__ b,
+                                                  float *__restrict__ dlogits, float *__restrict__ du,
+                                                  float *__restrict__ part, int H, int K) {
+  __shared__ float red[NW * 2 * C2];
+  const int W = H, P = H * W, pk = PKC ? PKC : H / 14, Q = C2 * 196;
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const int label = labels[n];
+  float dl[KMAX];
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) dl[k] = (k < K) ? probs[(size_t)n * K + k] - (k == label ? 1.0f : 0.0f) : 0.f;
+  if (tid < K) dlogits[(size_t)n * K + tid] = probs[(size_t)n * K + tid] - (tid == label ? 1.0f : 0.0f);
+  const unsigned char *__restrict__ pix = pool_idx + (size_t)n * Q;
+  // phase 1: fc input delta of every pooling window (one window per thread trip), kept in LDS
+  extern __shared__ float sdf[];  // Q floats
+  for (int f = tid; f < Q; f += TPB) {
+    float d = 0.f;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+      if (k < K) d += dl[k] * Wfc[(size_t)f * K + k];
+    sdf[f] = d;
+  }
+  __syncthreads();
+  float s[2 * C2];
+#pragma unroll
+  for (int c = 0; c < 2 * C2; ++c) s[c] = 0.f;
+  for (int p = tid; p < P; p += TPB) {
+    const float4 *src = reinterpret_cast<const float4 *>(z + ((size_t)n * P + p) * C2);
+    float4 *dst = reinterpret_cast<float4 *>(du + ((size_t)n * P + p) * C2);
+    const int F0 = p * C2;
+    int ch = F0 / P, rem = F0 - ch * P, h = rem / W, w = rem - h * W;
+    if (PKC == 2 && (W & 3) == 0) {
+      // 2x2 windows, row length a multiple of 4: each group of 4 consecutive elements lies in one
+      // row and covers exactly two windows f0, f0+1 (f0 even).  Everything a group needs (two slot
+      // bytes, two fc rows) is loaded unconditionally, so all loads of a pixel are independent.
+#pragma unroll
+      for (int q = 0; q < C2 / 4; ++q) {
+        const float4 v4 = src[q];
+        const float zv[4] = {v4.x, v4.y, v4.z, v4.w};
+        const int f0 = ch * 196 + (h >> 1) * 14 + (w >> 1);
+        const unsigned short sl2 = *reinterpret_cast<const unsigned short *>(pix + f0);
+        const int win_slot[2] = {sl2 & 0xff, sl2 >> 8};
+        const float2 df2 = *reinterpret_cast<const float2 *>(sdf + f0);
+        const float df[2] = {df2.x, df2.y};
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int c = 4 * q + e;
+          const float xh = (zv[e] - st[c]) * st[C2 + c];
+          const float y = xh * g[c] + b[c];
+          const int slot = (h & 1) * 2 + (e & 1);
+          const float d = (y > 0.f && win_slot[e >> 1] == slot) ? df[e >> 1] : 0.f;
+          o[e] = d;
+          s[c] += d;
+          s[C2 + c] += d * xh;
+        }
+        dst[q] = make_float4(o[0], o[1], o[2], o[3]);
+        w += 4;
+        if (w == W) {
+          w = 0;
+          if (++h == H) {
+            h = 0;
+            ++ch;
+          }
+        }
+      }
+      continue;
+    }
+#pragma unroll
+    for (int q = 0; q < C2 / 4; ++q) {
+      const float4 v4 = src[q];
+      const float zv[4] = {v4.x, v4.y, v4.z, v4.w};
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = 4 * q + e;
+        const float xh = (zv[e] - st[c]) * st[C2 + c];
+        const float y = xh * g[c] + b[c];
+        const int f = ch * 196 + (h / pk) * 14 + (w / pk);
+        const int slot = (h % pk) * pk + (w % pk);
+        const float d = (y > 0.f && pix[f] == slot) ? sdf[f] : 0.f;
+        o[e] = d;
+        s[c] += d;
+        s[C2 + c] += d * xh;
+        if (++w == W) {
+          w = 0;
+          if (++h == H) {
+            h = 0;
+            ++ch;
+          }
+        }
+      }
+      dst[q] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+  }
+  block_sum<2 * C2>(s, red);
+  if (tid < 2 * C2) part[(size_t)n * 2 * C2 + tid] = s[tid];
+}
+
+}  // namespace vt
+
+using namespace vt;
+
+extern "C" int vt_head_fwd(const float *z, const float *pn_stat, const float *pn_gamma, const float *pn_beta,
+                           const float *wfc, const float *bfc, float *pooled, unsigned char *pool_idx, float *logits,
+                           float *probs, int N, int H, int K, vt_stream s) {
+  if (N < 1 || H < 14 || H % 14 != 0 || K < 1 || K > KMAX) return VT_EUNSUPPORTED;
+  hipLaunchKernelGGL(k_head_fwd, dim3(N), dim3(TPB), 0, (hipStream_t)s, z, pn_stat, pn_gamma, pn_beta, wfc, bfc, pooled,
+                     pool_idx, logits, probs, H, K);
+  VT_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int vt_head_bwd(const float *probs, const int *labels, const float *wfc, const unsigned char *pool_idx,
+                           const float *z, const float *pn_stat, const float *pn_gamma, const float *pn_beta,
+                           float *d_logits, float *du, float *part, int N, int H, int K, vt_stream s) {
+  if (N < 1 || H < 14 || H % 14 != 0 || K < 1 || K > KMAX) return VT_EUNSUPPORTED;
+  const size_t lds = (size_t)C2 * 196 * sizeof(float);
+  if (H == 28)
+    hipLaunchKernelGGL(k_head_bwd<2>, dim3(N), dim3(TPB), lds, (hipStream_t)s, probs, labels, wfc, pool_idx, z, pn_stat,
+                       pn_gamma, pn_beta, d_logits, du, part, H, K);
+  else
+    hipLaunchKernelGGL(k_head_bwd<0>, dim3(N), dim3(TPB), lds, (hipStream_t)s, probs, labels, wfc, pool_idx, z, pn_stat,
+                       pn_gamma, pn_beta, d_logits, du, part, H, K);
+  VT_CHECK_LAUNCH();
+  return 0;
+}

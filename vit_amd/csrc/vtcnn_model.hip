@@ -551,7 +551,7 @@ extern "C" int vt_model_forward(vt_model *m, const float *d_images, int n, float
   STEP("projector_tokens_fwd", vt_projector_tokens_fwd(m->s2, m->stat_n2, m->P_("norm2.gamma"), m->P_("norm2.beta"), m->P_("proj.linear1.W"),
                                 m->P_("proj.linear2.W"), m->P_("proj.linear3.W"), m->P_("proj.linear3.b"), m->o, m->pk, n, s));
   STEP("projector_fwd", vt_projector_fwd(m->conv, m->stat_bn, m->P_("bn.gamma"), m->P_("bn.beta"), m->pk, m->P_("proj.downsample.W"),
-                         m->P_("proj.downsample.b"), m->projA, m->z, m->part, n, P, s));
+                         m->P_("proj.downsample.b"), m->P_("proj.norm.running_mean"), m->projA, m->z, m->part, n, P, s));
   STEP("bn_stats_finalize", vt_bn_stats_finalize(m->part, n, C2, P, (long)n * P, m->P_("proj.norm.running_mean"), m->P_("proj.norm.running_var"),
                              m->stat_pn, s));
   STEP("head_fwd", vt_head_fwd(m->z, m->stat_pn, m->P_("proj.norm.gamma"), m->P_("proj.norm.beta"), m->P_("fc.W"), m->P_("fc.b"),
