@@ -118,14 +118,11 @@ def main():
     rng = np.random.default_rng(123 + rank)
     xs = torch.from_numpy(rng.integers(0, 256, size=(nb, B, 1, 28, 28)).astype(np.float32) / np.float32(255.0)).cuda()
     ys = torch.from_numpy(rng.integers(0, a.classes, size=(nb, B)).astype(np.int32)).cuda()
-    divisor = float(B * world)
+    from vit_amd.parallel import DataParallel
+    dp = DataParallel(m, world=world, rank=rank)  # world 1: plain forward / backward / SGD
 
     def step(i):
-        m.forward(xs[i % nb])
-        m.backward(ys[i % nb])
-        if dist is not None:
-            dist.all_reduce(m.grads)
-        m.update_weights(divisor)
+        dp.train_step(xs[i % nb], ys[i % nb], B)
 
     def sync():
         torch.cuda.synchronize()
