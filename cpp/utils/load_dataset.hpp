@@ -1,0 +1,121 @@
+// Dataset loading and batching with the reference's semantics (utils/load_dataset.hpp:12-165):
+// IDX files (big-endian headers, pixel u8/255.0f), DataLoader that shuffles its index vector in
+// the constructor and again at every reset() from one mt19937(seed), short last batch.
+// The bit-exact pieces (IDX decode, shuffle) are the C ABI's host entry points.
+#pragma once
+#include <filesystem>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/vtcnn_hip.h"
+#include "tensor.hpp"
+
+struct Dataset {
+  std::vector<std::vector<float>> images;
+  std::vector<int> labels;
+};
+
+inline std::vector<std::vector<float>> loadImages2D(const std::string &filename, int max_images = 9999999) {
+  int n = 0, r = 0, c = 0;
+  if (vt_idx_read_images(filename.c_str(), max_images, nullptr, &n, &r, &c) != 0)
+    throw std::runtime_error("No se pudo abrir el archivo de imágenes");
+  std::vector<float> flat((size_t)n * r * c);
+  vt_idx_read_images(filename.c_str(), max_images, flat.data(), &n, &r, &c);
+  std::vector<std::vector<float>> out(n);
+  for (int i = 0; i < n; ++i) out[i].assign(flat.begin() + (size_t)i * r * c, flat.begin() + (size_t)(i + 1) * r * c);
+  return out;
+}
+
+inline std::vector<int> loadLabels(const std::string &filename, int max_labels = 9999999) {
+  int n = 0;
+  if (vt_idx_read_labels(filename.c_str(), max_labels, nullptr, &n) != 0)
+    throw std::runtime_error("No se pudo abrir el archivo de etiquetas");
+  std::vector<int> out(n);
+  vt_idx_read_labels(filename.c_str(), max_labels, out.data(), &n);
+  return out;
+}
+
+inline Dataset load_dataset(const std::string &image_path, const std::string &label_path, int max_samples = 9999999) {
+  Dataset d{loadImages2D(image_path, max_samples), loadLabels(label_path, max_samples)};
+  if (d.images.size() != d.labels.size()) throw std::runtime_error("El número de imágenes y etiquetas no coincide");
+  return d;
+}
+
+class DataLoader {
+  const std::vector<std::vector<float>> &images;
+  const std::vector<int> &labels;
+  size_t batch_size, index = 0;
+  std::vector<int> indices;
+  unsigned seed;
+  int resets = 0;
+  int C, H, W;
+
+  void reshuffle() {
+    indices.resize(images.size());
+    if (vt_loader_indices((int)images.size(), seed, resets, indices.data()) != 0)
+      throw std::runtime_error("DataLoader: vt_loader_indices failed");
+  }
+
+ public:
+  DataLoader(const std::vector<std::vector<float>> &imgs, const std::vector<int> &lbls, size_t b_size, int channels = 1,
+             int height = 28, int width = 28, int /*num_cls*/ = 10, unsigned int seed_ = 42)
+      : images(imgs), labels(lbls), batch_size(b_size), seed(seed_), C(channels), H(height), W(width) {
+    if (images.size() != labels.size()) throw std::runtime_error("Mismatch entre imágenes y etiquetas");
+    reshuffle();
+  }
+  std::pair<Tensor, Tensor> next_batch() {
+    const size_t end = std::min(index + batch_size, images.size()), n = end - index, per = (size_t)C * H * W;
+    std::vector<float> x(n * per), y(n);
+    for (size_t i = 0; i < n; ++i) {
+      const size_t src = (size_t)indices[index + i];
+      std::copy(images[src].begin(), images[src].end(), x.begin() + i * per);
+      y[i] = static_cast<float>(labels[src]);
+    }
+    index = end;
+    return {Tensor({(int)n, C, H, W}, std::move(x)), Tensor({(int)n, 1}, std::move(y))};
+  }
+  bool has_next() const { return index < images.size(); }
+  void reset() {
+    index = 0;
+    ++resets;
+    reshuffle();
+  }
+  size_t total_batches() const { return (images.size() + batch_size - 1) / batch_size; }
+  const std::vector<int> &order() const { return indices; }
+};
+
+// Custom images for `predict`: binary PGM (P5, 28x28, maxval 255) files in alphabetical order,
+// pixel/255.0f.  (The reference decodes PNG/JPG through a vendored third-party header,
+// utils/load_image_stb.hpp; that decoder is outside this engine.)
+inline Dataset load_custom_images_from_folder(const std::string &folder_path) {
+  namespace fs = std::filesystem;
+  Dataset ds;
+  std::vector<fs::path> files;
+  for (const auto &e : fs::directory_iterator(folder_path))  // throws if the folder is missing, like the reference
+    if (e.is_regular_file() && e.path().extension() == ".pgm") files.push_back(e.path());
+  std::sort(files.begin(), files.end(), [](const fs::path &a, const fs::path &b) { return a.filename() < b.filename(); });
+  for (const fs::path &p : files) {
+    FILE *f = std::fopen(p.c_str(), "rb");
+    if (!f) continue;
+    int w = 0, h = 0, mx = 0;
+    std::vector<float> img;
+    if (std::fscanf(f, "P5 %d %d %d", &w, &h, &mx) == 3 && w == 28 && h == 28 && mx == 255) {
+      std::fgetc(f);
+      std::vector<unsigned char> raw(784);
+      if (std::fread(raw.data(), 1, 784, f) == 784) {
+        img.resize(784);
+        for (int i = 0; i < 784; ++i) img[i] = static_cast<float>(raw[i]) / 255.0f;
+      }
+    }
+    std::fclose(f);
+    if (!img.empty()) {
+      ds.images.push_back(std::move(img));
+      ds.labels.push_back(0);
+    } else {
+      std::fprintf(stderr, "Error al cargar %s\n", p.c_str());
+    }
+  }
+  return ds;
+}

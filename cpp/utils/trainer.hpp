@@ -1,0 +1,139 @@
+// Training / evaluation loop with the reference's semantics and console output
+// (utils/trainer.hpp:9-243): per batch forward, backward, update_weights(batch_size), zero_grad;
+// evaluation toggles set_training(false/true); evaluate_test prints macro/weighted F1, per-class
+// precision/recall/F1 and the confusion matrix.
+#pragma once
+#include <chrono>
+#include <iomanip>
+#include <iostream>
+
+#include "../model/model.hpp"
+#include "load_dataset.hpp"
+#include "tensor.hpp"
+
+class Trainer {
+  Model &model;
+  DataLoader &train_loader;
+  DataLoader &val_loader;
+  DataLoader *test_loader;
+  int num_classes;
+  int batch_size;
+
+  struct Pass {
+    float loss = 0.f, acc = 0.f;
+    int batches = 0;
+    std::vector<int> truth, pred;
+  };
+  // forward-only sweep over a loader in eval mode
+  Pass sweep(DataLoader &loader, bool keep_labels) {
+    Pass p;
+    model.set_training(false);
+    while (loader.has_next()) {
+      auto batch = loader.next_batch();
+      const Tensor &X = batch.first, &y = batch.second;
+      const Tensor onehot = Tensor::one_hot(y, num_classes);
+      const Tensor preds = model.forward(X);
+      p.loss += Tensor::compute_loss(preds, onehot);
+      p.acc += Tensor::compute_accuracy(preds, y, num_classes);
+      ++p.batches;
+      if (keep_labels) {
+        const std::vector<int> yp = Tensor::argmax_batch(preds), yt = y.to_vector();
+        p.pred.insert(p.pred.end(), yp.begin(), yp.end());
+        p.truth.insert(p.truth.end(), yt.begin(), yt.end());
+      }
+    }
+    model.set_training(true);
+    return p;
+  }
+
+ public:
+  Trainer(Model &model_, DataLoader &train_loader_, DataLoader &val_loader_, int num_classes_, int batch_size_,
+          DataLoader *test_loader_ = nullptr)
+      : model(model_), train_loader(train_loader_), val_loader(val_loader_), test_loader(test_loader_),
+        num_classes(num_classes_), batch_size(batch_size_) {}
+
+  void train(int epochs, int /*log_every*/, std::string /*device*/) {
+    for (int epoch = 0; epoch < epochs; ++epoch) {
+      const auto t0 = std::chrono::high_resolution_clock::now();
+      std::cout << "Epoch " << (epoch + 1) << "/" << epochs << "\n";
+      train_loader.reset();
+      float epoch_loss = 0.0f, epoch_acc = 0.0f;
+      int batches = 0;
+      long images = 0;
+      while (train_loader.has_next()) {
+        auto batch = train_loader.next_batch();
+        const Tensor &X = batch.first, &y = batch.second;
+        const Tensor onehot = Tensor::one_hot(y, num_classes);
+        const Tensor preds = model.forward(X);
+        model.backward(onehot);
+        model.update_weights(batch_size);  // the constant loader batch size, even on a short last batch
+        model.zero_grad();
+        epoch_loss += Tensor::compute_loss(preds, onehot);
+        epoch_acc += Tensor::compute_accuracy(preds, y, num_classes);
+        ++batches;
+        images += X.shape[0];
+      }
+      const std::chrono::duration<double> dt = std::chrono::high_resolution_clock::now() - t0;
+      std::cout << std::fixed << std::setprecision(4);
+      std::cout << "Train Loss: " << (epoch_loss / batches) << " | Accuracy: " << (epoch_acc / batches) * 100.0f << "%"
+                << " | Time: " << dt.count() << " s | " << (double)images / dt.count() << " images/sec\n";
+      evaluate();
+    }
+    if (test_loader) {
+      std::cout << "\n=== Evaluación final sobre conjunto de test ===\n";
+      evaluate_test();
+    }
+  }
+
+  void evaluate() {
+    val_loader.reset();
+    const Pass p = sweep(val_loader, false);
+    std::cout << "Val Loss: " << (p.loss / p.batches) << " | Accuracy: " << (p.acc / p.batches) * 100.0f << "%\n";
+  }
+
+  // returns the predicted labels in loader order (the reference returns nothing; the printout is the same)
+  std::vector<int> evaluate_test() {
+    if (!test_loader) {
+      std::cout << "[WARN] No se proporcionó test_loader\n";
+      return {};
+    }
+    test_loader->reset();
+    const Pass p = sweep(*test_loader, true);
+    std::cout << "[TEST] Final Evaluation — Loss: " << (p.loss / p.batches) << " | Accuracy: " << (p.acc / p.batches) * 100.0f
+              << "%\n";
+    const Tensor::ClassStats s = Tensor::class_stats(p.truth, p.pred, num_classes);
+    const auto cm = Tensor::confusion_matrix(p.truth, p.pred, num_classes);
+    std::cout << " - F1 Score (macro):    " << s.macro_f1 << "\n";
+    std::cout << " - F1 Score (weighted): " << s.weighted_f1 << "\n";
+    std::cout << " - Precision (macro):   " << s.macro_precision << "\n";
+    std::cout << " - Recall (macro):      " << s.macro_recall << "\n";
+    std::cout << "\n📊 Per-Class Metrics:\n";
+    std::cout << std::setw(8) << "Class" << std::setw(12) << "Precision" << std::setw(12) << "Recall" << std::setw(12)
+              << "F1 Score" << "\n"
+              << std::string(44, '-') << "\n";
+    for (int k = 0; k < num_classes; ++k)
+      std::cout << std::setw(8) << k << std::fixed << std::setprecision(4) << std::setw(12) << s.precision[k] << std::setw(12)
+                << s.recall[k] << std::setw(12) << s.f1[k] << "\n";
+    std::cout << "\n🧩 Matriz de Confusión:\n    ";
+    for (int j = 0; j < num_classes; ++j) std::cout << std::setw(4) << j;
+    std::cout << "\n";
+    for (int i = 0; i < num_classes; ++i) {
+      std::cout << std::setw(2) << i << ": ";
+      for (int j = 0; j < num_classes; ++j) std::cout << std::setw(4) << cm[i][j];
+      std::cout << "\n";
+    }
+    return p.pred;
+  }
+
+  // single 28x28 image, eval mode, first maximum wins
+  int predict(const std::vector<float> &image_data) {
+    if (image_data.size() != 28 * 28) throw std::runtime_error("La imagen debe ser de tamaño 28x28");
+    const Tensor input({1, 1, 28, 28}, image_data);
+    model.set_training(false);
+    const Tensor out = model.forward(input);
+    int best = 0;
+    for (size_t i = 1; i < out.data.size(); ++i)
+      if (out.data[i] > out.data[best]) best = (int)i;
+    return best;
+  }
+};

@@ -223,6 +223,11 @@ int vt_transformer_bwd_c(const float *da, const float *n1_coef, const float *wo,
  * scratch >= groups * heads * ceil(N/64) * 1536 floats. */
 int vt_mha_bwd(const float *qkv, const float *dc, const float *tok, const float *wqkv, float *g_qkv, float *scratch,
                int N, int groups, vt_stream s);
+/* The two halves of vt_mha_bwd, separately launchable (and separately timed): the per-row
+ * attention sums on the matrix cores, then the merge into the six gradient tensors. */
+int vt_mha_bwd_rows(const float *qkv, const float *dc, const float *tok, float *scratch, int N, int groups, vt_stream s);
+int vt_mha_bwd_wgrad(const float *qkv, const float *dc, const float *tok, const float *wqkv, float *g_qkv,
+                     float *scratch, int N, int groups, vt_stream s);
 /* DenseLayer::backward over a row matrix (dense_layer.hpp:79-100): gW = X^T dY, gb = sum dY,
  * dX = dY W^T (optionally accumulated into dX).  in,out <= 32. */
 int vt_dense_bwd_rows(const float *X, const float *W, const float *dY, float *gW, float *gb, float *dX,

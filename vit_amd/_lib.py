@@ -83,6 +83,8 @@ SIGNATURES = {
     "vt_transformer_bwd_b": (i, [p] * 14 + [l, p]),
     "vt_transformer_bwd_c": (i, [p] * 8 + [l, p]),
     "vt_mha_bwd": (i, [p] * 6 + [i, i, p]),
+    "vt_mha_bwd_rows": (i, [p] * 4 + [i, i, p]),
+    "vt_mha_bwd_wgrad": (i, [p] * 6 + [i, i, p]),
 }
 del p, i, l, f, u
 

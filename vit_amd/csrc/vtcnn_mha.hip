@@ -253,20 +253,30 @@ static int mha_splits(int N, int groups) {
   return ns < 1 ? 1 : ns;
 }
 
-// g_qkv: [q0 | k0 | v0 | q1 | k1 | v1] gradients (arena order);
-// scratch >= heads*4*(2*D + 2)*rows + heads*ceil(rows/64)*1536 floats with rows = N*groups.
-extern "C" int vt_mha_bwd(const float *qkv, const float *dc, const float *tok, const float *wqkv, float *g_qkv,
-                          float *scratch, int N, int groups, vt_stream s) {
+// Step 1: per-row attention sums (k_mha_rows).  scratch as for vt_mha_bwd.
+extern "C" int vt_mha_bwd_rows(const float *qkv, const float *dc, const float *tok, float *scratch, int N, int groups,
+                               vt_stream s) {
   if (N < 1 || groups < 1) return VT_EINVAL;
   const int itiles = (N + 31) / 32, ns = mha_splits(N, groups);
+  const long rows = (long)N * groups;
+  float *yz = scratch;
+  float *st = yz + (size_t)HEADS * ns * 2 * D * rows;
+  hipLaunchKernelGGL(k_mha_rows, dim3(HEADS * groups * itiles * ns), dim3(64), 0, (hipStream_t)s, qkv, dc, tok, yz, st,
+                     N, rows, groups, ns);
+  VT_CHECK_LAUNCH();
+  return 0;
+}
+
+// Step 2: merge the j splits and form the six gradient tensors from the row sums of step 1.
+extern "C" int vt_mha_bwd_wgrad(const float *qkv, const float *dc, const float *tok, const float *wqkv, float *g_qkv,
+                                float *scratch, int N, int groups, vt_stream s) {
+  if (N < 1 || groups < 1) return VT_EINVAL;
+  const int ns = mha_splits(N, groups);
   const long rows = (long)N * groups;
   const int nrb = (int)((rows + RB - 1) / RB);
   float *yz = scratch;
   float *st = yz + (size_t)HEADS * ns * 2 * D * rows;
   float *slab = st + (size_t)HEADS * ns * 2 * rows;
-  hipLaunchKernelGGL(k_mha_rows, dim3(HEADS * groups * itiles * ns), dim3(64), 0, (hipStream_t)s, qkv, dc, tok, yz, st,
-                     N, rows, groups, ns);
-  VT_CHECK_LAUNCH();
   hipLaunchKernelGGL(k_mha_wgrad, dim3(nrb, HEADS), dim3(TPB), 0, (hipStream_t)s, yz, st, qkv, dc, tok, wqkv, slab, rows,
                      ns);
   VT_CHECK_LAUNCH();
@@ -276,4 +286,13 @@ extern "C" int vt_mha_bwd(const float *qkv, const float *dc, const float *tok, c
     if (rc) return rc;
   }
   return 0;
+}
+
+// g_qkv: [q0 | k0 | v0 | q1 | k1 | v1] gradients (arena order);
+// scratch >= heads*4*(2*D + 2)*rows + heads*ceil(rows/64)*1536 floats with rows = N*groups.
+extern "C" int vt_mha_bwd(const float *qkv, const float *dc, const float *tok, const float *wqkv, float *g_qkv,
+                          float *scratch, int N, int groups, vt_stream s) {
+  const int rc = vt_mha_bwd_rows(qkv, dc, tok, scratch, N, groups, s);
+  if (rc) return rc;
+  return vt_mha_bwd_wgrad(qkv, dc, tok, wqkv, g_qkv, scratch, N, groups, s);
 }

@@ -592,7 +592,8 @@ extern "C" int vt_model_backward(vt_model *m, const int *d_labels, vt_stream s) 
   STEP("bn_bwd_finalize", vt_bn_bwd_finalize(m->part, nrb, D, NL, m->P_("norm1.gamma"), m->stat_n1, m->tok, m->G_("norm1.gamma"),
                            m->G_("norm1.beta"), m->coef_n1, s));
   STEP("transformer_bwd_c", vt_transformer_bwd_c(m->da, m->coef_n1, m->P_("mha.o.W"), m->tok, m->P_("mha.q0.W"), m->dr, m->dc, m->qkv, NL, s));
-  STEP("mha_bwd", vt_mha_bwd(m->qkv, m->dc, m->tok, m->P_("mha.q0.W"), m->G_("mha.q0.W"), m->rowscratch, n, L, s));
+  STEP("mha_bwd_rows", vt_mha_bwd_rows(m->qkv, m->dc, m->tok, m->rowscratch, n, L, s));
+  STEP("mha_bwd_wgrad", vt_mha_bwd_wgrad(m->qkv, m->dc, m->tok, m->P_("mha.q0.W"), m->G_("mha.q0.W"), m->rowscratch, n, L, s));
   // the output projection's cached input is the zero concat: its gradient is exactly zero
   HIPCHK(hipMemsetAsync(m->G_("mha.o.W"), 0, sizeof(float) * D * D, hs));
   // tokenizer.backward2(projector token delta, projector input delta) + BatchNorm2D + conv
