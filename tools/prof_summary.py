@@ -1,12 +1,47 @@
-"""Summarises a rocprofv3 --kernel-trace --stats csv directory: per-kernel calls / average / share."""
-import csv, glob, sys
-d = sys.argv[1]
-steps = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-f = sorted(glob.glob(d + "/**/*kernel_stats.csv", recursive=True))[0]
-rows = list(csv.DictReader(open(f)))
-tot = sum(float(r["TotalDurationNs"]) for r in rows)
-print("%-30s %6s %11s %7s" % ("kernel", "calls", "avg_us", "share"))
-for r in rows:
-    name = r["Name"].split("(")[0].replace("vt::", "")
-    print("%-30s %6s %11.2f %6.1f%%" % (name[:30], r["Calls"], float(r["AverageNs"]) / 1e3, 100 * float(r["TotalDurationNs"]) / tot))
-print("sum of kernel time per step: %.1f us (%d steps)" % (tot / steps / 1e3, steps))
+"""Summarises a rocprofv3 --kernel-trace --stats output directory (csv or rocpd .db): per-kernel
+calls / average duration / share, plus launch geometry and register use when the .db holds them.
+
+    python tools/prof_summary.py <dir> [steps]
+"""
+import csv
+import glob
+import sqlite3
+import sys
+
+
+def short(name):
+    return name.split("(")[0].replace("vt::", "")[:34]
+
+
+def from_csv(path):
+    rows = list(csv.DictReader(open(path)))
+    return [(r["Name"], int(r["Calls"]), float(r["TotalDurationNs"]) / 1e3, float(r["AverageNs"]) / 1e3, "") for r in rows]
+
+
+def from_db(path):
+    c = sqlite3.connect(path)
+    q = ("select name, count(*), sum(duration)/1e3, avg(duration)/1e3, min(grid_x), max(grid_x), max(workgroup_x), "
+         "max(vgpr_count), max(accum_vgpr_count), max(sgpr_count), max(lds_size), max(scratch_size) "
+         "from kernels group by name order by sum(duration) desc")
+    out = []
+    for n, calls, tot, avg, g0, g1, wg, vg, ag, sg, lds, scr in c.execute(q):
+        geo = "grid %s wg %s vgpr %s+%s sgpr %s lds %s scratch %s" % (g1 if g0 == g1 else "%s..%s" % (g0, g1), wg, vg, ag, sg, lds, scr)
+        out.append((n, calls, tot, avg, geo))
+    return out
+
+
+def main():
+    d = sys.argv[1]
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    dbs = sorted(glob.glob(d + "/**/*.db", recursive=True))
+    csvs = sorted(glob.glob(d + "/**/*kernel_stats.csv", recursive=True))
+    rows = from_db(dbs[0]) if dbs else from_csv(csvs[0])
+    tot = sum(r[2] for r in rows)
+    print("%-34s %6s %10s %7s  %s" % ("kernel", "calls", "avg_us", "share", "launch"))
+    for n, calls, t, avg, geo in rows:
+        print("%-34s %6d %10.2f %6.1f%%  %s" % (short(n), calls, avg, 100 * t / tot, geo))
+    print("sum of kernel time per step: %.1f us (%d steps)" % (tot / steps, steps))
+
+
+if __name__ == "__main__":
+    main()

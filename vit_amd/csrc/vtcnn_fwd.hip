@@ -403,90 +403,6 @@ __global__ __launch_bounds__(TPB) void k_proj_tokens_fwd(const float *__restrict
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Pixel side of ProjectorLayer::forward (reference layers/projector_layer.hpp:65-104).
-//   a = softmax_L(x.Mq);  z = (x.Wd + bd) + a.v    (+ per-sample partial stats of z)
-// One workgroup per image, one pixel per loop trip.  Mq, v, Wd, bd are wave-uniform operands read
-// through the scalar cache (the loop is deliberately not unrolled: with four pixels in flight the
-// compiler keeps every operand live at once and spills hundreds of SGPRs).
-// The partial statistics are accumulated around a pivot (the layer's running mean: any value
-// near the batch mean works) so no per-pixel value has to stay live after its trip:
-//   M2 = sum (z-piv)^2 - (sum (z-piv))^2 / P.
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(TPB) void k_proj_fwd(const float *__restrict__ conv, const float *__restrict__ st,
-                                                  const float *__restrict__ g, const float *__restrict__ b,
-                                                  const float *__restrict__ pk, const float *__restrict__ Wd,
-                                                  const float *__restrict__ bd, const float *__restrict__ piv,
-                                                  float *__restrict__ projA, float *__restrict__ z,
-                                                  float *__restrict__ part_pn, int P) {
-  __shared__ float red[NW * 2 * C2];
-  const int n = blockIdx.x, tid = threadIdx.x;
-  const float *__restrict__ mq = pk + (size_t)n * PK_STRIDE;
-  const float *__restrict__ vv = mq + C1 * L;
-  float s[2 * C2];
-#pragma unroll
-  for (int c = 0; c < 2 * C2; ++c) s[c] = 0.f;
-#pragma unroll 1
-  for (int p = tid; p < P; p += TPB) {
-    float x[C1];
-    load_x(conv, (size_t)n * P + p, st, g, b, x);
-    float a[L];
-#pragma unroll
-    for (int l = 0; l < L; ++l) a[l] = 0.f;
-#pragma unroll
-    for (int ch = 0; ch < C1; ++ch) {
-#pragma unroll
-      for (int l = 0; l < L; ++l) a[l] += x[ch] * mq[ch * L + l];
-    }
-    float mx = a[0];
-#pragma unroll
-    for (int l = 1; l < L; ++l) mx = fmaxf(mx, a[l]);
-    float sum = 0.f;
-#pragma unroll
-    for (int l = 0; l < L; ++l) {
-      a[l] = expf(a[l] - mx);
-      sum += a[l];
-    }
-#pragma unroll
-    for (int l = 0; l < L; ++l) a[l] = a[l] / sum;
-    float ds[C2], av[C2];
-#pragma unroll
-    for (int c = 0; c < C2; ++c) { ds[c] = 0.f; av[c] = 0.f; }
-#pragma unroll
-    for (int ch = 0; ch < C1; ++ch) {
-#pragma unroll
-      for (int c = 0; c < C2; ++c) ds[c] += x[ch] * Wd[ch * C2 + c];
-    }
-#pragma unroll
-    for (int l = 0; l < L; ++l) {
-#pragma unroll
-      for (int c = 0; c < C2; ++c) av[c] += a[l] * vv[l * C2 + c];
-    }
-    float zv[C2];
-#pragma unroll
-    for (int c = 0; c < C2; ++c) {
-      zv[c] = (ds[c] + bd[c]) + av[c];
-      const float dlt = zv[c] - piv[c];
-      s[c] += dlt;
-      s[C2 + c] += dlt * dlt;
-    }
-    float4 *da = reinterpret_cast<float4 *>(projA + ((size_t)n * P + p) * L);
-    float4 *dz = reinterpret_cast<float4 *>(z + ((size_t)n * P + p) * C2);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      da[q] = make_float4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
-      dz[q] = make_float4(zv[4 * q], zv[4 * q + 1], zv[4 * q + 2], zv[4 * q + 3]);
-    }
-  }
-  if (part_pn == nullptr) return;
-  block_sum<2 * C2>(s, red);
-  if (tid < C2) {
-    const float d1 = s[tid], d2 = s[C2 + tid];
-    part_pn[(size_t)n * 2 * C2 + tid] = d1 + (float)P * piv[tid];
-    part_pn[(size_t)n * 2 * C2 + C2 + tid] = fmaxf(d2 - d1 * d1 / (float)P, 0.f);
-  }
-}
-
 // Tensor::argmax_batch (first maximum, tensor_cpu.hpp:1294-1307) and the cross-entropy terms of
 // Tensor::compute_loss (tensor_cpu.hpp:1155-1173).  One workgroup; fixed order => reproducible.
 __global__ __launch_bounds__(TPB) void k_metrics(const float *__restrict__ probs, const int *__restrict__ labels, int N,
@@ -572,16 +488,6 @@ extern "C" int vt_projector_tokens_fwd(const float *s2, const float *n2_stat, co
   if (N < 1) return VT_EINVAL;
   hipLaunchKernelGGL(k_proj_tokens_fwd, dim3(N), dim3(TPB), 0, (hipStream_t)s, s2, n2_stat, n2_gamma, n2_beta, wq, wk,
                      wv, bv, o, pk);
-  VT_CHECK_LAUNCH();
-  return 0;
-}
-
-extern "C" int vt_projector_fwd(const float *conv_out, const float *bn_stat, const float *bn_gamma, const float *bn_beta,
-                                const float *pk, const float *wd, const float *bd, const float *pivot, float *proj_a,
-                                float *z, float *part_pn, int N, int P, vt_stream s) {
-  if (N < 1 || P < 1 || !pivot) return VT_EUNSUPPORTED;
-  hipLaunchKernelGGL(k_proj_fwd, dim3(N), dim3(TPB), 0, (hipStream_t)s, conv_out, bn_stat, bn_gamma, bn_beta, pk, wd,
-                     bd, pivot, proj_a, z, part_pn, P);
   VT_CHECK_LAUNCH();
   return 0;
 }

@@ -1,0 +1,177 @@
+// Per-pixel kernels of the VTCNN hot path on the gfx950 matrix cores.
+//
+// The per-pixel contractions of the tokenizer and the projector are 8-, 16- and 32-wide: too narrow
+// to be GEMMs worth a library call, but on the vector ALUs every multiply needs a wave-uniform
+// weight operand (scalar registers or LDS broadcasts), and delivering those operands, not the
+// arithmetic or the HBM traffic, bounds the kernels.  v_mfma_f32_16x16x4_f32 removes the problem:
+// the weights sit distributed over the lanes of a few vector registers, a tile of 16 pixels is the
+// other operand, accumulation is exact fp32, and the matrix pipe runs beside the vector pipe that
+// does the softmax.
+//
+// Register layouts of v_mfma_f32_16x16x4_f32 (lane = 16*g + j, g = 0..3, j = 0..15):
+//   A[i][k]: lane holds i = j, k = g            B[k][j']: lane holds j' = j, k = g
+//   D[i][j']: register v of the lane holds i = 4*g + v, j' = j
+// Two facts are used throughout:
+//   * a contraction may visit its terms in any order, so a D tile ("row 4g+v in register v") is
+//     directly the B (or A) operand of the NEXT product if step v of that product is defined to
+//     contract over the rows {4g+v : g = 0..3} and the other operand is permuted to match;
+//   * the same register is an A operand (pixel = output row) or a B operand (pixel = output column).
+// "T layout" below: lane = pixel j, registers = features 4g+v.  "N layout": lane = feature j,
+// registers = pixels 4g+v (what a contraction over pixels needs).
+#include "vtcnn_common.h"
+
+namespace vt {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f4 mfma16(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+// sum / max over the four lane groups g (lanes j, j+16, j+32, j+48)
+__device__ __forceinline__ float gsum(float x) {
+  x += __shfl_xor(x, 16);
+  x += __shfl_xor(x, 32);
+  return x;
+}
+__device__ __forceinline__ float gmax(float x) {
+  x = fmaxf(x, __shfl_xor(x, 16));
+  x = fmaxf(x, __shfl_xor(x, 32));
+  return x;
+}
+// sum over the 16 lanes j of one lane group
+__device__ __forceinline__ float jsum(float x) {
+  x += __shfl_xor(x, 1);
+  x += __shfl_xor(x, 2);
+  x += __shfl_xor(x, 4);
+  x += __shfl_xor(x, 8);
+  return x;
+}
+
+// BatchNorm2D apply for the two channels 2g, 2g+1 of pixel j (x_norm * gamma + beta,
+// batch_normalization_layer.hpp:279,296); same operation order as load_x.
+struct BnPair {
+  float mean[2], inv[2], gam[2], bet[2];
+  __device__ __forceinline__ void init(const float *st, const float *g, const float *b, int gq) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int ch = 2 * gq + s;
+      mean[s] = st[ch];
+      inv[s] = st[C1 + ch];
+      gam[s] = g[ch];
+      bet[s] = b[ch];
+    }
+  }
+  __device__ __forceinline__ float apply(float raw, int s) const { return ((raw - mean[s]) * inv[s]) * gam[s] + bet[s]; }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Pixel side of ProjectorLayer::forward (reference layers/projector_layer.hpp:65-104).
+//   a = softmax_L(x.Mq);  z = (x.Wd + bd) + a.v    (+ per-sample partial statistics of z)
+// One workgroup per image, one wave per 16-pixel tile.  Per tile: 2 MFMAs for the scores (T
+// layout, so the softmax over the 16 tokens is 4 registers x 4 lane groups), 2 for the downsample
+// and 4 for a.v, the softmax output feeding the last product straight from its registers.
+// The partial statistics are accumulated around a pivot (the layer's running mean: any value near
+// the batch mean works):  M2 = sum (z-piv)^2 - (sum (z-piv))^2 / P.
+// projA (the attention map) is written only when the pointer is non-null (debug / tests); the
+// backward pass recomputes it.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void k_proj_fwd(const float *__restrict__ conv, const float *__restrict__ st,
+                                                  const float *__restrict__ g, const float *__restrict__ b,
+                                                  const float *__restrict__ pk, const float *__restrict__ Wd,
+                                                  const float *__restrict__ bd, const float *__restrict__ piv,
+                                                  float *__restrict__ projA, float *__restrict__ z,
+                                                  float *__restrict__ part_pn, int P) {
+  __shared__ float red[NW][2 * C2];
+  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, gq = lane >> 4;
+  const float *__restrict__ mq = pk + (size_t)n * PK_STRIDE;
+  const float *__restrict__ vv = mq + C1 * L;
+  float amq[2], awd[2], av[4], pv[4];
+  f4 cinit;
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    amq[s] = mq[(2 * gq + s) * L + j];   // A[token j][channel 2g+s]
+    awd[s] = Wd[(2 * gq + s) * C2 + j];  // A[c2 j][channel 2g+s]
+  }
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    av[v] = vv[(4 * gq + v) * C2 + j];  // A[c2 j][token 4g+v]
+    pv[v] = piv[4 * gq + v];
+    cinit[v] = bd[4 * gq + v];
+  }
+  BnPair bn;
+  bn.init(st, g, b, gq);
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  const int ntiles = (P + 15) >> 4;
+  for (int t = wave; t < ntiles; t += NW) {
+    const int p = t * 16 + j;
+    const bool ok = p < P;
+    float x0 = 0.f, x1 = 0.f;
+    if (ok) {
+      const float2 raw = *reinterpret_cast<const float2 *>(conv + ((size_t)n * P + p) * C1 + 2 * gq);
+      x0 = bn.apply(raw.x, 0);
+      x1 = bn.apply(raw.y, 1);
+    }
+    f4 sc = {0.f, 0.f, 0.f, 0.f};
+    sc = mfma16(amq[0], x0, sc);
+    sc = mfma16(amq[1], x1, sc);
+    const float mx = gmax(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])));
+    f4 a;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) a[v] = expf(sc[v] - mx);
+    const float sum = gsum((a[0] + a[1]) + (a[2] + a[3]));
+#pragma unroll
+    for (int v = 0; v < 4; ++v) a[v] = a[v] / sum;
+    f4 zc = cinit;
+    zc = mfma16(awd[0], x0, zc);
+    zc = mfma16(awd[1], x1, zc);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) zc = mfma16(av[v], a[v], zc);
+    if (ok) {
+      if (projA) *reinterpret_cast<f4 *>(projA + ((size_t)n * P + p) * L + 4 * gq) = a;
+      *reinterpret_cast<f4 *>(z + ((size_t)n * P + p) * C2 + 4 * gq) = zc;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const float dlt = zc[v] - pv[v];
+        s1[v] += dlt;
+        s2[v] += dlt * dlt;
+      }
+    }
+  }
+  if (part_pn == nullptr) return;
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    s1[v] = jsum(s1[v]);
+    s2[v] = jsum(s2[v]);
+  }
+  if (j == 0) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      red[wave][4 * gq + v] = s1[v];
+      red[wave][C2 + 4 * gq + v] = s2[v];
+    }
+  }
+  __syncthreads();
+  if (tid < C2) {
+    float d1 = 0.f, d2 = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      d1 += red[w][tid];
+      d2 += red[w][C2 + tid];
+    }
+    part_pn[(size_t)n * 2 * C2 + tid] = d1 + (float)P * piv[tid];
+    part_pn[(size_t)n * 2 * C2 + C2 + tid] = fmaxf(d2 - d1 * d1 / (float)P, 0.f);
+  }
+}
+
+}  // namespace vt
+
+using namespace vt;
+
+extern "C" int vt_projector_fwd(const float *conv_out, const float *bn_stat, const float *bn_gamma, const float *bn_beta,
+                                const float *pk, const float *wd, const float *bd, const float *pivot, float *proj_a,
+                                float *z, float *part_pn, int N, int P, vt_stream s) {
+  if (N < 1 || P < 1 || !pivot) return VT_EUNSUPPORTED;
+  hipLaunchKernelGGL(k_proj_fwd, dim3(N), dim3(TPB), 0, (hipStream_t)s, conv_out, bn_stat, bn_gamma, bn_beta, pk, wd,
+                     bd, pivot, proj_a, z, part_pn, P);
+  VT_CHECK_LAUNCH();
+  return 0;
+}
