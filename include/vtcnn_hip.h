@@ -189,11 +189,11 @@ int vt_fc_wgrad(const float *pooled, const float *d_logits, float *gw, float *gb
  * delta_in = delta * scale + shift, including the reference's row-0 variance term. */
 int vt_bn_bwd_finalize(const float *part, int nblocks, int C, long rows_total, const float *gamma, const float *stat,
                        const float *in_row0, float *ggamma, float *gbeta, float *coef, vt_stream s);
-/* ProjectorLayer::backward, pixel side (projector_layer.hpp:133-184, 204-213). */
+/* ProjectorLayer::backward, pixel side (projector_layer.hpp:133-184, 204-213).  The attention map
+ * is recomputed from conv_out and the per-sample token block pk, not read back. */
 int vt_projector_bwd(const float *du, const float *pn_coef, const float *conv_out, const float *bn_stat,
-                     const float *bn_gamma, const float *bn_beta, const float *proj_a, const float *pk,
-                     const float *wq, const float *wd, float *pdx, float *dv, float *dk, float *gslab, int N,
-                     int P, vt_stream s);
+                     const float *bn_gamma, const float *bn_beta, const float *pk, const float *wq,
+                     const float *wd, float *pdx, float *dv, float *dk, float *gslab, int N, int P, vt_stream s);
 /* ProjectorLayer::backward, token side (projector_layer.hpp:186-202): Dense backward of linear3
  * (values) and linear2 (keys) over the N*L token rows.  g_wk_wv_bv receives the contiguous
  * gradient block [proj.linear2.W | proj.linear3.W | proj.linear3.b]; pdt the token delta.

@@ -71,7 +71,7 @@ SIGNATURES = {
     "vt_head_bwd": (i, [p] * 11 + [i, i, i, p]),
     "vt_fc_wgrad": (i, [p] * 5 + [i, i, i, p]),
     "vt_bn_bwd_finalize": (i, [p, i, i, l, p, p, p, p, p, p, p]),
-    "vt_projector_bwd": (i, [p] * 14 + [i, i, p]),
+    "vt_projector_bwd": (i, [p] * 13 + [i, i, p]),
     "vt_dense_bwd_rows": (i, [p, p, p, p, p, p, i, p, l, i, i, i, p]),
     "vt_tokenizer_bwd": (i, [p] * 10 + [i, i, p]),
     "vt_conv3x3_wgrad": (i, [p, p, p, p, i, i, i, i, p]),

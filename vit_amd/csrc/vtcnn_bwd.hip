@@ -133,181 +133,6 @@ __global__ __launch_bounds__(FIN_T) void k_bn_bwd_finalize(const float *__restri
 }
 
 // ---------------------------------------------------------------------------------------------
-// ProjectorLayer::backward, pixel side (reference layers/projector_layer.hpp:133-184, 204-213).
-// Per pixel (dz = BatchNorm1D input delta):
-//   dx  = dz . Wd^T                                   downsample Dense backward
-//   da  = dz . v^T;  ds = a * (da - sum_l da*a)       softmax_backward over tokens (tensor_cpu.hpp:946-950)
-//   dx += ds . Mq^T                                   (= x_q_delta . Wq^T with Mq = Wq k^T folded)
-// Per-sample sums over pixels (staged through LDS in chunks of 256 pixels):
-//   G[c][l]   = sum_p x[c] ds[l]      ->  dk = G^T Wq (token key delta),  gWq_n = G k
-//   dv[l][c2] = sum_p a[l] dz[c2]     (value delta)
-//   gWd_n     = sum_p x^T dz,  gbd_n = sum_p dz
-// gslab record per image: gWq_n[C1*D] | gWd_n[C1*C2] | gbd_n[C2]  (GS_STRIDE floats).
-// ---------------------------------------------------------------------------------------------
-constexpr int GS_STRIDE = C1 * D + C1 * C2 + C2;  // 400
-constexpr int SX = 12, SA = 20;                   // padded LDS row strides (conflict-free b128)
-__global__ __launch_bounds__(TPB) void k_proj_bwd(const float *__restrict__ du, const float *__restrict__ coef,
-                                                  const float *__restrict__ conv, const float *__restrict__ st,
-                                                  const float *__restrict__ g, const float *__restrict__ b,
-                                                  const float *__restrict__ projA, const float *__restrict__ pk,
-                                                  const float *__restrict__ Wq, const float *__restrict__ Wd,
-                                                  float *__restrict__ pdx, float *__restrict__ dv_out,
-                                                  float *__restrict__ dk_out, float *__restrict__ gslab, int P) {
-  extern __shared__ float sm[];
-  float *sx = sm;                  // [256][SX]
-  float *sa = sx + TPB * SX;       // [256][SA]
-  float *sdz = sa + TPB * SA;      // [256][SA]
-  float *sds = sdz + TPB * SA;     // [256][SA]
-  float *sred = sds + TPB * SA;    // [8][32][18] cross-group reduction
-  float *sG = sred + 8 * 32 * 18;  // [C1][L]
-  const int n = blockIdx.x, tid = threadIdx.x;
-  const float *__restrict__ mq = pk + (size_t)n * PK_STRIDE;
-  const float *__restrict__ vv = mq + C1 * L;
-  const float *__restrict__ kk = vv + L * C2;
-  const int j = tid & 31, pg = tid >> 5, jj = j & 15;
-  const bool lo = j < 16;
-  float ax[C1], aa[8], ab = 0.f;
-#pragma unroll
-  for (int c = 0; c < C1; ++c) ax[c] = 0.f;
-#pragma unroll
-  for (int l = 0; l < 8; ++l) aa[l] = 0.f;
-
-  for (int it = 0; it < PPT; ++it) {
-    const int p = tid + it * TPB;
-    const bool ok = p < P;
-    float x[C1], a[L], dz[C2], ds[L];
-    if (ok) {
-      load_x(conv, (size_t)n * P + p, st, g, b, x);
-      const float4 *as = reinterpret_cast<const float4 *>(projA + ((size_t)n * P + p) * L);
-      const float4 *us = reinterpret_cast<const float4 *>(du + ((size_t)n * P + p) * C2);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float4 av = as[q], uv = us[q];
-        a[4 * q] = av.x; a[4 * q + 1] = av.y; a[4 * q + 2] = av.z; a[4 * q + 3] = av.w;
-        dz[4 * q] = uv.x * coef[4 * q] + coef[C2 + 4 * q];
-        dz[4 * q + 1] = uv.y * coef[4 * q + 1] + coef[C2 + 4 * q + 1];
-        dz[4 * q + 2] = uv.z * coef[4 * q + 2] + coef[C2 + 4 * q + 2];
-        dz[4 * q + 3] = uv.w * coef[4 * q + 3] + coef[C2 + 4 * q + 3];
-      }
-      float dx[C1];
-#pragma unroll
-      for (int c = 0; c < C1; ++c) {
-        float s = 0.f;
-#pragma unroll
-        for (int c2 = 0; c2 < C2; ++c2) s += dz[c2] * Wd[c * C2 + c2];
-        dx[c] = s;
-      }
-      float dot = 0.f;
-#pragma unroll
-      for (int l = 0; l < L; ++l) {
-        float s = 0.f;
-#pragma unroll
-        for (int c2 = 0; c2 < C2; ++c2) s += dz[c2] * vv[l * C2 + c2];
-        ds[l] = s;
-        dot += s * a[l];
-      }
-#pragma unroll
-      for (int l = 0; l < L; ++l) ds[l] = a[l] * (ds[l] - dot);
-#pragma unroll
-      for (int c = 0; c < C1; ++c) {
-        float s = 0.f;
-#pragma unroll
-        for (int l = 0; l < L; ++l) s += ds[l] * mq[c * L + l];
-        dx[c] += s;
-      }
-      float4 *dst = reinterpret_cast<float4 *>(pdx + ((size_t)n * P + p) * C1);
-      dst[0] = make_float4(dx[0], dx[1], dx[2], dx[3]);
-      dst[1] = make_float4(dx[4], dx[5], dx[6], dx[7]);
-    } else {
-#pragma unroll
-      for (int c = 0; c < C1; ++c) x[c] = 0.f;
-#pragma unroll
-      for (int l = 0; l < L; ++l) { a[l] = 0.f; dz[l] = 0.f; ds[l] = 0.f; }
-    }
-    __syncthreads();  // previous chunk fully consumed
-    {
-      float4 *d = reinterpret_cast<float4 *>(sx + tid * SX);
-      d[0] = make_float4(x[0], x[1], x[2], x[3]);
-      d[1] = make_float4(x[4], x[5], x[6], x[7]);
-      float4 *da = reinterpret_cast<float4 *>(sa + tid * SA);
-      float4 *dd = reinterpret_cast<float4 *>(sdz + tid * SA);
-      float4 *de = reinterpret_cast<float4 *>(sds + tid * SA);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        da[q] = make_float4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
-        dd[q] = make_float4(dz[4 * q], dz[4 * q + 1], dz[4 * q + 2], dz[4 * q + 3]);
-        de[q] = make_float4(ds[4 * q], ds[4 * q + 1], ds[4 * q + 2], ds[4 * q + 3]);
-      }
-    }
-    __syncthreads();
-    // lanes j<16 own column dz[j]: x (x) dz[j], a[0..7] (x) dz[j], sum dz[j]
-    // lanes j>=16 own column ds[j-16]: x (x) ds[j-16], and a[8..15] (x) dz[j-16]
-    const int aoff = lo ? 0 : 8;
-#pragma unroll 4
-    for (int m = 0; m < 32; ++m) {
-      const int q = pg + 8 * m;
-      const float wdz = sdz[q * SA + jj];
-      const float wds = sds[q * SA + jj];
-      const float w = lo ? wdz : wds;
-      const float4 x0 = *reinterpret_cast<const float4 *>(sx + q * SX);
-      const float4 x1 = *reinterpret_cast<const float4 *>(sx + q * SX + 4);
-      const float4 a0 = *reinterpret_cast<const float4 *>(sa + q * SA + aoff);
-      const float4 a1 = *reinterpret_cast<const float4 *>(sa + q * SA + aoff + 4);
-      ax[0] += x0.x * w; ax[1] += x0.y * w; ax[2] += x0.z * w; ax[3] += x0.w * w;
-      ax[4] += x1.x * w; ax[5] += x1.y * w; ax[6] += x1.z * w; ax[7] += x1.w * w;
-      aa[0] += a0.x * wdz; aa[1] += a0.y * wdz; aa[2] += a0.z * wdz; aa[3] += a0.w * wdz;
-      aa[4] += a1.x * wdz; aa[5] += a1.y * wdz; aa[6] += a1.z * wdz; aa[7] += a1.w * wdz;
-      ab += wdz;
-    }
-  }
-  // cross pixel-group reduction: 8 groups x 32 columns x 17 values
-  __syncthreads();
-  {
-    float *r = sred + (pg * 32 + j) * 18;
-#pragma unroll
-    for (int c = 0; c < C1; ++c) r[c] = ax[c];
-#pragma unroll
-    for (int l = 0; l < 8; ++l) r[8 + l] = aa[l];
-    r[16] = ab;
-  }
-  __syncthreads();
-  float *srow = gslab + (size_t)n * GS_STRIDE;
-  for (int o = tid; o < 32 * 17; o += TPB) {
-    const int col = o / 17, k = o % 17;
-    float s = 0.f;
-#pragma unroll
-    for (int gq = 0; gq < 8; ++gq) s += sred[(gq * 32 + col) * 18 + k];
-    const int cj = col & 15;
-    if (k < 8) {
-      if (col < 16) srow[C1 * D + k * C2 + cj] = s;  // gWd_n[c=k][c2=cj]
-      else sG[k * L + cj] = s;                       // G[c=k][l=cj]
-    } else if (k < 16) {
-      const int l = (col < 16 ? 0 : 8) + (k - 8);
-      dv_out[((size_t)n * L + l) * C2 + cj] = s;     // dv[l][c2=cj]
-    } else if (col < 16) {
-      srow[C1 * D + C1 * C2 + cj] = s;               // gbd_n[c2]
-    }
-  }
-  __syncthreads();
-  // token key delta dk[l][d] = sum_c G[c][l] Wq[c][d]  (t_q_delta = x_q^T . softmax_delta, :183-184)
-  for (int o = tid; o < L * D; o += TPB) {
-    const int l = o / D, d = o % D;
-    float s = 0.f;
-#pragma unroll
-    for (int c = 0; c < C1; ++c) s += sG[c * L + l] * Wq[c * D + d];
-    dk_out[(size_t)n * L * D + o] = s;
-  }
-  // gWq_n[c][d] = sum_l G[c][l] k[l][d]  (linear1 grad = x^T . (softmax_delta . t_q), :180, 205-206)
-  for (int o = tid; o < C1 * D; o += TPB) {
-    const int c = o / D, d = o % D;
-    float s = 0.f;
-#pragma unroll
-    for (int l = 0; l < L; ++l) s += sG[c * L + l] * kk[l * D + d];
-    srow[o] = s;
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
 // ProjectorLayer::backward, token side (reference projector_layer.hpp:186-202): Dense backward of
 // linear3 (values) and linear2 (keys) over the N*L token rows.
 //   gWv = o^T dv, gbv = sum dv, gWk = o^T dk, token delta = dv.Wv^T + dk.Wk^T
@@ -793,24 +618,6 @@ extern "C" int vt_bn_bwd_finalize(const float *part, int nblocks, int C, long ro
   if (C < 1 || FIN_T % (2 * C) != 0 || nblocks < 1 || rows_total < 1) return VT_EUNSUPPORTED;
   hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(1), dim3(FIN_T), 0, (hipStream_t)s, part, nblocks, C, rows_total, gamma,
                      stat, in_row0, ggamma, gbeta, coef);
-  VT_CHECK_LAUNCH();
-  return 0;
-}
-
-extern "C" int vt_projector_bwd(const float *du, const float *pn_coef, const float *conv_out, const float *bn_stat,
-                                const float *bn_gamma, const float *bn_beta, const float *proj_a, const float *pk,
-                                const float *wq, const float *wd, float *pdx, float *dv, float *dk, float *gslab, int N,
-                                int P, vt_stream s) {
-  if (N < 1 || P < 1 || P > PPT * TPB) return VT_EUNSUPPORTED;
-  const size_t lds = (size_t)(TPB * SX + 3 * TPB * SA + 8 * 32 * 18 + C1 * L) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void *)k_proj_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(k_proj_bwd, dim3(N), dim3(TPB), lds, (hipStream_t)s, du, pn_coef, conv_out, bn_stat, bn_gamma,
-                     bn_beta, proj_a, pk, wq, wd, pdx, dv, dk, gslab, P);
   VT_CHECK_LAUNCH();
   return 0;
 }

@@ -577,7 +577,7 @@ extern "C" int vt_model_backward(vt_model *m, const int *d_labels, vt_stream s) 
                            m->G_("proj.norm.gamma"), m->G_("proj.norm.beta"), m->coef_pn, s));
   STEP("fc_wgrad", vt_fc_wgrad(m->pooled, m->dlogits, m->G_("fc.W"), m->G_("fc.b"), m->rowscratch, n, Q, K, s));
   // projector
-  STEP("projector_bwd", vt_projector_bwd(m->du, m->coef_pn, m->conv, m->stat_bn, m->P_("bn.gamma"), m->P_("bn.beta"), m->projA, m->pk,
+  STEP("projector_bwd", vt_projector_bwd(m->du, m->coef_pn, m->conv, m->stat_bn, m->P_("bn.gamma"), m->P_("bn.beta"), m->pk,
                          m->P_("proj.linear1.W"), m->P_("proj.downsample.W"), m->pdx, m->dv, m->dk, m->gslab, n, P, s));
   STEP("reduce_rows", vt_reduce_rows(m->gslab, n, C1 * D, 400, m->G_("proj.linear1.W"), s));
   STEP("reduce_rows", vt_reduce_rows(m->gslab + C1 * D, n, C1 * C2 + C2, 400, m->G_("proj.downsample.W"), s));

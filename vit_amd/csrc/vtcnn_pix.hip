@@ -162,6 +162,163 @@ __global__ __launch_bounds__(TPB) void k_proj_fwd(const float *__restrict__ conv
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// ProjectorLayer::backward, pixel side (reference layers/projector_layer.hpp:133-184, 204-213).
+// Per pixel (dz = BatchNorm1D input delta, a = softmax_L(x.Mq) recomputed):
+//   dx  = dz . Wd^T                                   downsample Dense backward
+//   da  = dz . v^T;  ds = a * (da - sum_l da*a)       softmax_backward over tokens (tensor_cpu.hpp:946-950)
+//   dx += ds . Mq^T                                   (= x_q_delta . Wq^T with Mq = Wq k^T folded)
+// Per-sample sums over pixels:
+//   G[c][l]   = sum_p x[c] ds[l]      ->  dk = G^T Wq (token key delta),  gWq_n = G k
+//   dv[l][c2] = sum_p a[l] dz[c2]     (value delta)
+//   gWd_n     = sum_p x^T dz,  gbd_n = sum_p dz
+// gslab record per image: gWq_n[C1*D] | gWd_n[C1*C2] | gbd_n[C2]  (GS_STRIDE floats).
+//
+// One wave per 16-pixel tile.  The per-pixel part runs in T layout (26 MFMAs per tile in total):
+// scores (2), da (4), dx (8, the token and the c2 contraction chained into one accumulator).
+// The sums over pixels need the pixel as the contraction index, i.e. x, a, dz, ds in N layout:
+// the wave passes the four tiles through its private LDS patch (row stride 60 floats: the b128
+// writes of 8 consecutive lanes cover all banks) and accumulates G, gWd|gbd (a row of ones in the
+// x operand yields the bias gradient) and dv in three D tiles that stay in registers over all
+// tiles of the wave; the four waves are summed through LDS at the end.
+// ---------------------------------------------------------------------------------------------
+constexpr int GS_STRIDE = C1 * D + C1 * C2 + C2;  // 400
+constexpr int PB_RS = 60;                          // LDS row stride of the transposition patch
+constexpr int PB_X = 0, PB_A = 8, PB_DZ = 24, PB_DS = 40;
+__global__ __launch_bounds__(TPB) void k_proj_bwd(const float *__restrict__ du, const float *__restrict__ coef,
+                                                  const float *__restrict__ conv, const float *__restrict__ st,
+                                                  const float *__restrict__ g, const float *__restrict__ b,
+                                                  const float *__restrict__ pk, const float *__restrict__ Wq,
+                                                  const float *__restrict__ Wd, float *__restrict__ pdx,
+                                                  float *__restrict__ dv_out, float *__restrict__ dk_out,
+                                                  float *__restrict__ gslab, int P) {
+  __shared__ __attribute__((aligned(16))) float patch[NW][16 * PB_RS];
+  __shared__ float sred[NW][3][256];
+  __shared__ float sG[C1 * L];
+  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, gq = lane >> 4;
+  const float *__restrict__ mq = pk + (size_t)n * PK_STRIDE;
+  const float *__restrict__ vv = mq + C1 * L;
+  const float *__restrict__ kk = vv + L * C2;
+  float amq[2], av[4], awd[4], amt[4], cf0[4], cf1[4];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) amq[s] = mq[(2 * gq + s) * L + j];  // A[token j][channel 2g+s]
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    av[v] = vv[j * C2 + 4 * gq + v];                       // A[token j][c2 4g+v]
+    awd[v] = j < C1 ? Wd[j * C2 + 4 * gq + v] : 0.f;       // A[channel j][c2 4g+v]
+    amt[v] = j < C1 ? mq[j * L + 4 * gq + v] : 0.f;        // A[channel j][token 4g+v]
+    cf0[v] = coef[4 * gq + v];
+    cf1[v] = coef[C2 + 4 * gq + v];
+  }
+  BnPair bn;
+  bn.init(st, g, b, gq);
+  f4 accG = {0.f, 0.f, 0.f, 0.f}, accW = accG, accV = accG;
+  float *pt = patch[wave];
+  const int ntiles = (P + 15) >> 4;
+  for (int t = wave; t < ntiles; t += NW) {
+    const int p = t * 16 + j;
+    const bool ok = p < P;
+    float x0 = 0.f, x1 = 0.f;
+    f4 dz = {0.f, 0.f, 0.f, 0.f};
+    if (ok) {
+      const float2 raw = *reinterpret_cast<const float2 *>(conv + ((size_t)n * P + p) * C1 + 2 * gq);
+      const f4 u = *reinterpret_cast<const f4 *>(du + ((size_t)n * P + p) * C2 + 4 * gq);
+      x0 = bn.apply(raw.x, 0);
+      x1 = bn.apply(raw.y, 1);
+#pragma unroll
+      for (int v = 0; v < 4; ++v) dz[v] = u[v] * cf0[v] + cf1[v];
+    }
+    f4 sc = {0.f, 0.f, 0.f, 0.f};
+    sc = mfma16(amq[0], x0, sc);
+    sc = mfma16(amq[1], x1, sc);
+    const float mx = gmax(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])));
+    f4 a;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) a[v] = expf(sc[v] - mx);
+    const float sum = gsum((a[0] + a[1]) + (a[2] + a[3]));
+#pragma unroll
+    for (int v = 0; v < 4; ++v) a[v] = a[v] / sum;
+    f4 da = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int v = 0; v < 4; ++v) da = mfma16(av[v], dz[v], da);
+    const float dot = gsum((da[0] * a[0] + da[1] * a[1]) + (da[2] * a[2] + da[3] * a[3]));
+    f4 ds;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) ds[v] = a[v] * (da[v] - dot);
+    f4 dx = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int v = 0; v < 4; ++v) dx = mfma16(awd[v], dz[v], dx);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) dx = mfma16(amt[v], ds[v], dx);
+    if (ok && gq < 2) *reinterpret_cast<f4 *>(pdx + ((size_t)n * P + p) * C1 + 4 * gq) = dx;
+    // T -> N through the wave's LDS patch
+    *reinterpret_cast<float2 *>(pt + j * PB_RS + PB_X + 2 * gq) = make_float2(x0, x1);
+    *reinterpret_cast<f4 *>(pt + j * PB_RS + PB_A + 4 * gq) = a;
+    *reinterpret_cast<f4 *>(pt + j * PB_RS + PB_DZ + 4 * gq) = dz;
+    *reinterpret_cast<f4 *>(pt + j * PB_RS + PB_DS + 4 * gq) = ds;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float xn[4], an[4], dzn[4], dsn[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const float *row = pt + (4 * gq + v) * PB_RS;
+      xn[v] = j < C1 ? row[PB_X + j] : (j == C1 ? 1.f : 0.f);
+      an[v] = row[PB_A + j];
+      dzn[v] = row[PB_DZ + j];
+      dsn[v] = row[PB_DS + j];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      accG = mfma16(xn[v], dsn[v], accG);  // [channel | .][token]
+      accW = mfma16(xn[v], dzn[v], accW);  // [channel | ones][c2]
+      accV = mfma16(an[v], dzn[v], accV);  // [token][c2]
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    sred[wave][0][(4 * gq + v) * 16 + j] = accG[v];
+    sred[wave][1][(4 * gq + v) * 16 + j] = accW[v];
+    sred[wave][2][(4 * gq + v) * 16 + j] = accV[v];
+  }
+  __syncthreads();
+  float *srow = gslab + (size_t)n * GS_STRIDE;
+  for (int o = tid; o < 3 * 256; o += TPB) {
+    const int which = o >> 8, idx = o & 255, r = idx >> 4, c = idx & 15;
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) s += sred[w][which][idx];
+    if (which == 0) {
+      if (r < C1) sG[r * L + c] = s;                       // G[channel r][token c]
+    } else if (which == 1) {
+      if (r < C1) srow[C1 * D + r * C2 + c] = s;           // gWd_n[channel r][c2]
+      else if (r == C1) srow[C1 * D + C1 * C2 + c] = s;    // gbd_n[c2]
+    } else {
+      dv_out[((size_t)n * L + r) * C2 + c] = s;            // dv[token r][c2]
+    }
+  }
+  __syncthreads();
+  // token key delta dk[l][d] = sum_c G[c][l] Wq[c][d]  (t_q_delta = x_q^T . softmax_delta, :183-184)
+  for (int o = tid; o < L * D; o += TPB) {
+    const int l = o / D, d = o % D;
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < C1; ++c) s += sG[c * L + l] * Wq[c * D + d];
+    dk_out[(size_t)n * L * D + o] = s;
+  }
+  // gWq_n[c][d] = sum_l G[c][l] k[l][d]  (linear1 grad = x^T . (softmax_delta . t_q), :180, 205-206)
+  for (int o = tid; o < C1 * D; o += TPB) {
+    const int c = o / D, d = o % D;
+    float s = 0.f;
+#pragma unroll
+    for (int l = 0; l < L; ++l) s += sG[c * L + l] * kk[l * D + d];
+    srow[o] = s;
+  }
+}
+
 }  // namespace vt
 
 using namespace vt;
@@ -172,6 +329,18 @@ extern "C" int vt_projector_fwd(const float *conv_out, const float *bn_stat, con
   if (N < 1 || P < 1 || !pivot) return VT_EUNSUPPORTED;
   hipLaunchKernelGGL(k_proj_fwd, dim3(N), dim3(TPB), 0, (hipStream_t)s, conv_out, bn_stat, bn_gamma, bn_beta, pk, wd,
                      bd, pivot, proj_a, z, part_pn, P);
+  VT_CHECK_LAUNCH();
+  return 0;
+}
+
+
+extern "C" int vt_projector_bwd(const float *du, const float *pn_coef, const float *conv_out, const float *bn_stat,
+                                const float *bn_gamma, const float *bn_beta, const float *pk, const float *wq,
+                                const float *wd, float *pdx, float *dv, float *dk, float *gslab, int N, int P,
+                                vt_stream s) {
+  if (N < 1 || P < 1) return VT_EUNSUPPORTED;
+  hipLaunchKernelGGL(k_proj_bwd, dim3(N), dim3(TPB), 0, (hipStream_t)s, du, pn_coef, conv_out, bn_stat, bn_gamma,
+                     bn_beta, pk, wq, wd, pdx, dv, dk, gslab, P);
   VT_CHECK_LAUNCH();
   return 0;
 }
