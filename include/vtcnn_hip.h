@@ -69,6 +69,11 @@ float *vt_model_grads_ptr(vt_model *m);
 int vt_model_save(vt_model *m, const char *path);
 int vt_model_load(vt_model *m, const char *path);
 
+/* Test aid: when on, forward also stores the two attention maps that the backward pass otherwise
+ * recomputes ("fwd.tok_A", "fwd.proj_a", each [N,P,L]: FilterTokenizer's softmax over pixels,
+ * tokenizer.hpp:36, and the projector's softmax over tokens, projector_layer.hpp:84) so that
+ * vt_model_read can return them.  Allocates the two buffers on first use. */
+int vt_model_keep_internals(vt_model *m, int on);
 /* VTCNN::set_training (model/vit_cnn.hpp:262-269): only BatchNorm2D honours eval mode; the three
  * BatchNorm1D layers always use batch statistics (layers/visual_transformer.hpp:221). */
 int vt_model_set_training(vt_model *m, int training);
@@ -139,11 +144,13 @@ int vt_bn_stats_finalize(const float *part, int nblocks, int C, long rows_per_bl
 /* Eval-mode statistics (batch_normalization_layer.hpp:287-291): stat from the running buffers. */
 int vt_bn_stats_eval(const float *running_mean, const float *running_var, int C, float *stat, vt_stream s);
 /* BatchNorm2D apply + flatten/transpose (model/vit_cnn.hpp:127-134) + FilterTokenizer::forward
- * (layers/tokenizer.hpp:22-48).  Writes tok_A [N,P,L], tokens [N*L,D] and per-sample partial
- * statistics of the tokens for the transformer's first BatchNorm1D. */
+ * (layers/tokenizer.hpp:22-48).  Writes tokens [N*L,D], the per-sample softmax statistics
+ * tok_stat [N][2][L] = (max, sum over pixels per token) the backward pass rebuilds A from, the
+ * per-sample partial statistics of the tokens for the transformer's first BatchNorm1D, and,
+ * when tok_A is non-null, the attention map [N,P,L] itself.  P <= 832. */
 int vt_tokenizer_fwd(const float *conv_out, const float *bn_stat, const float *bn_gamma, const float *bn_beta,
                      const float *w1, const float *b1, const float *w2, const float *b2, float *tok_A,
-                     float *tokens, float *part_n1, int N, int P, vt_stream s);
+                     float *tok_stat, float *tokens, float *part_n1, int N, int P, vt_stream s);
 /* TransformerLayer::forward up to the second BatchNorm's input (layers/transformer_layer.hpp:43-120);
  * the attention branch contributes exactly 0 in the reference (Tensor::concat returns zeros,
  * tensor_cpu.hpp:251).  rows = N*L.  Writes a, hdn (pre-ReLU), s2 = a + ffn(a) and the partial
@@ -234,8 +241,8 @@ int vt_dense_bwd_rows(const float *X, const float *W, const float *dY, float *gW
                       int accumulate_dx, float *scratch, long rows, int in, int out, int relu_x, vt_stream s);
 /* FilterTokenizer::backward2 (layers/tokenizer.hpp:50-107) + partial sums of BatchNorm2D backward. */
 int vt_tokenizer_bwd(const float *conv_out, const float *bn_stat, const float *bn_gamma, const float *bn_beta,
-                     const float *tok_A, const float *dT0, const float *w1, const float *pdx, float *dy,
-                     float *part, int N, int P, vt_stream s);
+                     const float *tok_stat, const float *dT0, const float *w1, const float *b1, const float *pdx,
+                     float *dy, float *part, int N, int P, vt_stream s);
 /* BatchNorm2D backward apply + Conv2DLayer::backward weight/bias gradients
  * (conv2d_layer.hpp:115-147); the conv input delta is never consumed and is not computed. */
 int vt_conv3x3_wgrad(const float *x, const float *dy, const float *bn_coef, float *gslab, int N, int Ci, int H, int W,

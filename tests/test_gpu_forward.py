@@ -18,6 +18,7 @@ def _model(k, max_batch, g=None):
     if g is not None:
         lo = Layout(make_dims(num_classes=k))
         m.set_arena(lo.pack(g, "p0."))
+    m.keep_internals(True)
     return m, torch
 
 

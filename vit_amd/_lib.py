@@ -46,6 +46,7 @@ SIGNATURES = {
     "vt_model_save": (i, [p, C.c_char_p]),
     "vt_model_load": (i, [p, C.c_char_p]),
     "vt_model_set_training": (i, [p, i]),
+    "vt_model_keep_internals": (i, [p, i]),
     "vt_model_forward": (i, [p, p, i, p, p]),
     "vt_model_backward": (i, [p, p, p]),
     "vt_model_sgd_step": (i, [p, f, f, p]),
@@ -62,7 +63,7 @@ SIGNATURES = {
     "vt_conv3x3_fwd": (i, [p, p, p, p, p, i, i, i, i, p]),
     "vt_bn_stats_finalize": (i, [p, i, i, l, l, p, p, p, p]),
     "vt_bn_stats_eval": (i, [p, p, i, p, p]),
-    "vt_tokenizer_fwd": (i, [p] * 11 + [i, i, p]),
+    "vt_tokenizer_fwd": (i, [p] * 12 + [i, i, p]),
     "vt_transformer_ffn_fwd": (i, [p] * 12 + [l, p]),
     "vt_projector_tokens_fwd": (i, [p] * 10 + [i, p]),
     "vt_projector_fwd": (i, [p] * 11 + [i, i, p]),
@@ -73,7 +74,7 @@ SIGNATURES = {
     "vt_bn_bwd_finalize": (i, [p, i, i, l, p, p, p, p, p, p, p]),
     "vt_projector_bwd": (i, [p] * 13 + [i, i, p]),
     "vt_dense_bwd_rows": (i, [p, p, p, p, p, p, i, p, l, i, i, i, p]),
-    "vt_tokenizer_bwd": (i, [p] * 10 + [i, i, p]),
+    "vt_tokenizer_bwd": (i, [p] * 11 + [i, i, p]),
     "vt_conv3x3_wgrad": (i, [p, p, p, p, i, i, i, i, p]),
     "vt_reduce_rows": (i, [p, l, i, i, p, p]),
     "vt_sgd_update": (i, [p, p, i, f, f, i, p]),

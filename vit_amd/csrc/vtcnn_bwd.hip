@@ -8,19 +8,6 @@
 
 namespace vt {
 
-__device__ __forceinline__ void load_x_raw(const float *__restrict__ conv, size_t rec, const float *__restrict__ st,
-                                           const float *__restrict__ g, const float *__restrict__ b, float (&x)[C1],
-                                           float (&xh)[C1]) {
-  const float4 *src = reinterpret_cast<const float4 *>(conv + rec * C1);
-  const float4 a = src[0], c = src[1];
-  const float raw[C1] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
-#pragma unroll
-  for (int ch = 0; ch < C1; ++ch) {
-    xh[ch] = (raw[ch] - st[ch]) * st[C1 + ch];
-    x[ch] = xh[ch] * g[ch] + b[ch];
-  }
-}
-
 // ---------------------------------------------------------------------------------------------
 // fc DenseLayer::backward weight / bias gradients (reference layers/dense_layer.hpp:92-96):
 // gW[f][k] = sum_n pooled[n][f] * delta[n][k], gb[k] = sum_n delta[n][k].  Thread = one input
@@ -378,68 +365,6 @@ __global__ __launch_bounds__(TPB) void k_tr_bwd_c(const float *__restrict__ da, 
 }
 
 // ---------------------------------------------------------------------------------------------
-// FilterTokenizer::backward2 (reference layers/tokenizer.hpp:50-107).  Per pixel:
-//   dA[l] = dT0[l] . x;  dx = A . dT0;  dS = A * (dA - sum_l dA*A)   (softmax_backward reduces over
-//   the token axis although the forward softmax ran over pixels, tokenizer.hpp:36,91)
-//   dx += dS . W1^T;  dx += projector input delta                         (tokenizer.hpp:97,105)
-// The tokenizer's own Dense gradients are never applied by the reference (no optimizer is ever
-// attached to them, tokenizer.hpp:18-19) and are not computed.  Fused: partial sums of the
-// BatchNorm2D backward over the result (vit_cnn.hpp:236-238).
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(TPB) void k_tokenizer_bwd(const float *__restrict__ conv, const float *__restrict__ st,
-                                                       const float *__restrict__ g, const float *__restrict__ b,
-                                                       const float *__restrict__ tokA, const float *__restrict__ dT0,
-                                                       const float *__restrict__ W1, const float *__restrict__ pdx,
-                                                       float *__restrict__ dy, float *__restrict__ part, int P) {
-  __shared__ float red[NW * 2 * C1];
-  const int n = blockIdx.x, tid = threadIdx.x;
-  const float *__restrict__ dt = dT0 + (size_t)n * L * C1;
-  float s[2 * C1];
-#pragma unroll
-  for (int c = 0; c < 2 * C1; ++c) s[c] = 0.f;
-  for (int p = tid; p < P; p += TPB) {
-    float x[C1], xh[C1], A[L];
-    load_x_raw(conv, (size_t)n * P + p, st, g, b, x, xh);
-    const float4 *as = reinterpret_cast<const float4 *>(tokA + ((size_t)n * P + p) * L);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float4 av = as[q];
-      A[4 * q] = av.x; A[4 * q + 1] = av.y; A[4 * q + 2] = av.z; A[4 * q + 3] = av.w;
-    }
-    float dA[L], dot = 0.f;
-#pragma unroll
-    for (int l = 0; l < L; ++l) {
-      float t = 0.f;
-#pragma unroll
-      for (int c = 0; c < C1; ++c) t += dt[l * C1 + c] * x[c];
-      dA[l] = t;
-      dot += t * A[l];
-    }
-    const float4 *ps = reinterpret_cast<const float4 *>(pdx + ((size_t)n * P + p) * C1);
-    const float4 p0 = ps[0], p1 = ps[1];
-    const float pin[C1] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
-    float dx[C1];
-#pragma unroll
-    for (int c = 0; c < C1; ++c) {
-      float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-      for (int l = 0; l < L; ++l) {
-        t1 += A[l] * dt[l * C1 + c];
-        t2 += (A[l] * (dA[l] - dot)) * W1[c * L + l];
-      }
-      dx[c] = (t1 + t2) + pin[c];
-      s[c] += dx[c];
-      s[C1 + c] += dx[c] * xh[c];
-    }
-    float4 *dst = reinterpret_cast<float4 *>(dy + ((size_t)n * P + p) * C1);
-    dst[0] = make_float4(dx[0], dx[1], dx[2], dx[3]);
-    dst[1] = make_float4(dx[4], dx[5], dx[6], dx[7]);
-  }
-  block_sum<2 * C1>(s, red);
-  if (tid < 2 * C1) part[(size_t)n * 2 * C1 + tid] = s[tid];
-}
-
-// ---------------------------------------------------------------------------------------------
 // BatchNorm2D backward apply + Conv2DLayer::backward gradients (reference
 // layers/conv2d_layer.hpp:115-147): gb[co] = sum delta, gW[co][ci][kh][kw] = sum xpad * delta.
 // The conv input delta (:150-190) is never consumed (first layer) and is not computed.
@@ -664,17 +589,6 @@ extern "C" int vt_transformer_bwd_c(const float *da, const float *n1_coef, const
   return 0;
 }
 
-extern "C" int vt_tokenizer_bwd(const float *conv_out, const float *bn_stat, const float *bn_gamma, const float *bn_beta,
-                                const float *tok_A, const float *dT0, const float *w1, const float *pdx, float *dy,
-                                float *part, int N, int P, vt_stream s) {
-  if (N < 1 || P < 1 || P > PPT * TPB) return VT_EUNSUPPORTED;
-  hipLaunchKernelGGL(k_tokenizer_bwd, dim3(N), dim3(TPB), 0, (hipStream_t)s, conv_out, bn_stat, bn_gamma, bn_beta,
-                     tok_A, dT0, w1, pdx, dy, part, P);
-  VT_CHECK_LAUNCH();
-  return 0;
-}
-
-// gslab: N rows of ld >= C1*Ci*9 + C1 floats.
 extern "C" int vt_conv3x3_wgrad(const float *x, const float *dy, const float *bn_coef, float *gslab, int N, int Ci,
                                 int H, int W, vt_stream s) {
   if (N < 1 || Ci < 1 || H * W > PPT * TPB) return VT_EUNSUPPORTED;

@@ -165,115 +165,6 @@ __global__ void k_bn_stats_eval(const float *__restrict__ run_mean, const float 
 }
 
 // ---------------------------------------------------------------------------------------------
-// FilterTokenizer::forward (reference layers/tokenizer.hpp:22-48) fused with the BatchNorm2D apply
-// and the NCHW->[N,P,C] transpose (model/vit_cnn.hpp:127-134).  One workgroup per image.
-//   S = x.W1 + b1;  A = softmax over the P pixels per token;  T0 = A^T.x;  t = T0.W2 + b2
-// The softmax reductions over pixels are wave shuffles + one LDS hop; T0 (16x8 sums over 784
-// pixels) uses the transposing butterfly reduction.
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(TPB) void k_tokenizer_fwd(const float *__restrict__ conv, const float *__restrict__ st,
-                                                       const float *__restrict__ g, const float *__restrict__ b,
-                                                       const float *__restrict__ W1, const float *__restrict__ b1,
-                                                       const float *__restrict__ W2, const float *__restrict__ b2,
-                                                       float *__restrict__ tokA, float *__restrict__ tok,
-                                                       float *__restrict__ part_n1, int P) {
-  __shared__ float red[NW * 64];
-  __shared__ float sT0[L * C1];
-  __shared__ float st_[L * D];
-  const int n = blockIdx.x, tid = threadIdx.x;
-  float x[PPT][C1], e[PPT][L];
-  float cm[L];
-#pragma unroll
-  for (int l = 0; l < L; ++l) cm[l] = -INFINITY;
-#pragma unroll
-  for (int it = 0; it < PPT; ++it) {
-    const int p = tid + it * TPB;
-    const bool ok = p < P;
-    if (ok) {
-      load_x(conv, (size_t)n * P + p, st, g, b, x[it]);
-    } else {
-#pragma unroll
-      for (int ch = 0; ch < C1; ++ch) x[it][ch] = 0.f;
-    }
-#pragma unroll
-    for (int l = 0; l < L; ++l) {
-      float s = 0.f;
-#pragma unroll
-      for (int ch = 0; ch < C1; ++ch) s += x[it][ch] * W1[ch * L + l];
-      s += b1[l];
-      e[it][l] = s;
-      cm[l] = ok ? fmaxf(cm[l], s) : cm[l];
-    }
-  }
-  block_max<L>(cm, red);
-  float cs[L];
-#pragma unroll
-  for (int l = 0; l < L; ++l) cs[l] = 0.f;
-#pragma unroll
-  for (int it = 0; it < PPT; ++it) {
-    const bool ok = tid + it * TPB < P;
-#pragma unroll
-    for (int l = 0; l < L; ++l) {
-      const float v = ok ? expf(e[it][l] - cm[l]) : 0.f;
-      e[it][l] = v;
-      cs[l] += v;
-    }
-  }
-  block_sum<L>(cs, red);
-#pragma unroll
-  for (int it = 0; it < PPT; ++it) {
-    const int p = tid + it * TPB;
-#pragma unroll
-    for (int l = 0; l < L; ++l) e[it][l] = e[it][l] / cs[l];
-    if (p < P) {
-      float4 *dst = reinterpret_cast<float4 *>(tokA + ((size_t)n * P + p) * L);
-#pragma unroll
-      for (int q = 0; q < L / 4; ++q) dst[q] = make_float4(e[it][4 * q], e[it][4 * q + 1], e[it][4 * q + 2], e[it][4 * q + 3]);
-    }
-  }
-  // T0[l][c] = sum_p A[p][l] * x[p][c]  (a^T . x, tokenizer.hpp:39-40), two halves of 8 tokens
-#pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    float acc[64];
-#pragma unroll
-    for (int lh = 0; lh < 8; ++lh)
-#pragma unroll
-      for (int ch = 0; ch < C1; ++ch) {
-        float s = 0.f;
-#pragma unroll
-        for (int it = 0; it < PPT; ++it) s += e[it][half * 8 + lh] * x[it][ch];
-        acc[lh * C1 + ch] = s;
-      }
-    block_xreduce<64>(acc, red, sT0 + half * 64);
-  }
-  // t = T0 . W2 + b2  (linear2, tokenizer.hpp:42-44)
-  for (int o = tid; o < L * D; o += TPB) {
-    const int l = o / D, d = o % D;
-    float s = 0.f;
-#pragma unroll
-    for (int ch = 0; ch < C1; ++ch) s += sT0[l * C1 + ch] * W2[ch * D + d];
-    s += b2[d];
-    st_[o] = s;
-    tok[(size_t)n * L * D + o] = s;
-  }
-  __syncthreads();
-  if (tid < D && part_n1 != nullptr) {  // per-sample partial statistics for the transformer's norm1
-    float s = 0.f;
-#pragma unroll
-    for (int l = 0; l < L; ++l) s += st_[l * D + tid];
-    const float mu = s * (1.0f / L);
-    float q = 0.f;
-#pragma unroll
-    for (int l = 0; l < L; ++l) {
-      const float dlt = st_[l * D + tid] - mu;
-      q += dlt * dlt;
-    }
-    part_n1[(size_t)n * 2 * D + tid] = s;
-    part_n1[(size_t)n * 2 * D + D + tid] = q;
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
 // TransformerLayer::forward (reference layers/transformer_layer.hpp:43-120) over the flat
 // [N*L, D] token matrix (Tensor::permute does not move data, tensor_cpu.hpp:719-747).
 // The attention branch is identically zero in the reference (Tensor::concat returns zeros,
@@ -456,16 +347,6 @@ extern "C" int vt_bn_stats_finalize(const float *part, int nblocks, int C, long 
 extern "C" int vt_bn_stats_eval(const float *running_mean, const float *running_var, int C, float *stat, vt_stream s) {
   if (C < 1 || C > 64) return VT_EUNSUPPORTED;
   hipLaunchKernelGGL(k_bn_stats_eval, dim3(1), dim3(64), 0, (hipStream_t)s, running_mean, running_var, C, stat);
-  VT_CHECK_LAUNCH();
-  return 0;
-}
-
-extern "C" int vt_tokenizer_fwd(const float *conv_out, const float *bn_stat, const float *bn_gamma, const float *bn_beta,
-                                const float *w1, const float *b1, const float *w2, const float *b2, float *tok_A,
-                                float *tokens, float *part_n1, int N, int P, vt_stream s) {
-  if (N < 1 || P < 1 || P > PPT * TPB) return VT_EUNSUPPORTED;
-  hipLaunchKernelGGL(k_tokenizer_fwd, dim3(N), dim3(TPB), 0, (hipStream_t)s, conv_out, bn_stat, bn_gamma, bn_beta, w1,
-                     b1, w2, b2, tok_A, tokens, part_n1, P);
   VT_CHECK_LAUNCH();
   return 0;
 }

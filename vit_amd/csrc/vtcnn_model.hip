@@ -32,12 +32,13 @@ struct vt_model {
   vt_layout lo;
   int maxN = 0, device = 0, lastN = 0, training = 1;
   int P = 0, Q = 0, K = 0;
+  bool keep_internals = false;  // also store the two attention maps (test aid)
   bool own_arena = false, own_grads = false;
   float *arena = nullptr, *grads = nullptr;
   std::vector<void *> allocs;
   std::map<std::string, std::pair<float *, long>> named;  // name -> (device ptr, floats per sample or total)
   // forward workspace
-  float *conv, *tokA, *tok, *a, *hdn, *s2, *o, *pk, *projA, *z, *pooled, *logits, *probs;
+  float *conv, *tokA = nullptr, *tokstat, *tok, *a, *hdn, *s2, *o, *pk, *projA = nullptr, *z, *pooled, *logits, *probs;
   unsigned char *pool_idx;
   float *part, *stat_bn, *stat_n1, *stat_n2, *stat_pn;
   const float *last_images = nullptr;
@@ -100,14 +101,13 @@ extern "C" int vt_model_create(const vt_dims *dims, int max_batch, int device, f
   if (ext_arena) m->arena = ext_arena; else { rc |= dalloc(m, &m->arena, lo.n_total); m->own_arena = true; }
   if (ext_grads) m->grads = ext_grads; else { rc |= dalloc(m, &m->grads, lo.n_trainable); m->own_grads = true; }
   rc |= dalloc(m, &m->conv, N * P * C1, "fwd.conv_out");
-  rc |= dalloc(m, &m->tokA, N * P * L, "fwd.tok_A");
+  rc |= dalloc(m, &m->tokstat, N * 2 * L, "fwd.tok_stat");
   rc |= dalloc(m, &m->tok, NL * D, "fwd.tok_out");
   rc |= dalloc(m, &m->a, NL * D, "fwd.tr_a");
   rc |= dalloc(m, &m->hdn, NL * D, "fwd.tr_hdn");
   rc |= dalloc(m, &m->s2, NL * D, "fwd.tr_s2");
   rc |= dalloc(m, &m->o, NL * D, "fwd.tr_out");
   rc |= dalloc(m, &m->pk, N * PK_STRIDE, "fwd.proj_pk");
-  rc |= dalloc(m, &m->projA, N * P * L, "fwd.proj_a");
   rc |= dalloc(m, &m->z, N * P * C2, "fwd.proj_z");
   rc |= dalloc(m, &m->pooled, N * Q, "fwd.pooled");
   rc |= dalloc(m, &m->logits, N * K, "fwd.logits");
@@ -520,6 +520,17 @@ extern "C" int vt_model_profile_read(vt_model *m, int idx, char *name_out, int n
   }
   return (int)m->prof_names.size();
 }
+extern "C" int vt_model_keep_internals(vt_model *m, int on) {
+  if (!m) return VT_EINVAL;
+  if (on && !m->tokA) {
+    HIPCHK(hipSetDevice(m->device));
+    const size_t n = (size_t)m->maxN * m->P * L;
+    if (dalloc(m, &m->tokA, n, "fwd.tok_A") != 0 || dalloc(m, &m->projA, n, "fwd.proj_a") != 0) return VT_ENOMEM;
+  }
+  m->keep_internals = on != 0;
+  return 0;
+}
+
 extern "C" int vt_model_set_training(vt_model *m, int training) {
   if (!m) return VT_EINVAL;
   m->training = training ? 1 : 0;
@@ -541,7 +552,8 @@ extern "C" int vt_model_forward(vt_model *m, const float *d_images, int n, float
     STEP("bn_stats_eval", vt_bn_stats_eval(m->P_("bn.running_mean"), m->P_("bn.running_var"), C1, m->stat_bn, s));
   // tokenizer; the three BatchNorm1D layers always use batch statistics (visual_transformer.hpp:221)
   STEP("tokenizer_fwd", vt_tokenizer_fwd(m->conv, m->stat_bn, m->P_("bn.gamma"), m->P_("bn.beta"), m->P_("tok.linear1.W"),
-                         m->P_("tok.linear1.b"), m->P_("tok.linear2.W"), m->P_("tok.linear2.b"), m->tokA, m->tok, m->part,
+                         m->P_("tok.linear1.b"), m->P_("tok.linear2.W"), m->P_("tok.linear2.b"), m->keep_internals ? m->tokA : nullptr, m->tokstat,
+                         m->tok, m->part,
                          n, P, s));
   STEP("bn_stats_finalize", vt_bn_stats_finalize(m->part, n, D, L, NL, m->P_("norm1.running_mean"), m->P_("norm1.running_var"), m->stat_n1, s));
   STEP("transformer_ffn_fwd", vt_transformer_ffn_fwd(m->tok, m->stat_n1, m->P_("norm1.gamma"), m->P_("norm1.beta"), m->P_("ffn.linear1.W"),
@@ -551,7 +563,8 @@ extern "C" int vt_model_forward(vt_model *m, const float *d_images, int n, float
   STEP("projector_tokens_fwd", vt_projector_tokens_fwd(m->s2, m->stat_n2, m->P_("norm2.gamma"), m->P_("norm2.beta"), m->P_("proj.linear1.W"),
                                 m->P_("proj.linear2.W"), m->P_("proj.linear3.W"), m->P_("proj.linear3.b"), m->o, m->pk, n, s));
   STEP("projector_fwd", vt_projector_fwd(m->conv, m->stat_bn, m->P_("bn.gamma"), m->P_("bn.beta"), m->pk, m->P_("proj.downsample.W"),
-                         m->P_("proj.downsample.b"), m->P_("proj.norm.running_mean"), m->projA, m->z, m->part, n, P, s));
+                         m->P_("proj.downsample.b"), m->P_("proj.norm.running_mean"),
+                         m->keep_internals ? m->projA : nullptr, m->z, m->part, n, P, s));
   STEP("bn_stats_finalize", vt_bn_stats_finalize(m->part, n, C2, P, (long)n * P, m->P_("proj.norm.running_mean"), m->P_("proj.norm.running_var"),
                              m->stat_pn, s));
   STEP("head_fwd", vt_head_fwd(m->z, m->stat_pn, m->P_("proj.norm.gamma"), m->P_("proj.norm.beta"), m->P_("fc.W"), m->P_("fc.b"),
@@ -597,8 +610,8 @@ extern "C" int vt_model_backward(vt_model *m, const int *d_labels, vt_stream s) 
   // the output projection's cached input is the zero concat: its gradient is exactly zero
   HIPCHK(hipMemsetAsync(m->G_("mha.o.W"), 0, sizeof(float) * D * D, hs));
   // tokenizer.backward2(projector token delta, projector input delta) + BatchNorm2D + conv
-  STEP("tokenizer_bwd", vt_tokenizer_bwd(m->conv, m->stat_bn, m->P_("bn.gamma"), m->P_("bn.beta"), m->tokA, m->dT0,
-                         m->P_("tok.linear1.W"), m->pdx, m->dy, m->part, n, P, s));
+  STEP("tokenizer_bwd", vt_tokenizer_bwd(m->conv, m->stat_bn, m->P_("bn.gamma"), m->P_("bn.beta"), m->tokstat, m->dT0,
+                         m->P_("tok.linear1.W"), m->P_("tok.linear1.b"), m->pdx, m->dy, m->part, n, P, s));
   STEP("bn_bwd_finalize", vt_bn_bwd_finalize(m->part, n, C1, (long)n * P, m->P_("bn.gamma"), m->stat_bn, m->conv, m->G_("bn.gamma"),
                            m->G_("bn.beta"), m->coef_bn, s));
   STEP("conv3x3_wgrad", vt_conv3x3_wgrad(m->last_images, m->dy, m->coef_bn, m->gslab, n, Ci, H, H, s));

@@ -319,6 +319,235 @@ __global__ __launch_bounds__(TPB) void k_proj_bwd(const float *__restrict__ du, 
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// FilterTokenizer::forward (reference layers/tokenizer.hpp:22-48) fused with the BatchNorm2D apply
+// and the NCHW->[N,P,C] transpose (model/vit_cnn.hpp:127-134).  One workgroup per image.
+//   S = x.W1 + b1;  A = softmax over the P pixels per token;  T0 = A^T.x;  t = T0.W2 + b2
+// S is produced in N layout (lane = token, registers = pixels), so the softmax over pixels reduces
+// inside the lane first and crosses lanes once per workgroup; all tiles of S stay in registers
+// between the three phases (maximum, sum, A^T.x).  A^T.x contracts over pixels with the N-layout
+// registers as the A operand and accumulates in one D tile per wave.
+// tok_stat[n] = (max_l[L], sum_l[L]) lets the backward pass rebuild A in a single sweep; tokA is
+// written only when non-null (debug / tests).
+// ---------------------------------------------------------------------------------------------
+constexpr int TK_MAXT = 13;  // tiles per wave: P <= 16 * NW * TK_MAXT = 832
+__global__ __launch_bounds__(TPB) void k_tokenizer_fwd(const float *__restrict__ conv, const float *__restrict__ st,
+                                                       const float *__restrict__ g, const float *__restrict__ b,
+                                                       const float *__restrict__ W1, const float *__restrict__ b1,
+                                                       const float *__restrict__ W2, const float *__restrict__ b2,
+                                                       float *__restrict__ tokA, float *__restrict__ tok_stat,
+                                                       float *__restrict__ tok, float *__restrict__ part_n1, int P) {
+  __shared__ float redm[NW][L], reds[NW][L];
+  __shared__ float sT[NW][256];
+  __shared__ float sT0[L * C1];
+  __shared__ float st_[L * D];
+  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, gq = lane >> 4;
+  const int ntiles = (P + 15) >> 4;
+  float bw[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) bw[s] = W1[(2 * gq + s) * L + j];  // B[channel 2g+s][token j]
+  const float bias = b1[j];
+  BnPair bn;
+  bn.init(st, g, b, gq);
+  float S[TK_MAXT][4];
+  float cm = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < TK_MAXT; ++i) {
+    const int t = wave + NW * i;
+    const int p = t * 16 + j;
+    float x0 = 0.f, x1 = 0.f;
+    if (t < ntiles && p < P) {
+      const float2 raw = *reinterpret_cast<const float2 *>(conv + ((size_t)n * P + p) * C1 + 2 * gq);
+      x0 = bn.apply(raw.x, 0);
+      x1 = bn.apply(raw.y, 1);
+    }
+    f4 sc = {bias, bias, bias, bias};
+    sc = mfma16(x0, bw[0], sc);
+    sc = mfma16(x1, bw[1], sc);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const bool valid = t < ntiles && t * 16 + 4 * gq + v < P;
+      S[i][v] = sc[v];
+      cm = valid ? fmaxf(cm, sc[v]) : cm;
+    }
+  }
+  cm = gmax(cm);
+  if (gq == 0) redm[wave][j] = cm;
+  __syncthreads();
+  cm = fmaxf(fmaxf(redm[0][j], redm[1][j]), fmaxf(redm[2][j], redm[3][j]));
+  float cs = 0.f;
+#pragma unroll
+  for (int i = 0; i < TK_MAXT; ++i) {
+    const int t = wave + NW * i;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const bool valid = t < ntiles && t * 16 + 4 * gq + v < P;
+      const float e = valid ? expf(S[i][v] - cm) : 0.f;
+      S[i][v] = e;
+      cs += e;
+    }
+  }
+  cs = gsum(cs);
+  if (gq == 0) reds[wave][j] = cs;
+  __syncthreads();
+  cs = (reds[0][j] + reds[1][j]) + (reds[2][j] + reds[3][j]);
+  if (tid < L) {
+    tok_stat[(size_t)n * 2 * L + tid] = cm;
+    tok_stat[(size_t)n * 2 * L + L + tid] = cs;
+  }
+  // T0[l][c] = sum_p A[p][l] * x[p][c]  (a^T . x, tokenizer.hpp:39-40): D[token][channel]
+  const int ch = j & (C1 - 1);
+  const float nmean = st[ch], ninv = st[C1 + ch], ngam = g[ch], nbet = b[ch];
+  f4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < TK_MAXT; ++i) {
+    const int t = wave + NW * i;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int pr = t * 16 + 4 * gq + v;
+      const bool valid = t < ntiles && pr < P;
+      const float av = S[i][v] / cs;
+      float xn = 0.f;
+      if (valid && j < C1) xn = ((conv[((size_t)n * P + pr) * C1 + j] - nmean) * ninv) * ngam + nbet;
+      acc = mfma16(av, xn, acc);
+      if (tokA != nullptr && valid) tokA[((size_t)n * P + pr) * L + j] = av;
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < 4; ++v) sT[wave][(4 * gq + v) * 16 + j] = acc[v];
+  __syncthreads();
+  {
+    const int l = tid >> 4, c = tid & 15;
+    if (c < C1) sT0[l * C1 + c] = (sT[0][tid] + sT[1][tid]) + (sT[2][tid] + sT[3][tid]);
+  }
+  __syncthreads();
+  // t = T0 . W2 + b2  (linear2, tokenizer.hpp:42-44)
+  for (int o = tid; o < L * D; o += TPB) {
+    const int l = o / D, d = o % D;
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < C1; ++c) s += sT0[l * C1 + c] * W2[c * D + d];
+    s += b2[d];
+    st_[o] = s;
+    tok[(size_t)n * L * D + o] = s;
+  }
+  __syncthreads();
+  if (tid < D && part_n1 != nullptr) {  // per-sample partial statistics for the transformer's norm1
+    float s = 0.f;
+#pragma unroll
+    for (int l = 0; l < L; ++l) s += st_[l * D + tid];
+    const float mu = s * (1.0f / L);
+    float q = 0.f;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      const float dlt = st_[l * D + tid] - mu;
+      q += dlt * dlt;
+    }
+    part_n1[(size_t)n * 2 * D + tid] = s;
+    part_n1[(size_t)n * 2 * D + D + tid] = q;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// FilterTokenizer::backward2 (reference layers/tokenizer.hpp:50-107).  Per pixel:
+//   dA[l] = dT0[l] . x;  dx = A . dT0;  dS = A * (dA - sum_l dA*A)   (softmax_backward reduces over
+//   the token axis although the forward softmax ran over pixels, tokenizer.hpp:36,91)
+//   dx += dS . W1^T;  dx += projector input delta                         (tokenizer.hpp:97,105)
+// The tokenizer's own Dense gradients are never applied by the reference (no optimizer is ever
+// attached to them, tokenizer.hpp:18-19) and are not computed.  Fused: partial sums of the
+// BatchNorm2D backward over the result (vit_cnn.hpp:236-238).
+// T layout throughout, 12 MFMAs per 16-pixel tile: S (2) and dA (2) share the x operand, dx chains
+// the two token contractions onto the projector's input delta loaded as the accumulator (8).
+// A is rebuilt from the per-sample (max, sum) the forward pass left in tok_stat.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void k_tokenizer_bwd(const float *__restrict__ conv, const float *__restrict__ st,
+                                                       const float *__restrict__ g, const float *__restrict__ b,
+                                                       const float *__restrict__ tok_stat, const float *__restrict__ dT0,
+                                                       const float *__restrict__ W1, const float *__restrict__ b1,
+                                                       const float *__restrict__ pdx, float *__restrict__ dy,
+                                                       float *__restrict__ part, int P) {
+  __shared__ float red[NW][2 * C1];
+  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, gq = lane >> 4;
+  const float *__restrict__ dt = dT0 + (size_t)n * L * C1;
+  const float *__restrict__ ts = tok_stat + (size_t)n * 2 * L;
+  float adt[2], aw1[2], a1[4], a2[4], cmv[4], csv[4], hm[4], hi[4];
+  f4 cS;
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    adt[s] = dt[j * C1 + 2 * gq + s];    // A[token j][channel 2g+s]
+    aw1[s] = W1[(2 * gq + s) * L + j];   // A[token j][channel 2g+s]
+  }
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    a1[v] = j < C1 ? dt[(4 * gq + v) * C1 + j] : 0.f;  // A[channel j][token 4g+v]
+    a2[v] = j < C1 ? W1[j * L + 4 * gq + v] : 0.f;     // A[channel j][token 4g+v]
+    cS[v] = b1[4 * gq + v];
+    cmv[v] = ts[4 * gq + v];
+    csv[v] = ts[L + 4 * gq + v];
+    const int c = (4 * gq + v) & (C1 - 1);
+    hm[v] = st[c];
+    hi[v] = st[C1 + c];
+  }
+  BnPair bn;
+  bn.init(st, g, b, gq);
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  const int ntiles = (P + 15) >> 4;
+  for (int t = wave; t < ntiles; t += NW) {
+    const int p = t * 16 + j;
+    const bool ok = p < P, lo = ok && gq < 2;
+    float x0 = 0.f, x1 = 0.f;
+    f4 dx = {0.f, 0.f, 0.f, 0.f}, raw4 = dx;
+    if (ok) {
+      const float2 raw = *reinterpret_cast<const float2 *>(conv + ((size_t)n * P + p) * C1 + 2 * gq);
+      x0 = bn.apply(raw.x, 0);
+      x1 = bn.apply(raw.y, 1);
+    }
+    if (lo) {
+      dx = *reinterpret_cast<const f4 *>(pdx + ((size_t)n * P + p) * C1 + 4 * gq);
+      raw4 = *reinterpret_cast<const f4 *>(conv + ((size_t)n * P + p) * C1 + 4 * gq);
+    }
+    f4 sc = cS, dA = {0.f, 0.f, 0.f, 0.f};
+    sc = mfma16(aw1[0], x0, sc);
+    sc = mfma16(aw1[1], x1, sc);
+    dA = mfma16(adt[0], x0, dA);
+    dA = mfma16(adt[1], x1, dA);
+    f4 A;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) A[v] = ok ? expf(sc[v] - cmv[v]) / csv[v] : 0.f;
+    const float dot = gsum((dA[0] * A[0] + dA[1] * A[1]) + (dA[2] * A[2] + dA[3] * A[3]));
+    f4 dS;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) dS[v] = A[v] * (dA[v] - dot);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) dx = mfma16(a1[v], A[v], dx);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) dx = mfma16(a2[v], dS[v], dx);
+    if (lo) {
+      *reinterpret_cast<f4 *>(dy + ((size_t)n * P + p) * C1 + 4 * gq) = dx;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        s1[v] += dx[v];
+        s2[v] += dx[v] * ((raw4[v] - hm[v]) * hi[v]);
+      }
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    s1[v] = jsum(s1[v]);
+    s2[v] = jsum(s2[v]);
+  }
+  if (j == 0 && gq < 2) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      red[wave][4 * gq + v] = s1[v];
+      red[wave][C1 + 4 * gq + v] = s2[v];
+    }
+  }
+  __syncthreads();
+  if (tid < 2 * C1) part[(size_t)n * 2 * C1 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+}
+
 }  // namespace vt
 
 using namespace vt;
@@ -341,6 +570,27 @@ extern "C" int vt_projector_bwd(const float *du, const float *pn_coef, const flo
   if (N < 1 || P < 1) return VT_EUNSUPPORTED;
   hipLaunchKernelGGL(k_proj_bwd, dim3(N), dim3(TPB), 0, (hipStream_t)s, du, pn_coef, conv_out, bn_stat, bn_gamma,
                      bn_beta, pk, wq, wd, pdx, dv, dk, gslab, P);
+  VT_CHECK_LAUNCH();
+  return 0;
+}
+
+
+extern "C" int vt_tokenizer_fwd(const float *conv_out, const float *bn_stat, const float *bn_gamma, const float *bn_beta,
+                                const float *w1, const float *b1, const float *w2, const float *b2, float *tok_A,
+                                float *tok_stat, float *tokens, float *part_n1, int N, int P, vt_stream s) {
+  if (N < 1 || P < 1 || P > 16 * NW * TK_MAXT || !tok_stat) return VT_EUNSUPPORTED;
+  hipLaunchKernelGGL(k_tokenizer_fwd, dim3(N), dim3(TPB), 0, (hipStream_t)s, conv_out, bn_stat, bn_gamma, bn_beta, w1,
+                     b1, w2, b2, tok_A, tok_stat, tokens, part_n1, P);
+  VT_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int vt_tokenizer_bwd(const float *conv_out, const float *bn_stat, const float *bn_gamma, const float *bn_beta,
+                                const float *tok_stat, const float *dT0, const float *w1, const float *b1,
+                                const float *pdx, float *dy, float *part, int N, int P, vt_stream s) {
+  if (N < 1 || P < 1) return VT_EUNSUPPORTED;
+  hipLaunchKernelGGL(k_tokenizer_bwd, dim3(N), dim3(TPB), 0, (hipStream_t)s, conv_out, bn_stat, bn_gamma, bn_beta,
+                     tok_stat, dT0, w1, b1, pdx, dy, part, P);
   VT_CHECK_LAUNCH();
   return 0;
 }

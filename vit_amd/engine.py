@@ -99,6 +99,10 @@ class VTCNN:
         self.training = bool(is_training)
         check(lib.vt_model_set_training(self._h, int(self.training)))
 
+    def keep_internals(self, on=True):
+        """Test aid: also store the attention maps "fwd.tok_A" / "fwd.proj_a" for read()."""
+        check(lib.vt_model_keep_internals(self._h, int(bool(on))))
+
     def forward(self, x):
         """VTCNN::forward: x [N,Ci,H,W] float32 CUDA tensor -> softmax probabilities [N,K]."""
         assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
