@@ -364,64 +364,6 @@ __global__ __launch_bounds__(TPB) void k_tr_bwd_c(const float *__restrict__ da, 
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// BatchNorm2D backward apply + Conv2DLayer::backward gradients (reference
-// layers/conv2d_layer.hpp:115-147): gb[co] = sum delta, gW[co][ci][kh][kw] = sum xpad * delta.
-// The conv input delta (:150-190) is never consumed (first layer) and is not computed.
-// One workgroup per image and input channel pass; per-image partials [C1*Ci*9 | C1].
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(TPB) void k_conv_wgrad(const float *__restrict__ X, const float *__restrict__ dy,
-                                                    const float *__restrict__ coef, float *__restrict__ gslab, int Ci,
-                                                    int H, int W, int ld) {
-  extern __shared__ float sm[];
-  const int P = H * W, TH = H + 2, TW = W + 2;
-  const int tile_n = Ci * TH * TW;
-  float *tile = sm;
-  float *red = sm + ((tile_n + 3) & ~3);  // NW*128
-  float *sout = red + NW * 128;           // 128
-  const int n = blockIdx.x, tid = threadIdx.x;
-  for (int i = tid; i < tile_n; i += TPB) {
-    const int ci = i / (TH * TW), r = i % (TH * TW), hh = r / TW - 1, ww = r % TW - 1;
-    float v = 0.f;
-    if (hh >= 0 && hh < H && ww >= 0 && ww < W) v = X[((size_t)(n * Ci + ci) * H + hh) * W + ww];
-    tile[i] = v;
-  }
-  __syncthreads();
-  float *row = gslab + (size_t)n * ld;
-  for (int ci = 0; ci < Ci; ++ci) {
-    float acc[128];
-#pragma unroll
-    for (int k = 0; k < 128; ++k) acc[k] = 0.f;
-    for (int p = tid; p < P; p += TPB) {
-      const int h = p / W, w = p % W;
-      const float4 *ds = reinterpret_cast<const float4 *>(dy + ((size_t)n * P + p) * C1);
-      const float4 d0 = ds[0], d1 = ds[1];
-      const float draw[C1] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
-      float dcv[C1];
-#pragma unroll
-      for (int co = 0; co < C1; ++co) {
-        dcv[co] = draw[co] * coef[co] + coef[C1 + co];
-        acc[72 + co] += dcv[co];
-      }
-#pragma unroll
-      for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-          const float xv = tile[(ci * TH + h + kh) * TW + w + kw];
-#pragma unroll
-          for (int co = 0; co < C1; ++co) acc[co * 9 + kh * 3 + kw] += xv * dcv[co];
-        }
-    }
-    block_xreduce<128>(acc, red, sout);
-    if (tid < 72) {
-      const int co = tid / 9, k = tid % 9;
-      row[(co * Ci + ci) * 9 + k] = sout[tid];
-    }
-    if (ci == 0 && tid < C1) row[C1 * Ci * 9 + tid] = sout[72 + tid];
-    __syncthreads();
-  }
-}
-
 // update_weights + SGD::update (reference e.g. layers/dense_layer.hpp:102-112,
 // utils/optimizer.hpp:22-28):  g <- g * (1/divisor);  w <- w - g * lr.  Two roundings, as there.
 __global__ __launch_bounds__(TPB) void k_sgd(float *__restrict__ w, float *__restrict__ gr, int n, float lr,
@@ -585,17 +527,6 @@ extern "C" int vt_transformer_bwd_c(const float *da, const float *n1_coef, const
   if (rows < 1) return VT_EINVAL;
   const int nb = (int)((rows + RB - 1) / RB);
   hipLaunchKernelGGL(k_tr_bwd_c, dim3(nb), dim3(TPB), 0, (hipStream_t)s, da, n1_coef, wo, tok, wqkv, dr, dc, qkv, rows);
-  VT_CHECK_LAUNCH();
-  return 0;
-}
-
-extern "C" int vt_conv3x3_wgrad(const float *x, const float *dy, const float *bn_coef, float *gslab, int N, int Ci,
-                                int H, int W, vt_stream s) {
-  if (N < 1 || Ci < 1 || H * W > PPT * TPB) return VT_EUNSUPPORTED;
-  const int ld = C1 * Ci * 9 + C1;
-  const size_t lds = (size_t)(((Ci * (H + 2) * (W + 2) + 3) & ~3) + NW * 128 + 128) * sizeof(float);
-  if (lds > 64 * 1024) return VT_EUNSUPPORTED;
-  hipLaunchKernelGGL(k_conv_wgrad, dim3(N), dim3(TPB), lds, (hipStream_t)s, x, dy, bn_coef, gslab, Ci, H, W, ld);
   VT_CHECK_LAUNCH();
   return 0;
 }

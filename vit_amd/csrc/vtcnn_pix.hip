@@ -548,6 +548,83 @@ __global__ __launch_bounds__(TPB) void k_tokenizer_bwd(const float *__restrict__
   if (tid < 2 * C1) part[(size_t)n * 2 * C1 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// BatchNorm2D backward apply + Conv2DLayer::backward gradients (reference
+// layers/conv2d_layer.hpp:115-147): gb[co] = sum delta, gW[co][ci][kh][kw] = sum xpad * delta.
+// The conv input delta (:150-190) is never consumed (first layer) and is not computed.
+// A contraction over pixels: D[tap][co] += A[tap][pixel] . B[pixel][co], with the shifted image
+// value as the A operand (lane = tap; lane 9 carries ones and yields the bias gradient) and the
+// delta in N layout as the B operand; 4 MFMAs per 16 pixels and input channel.  The image is read
+// straight from global memory (3 KB per channel and sample: it lives in L1).
+// Per-image partials [C1*Ci*9 | C1].
+// ---------------------------------------------------------------------------------------------
+constexpr int CW_MAXCI = 4;
+__global__ __launch_bounds__(TPB) void k_conv_wgrad(const float *__restrict__ X, const float *__restrict__ dy,
+                                                    const float *__restrict__ coef, float *__restrict__ gslab, int Ci,
+                                                    int H, int W, int ld) {
+  __shared__ float sred[NW][CW_MAXCI][256];
+  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, gq = lane >> 4;
+  const int P = H * W, ntiles = (P + 15) >> 4;
+  const int kh = j / 3 - 1, kw = j % 3 - 1;  // tap offsets of lanes j < 9
+  const float c0 = j < C1 ? coef[j] : 0.f, c1 = j < C1 ? coef[C1 + j] : 0.f;
+  const float invW = 1.0f / (float)W;
+  f4 acc[CW_MAXCI];
+#pragma unroll
+  for (int ci = 0; ci < CW_MAXCI; ++ci) acc[ci] = f4{0.f, 0.f, 0.f, 0.f};
+  for (int t = wave; t < ntiles; t += NW) {
+    float dv[4];
+    int hh[4], ww[4];
+    bool inb[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int pr = t * 16 + 4 * gq + v;
+      const bool valid = pr < P;
+      int h = (int)(((float)pr + 0.5f) * invW);
+      h -= (h * W > pr) ? 1 : 0;
+      h += ((h + 1) * W <= pr) ? 1 : 0;
+      const int w = pr - h * W;
+      hh[v] = h + kh;
+      ww[v] = w + kw;
+      inb[v] = valid && j < 9 && hh[v] >= 0 && hh[v] < H && ww[v] >= 0 && ww[v] < W;
+      dv[v] = (valid && j < C1) ? dy[((size_t)n * P + pr) * C1 + j] * c0 + c1 : 0.f;
+    }
+#pragma unroll
+    for (int ci = 0; ci < CW_MAXCI; ++ci) {
+      if (ci < Ci) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          float xv = inb[v] ? X[((size_t)(n * Ci + ci) * H + hh[v]) * W + ww[v]] : 0.f;
+          if (j == 9) xv = 1.f;  // invalid pixels have a zero delta, so the ones row needs no mask
+          acc[ci] = mfma16(xv, dv[v], acc[ci]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int ci = 0; ci < CW_MAXCI; ++ci)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) sred[wave][ci][(4 * gq + v) * 16 + j] = acc[ci][v];
+  __syncthreads();
+  float *row = gslab + (size_t)n * ld;
+  for (int o = tid; o < Ci * 9 * C1 + C1; o += TPB) {
+    int ci, tap, co;
+    if (o < Ci * 9 * C1) {
+      co = o / (Ci * 9);
+      ci = (o / 9) % Ci;
+      tap = o % 9;
+    } else {
+      co = o - Ci * 9 * C1;
+      ci = 0;
+      tap = 9;
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) s += sred[w][ci][tap * 16 + co];
+    row[o] = s;
+  }
+}
+
 }  // namespace vt
 
 using namespace vt;
@@ -591,6 +668,16 @@ extern "C" int vt_tokenizer_bwd(const float *conv_out, const float *bn_stat, con
   if (N < 1 || P < 1) return VT_EUNSUPPORTED;
   hipLaunchKernelGGL(k_tokenizer_bwd, dim3(N), dim3(TPB), 0, (hipStream_t)s, conv_out, bn_stat, bn_gamma, bn_beta,
                      tok_stat, dT0, w1, b1, pdx, dy, part, P);
+  VT_CHECK_LAUNCH();
+  return 0;
+}
+
+
+extern "C" int vt_conv3x3_wgrad(const float *x, const float *dy, const float *bn_coef, float *gslab, int N, int Ci,
+                                int H, int W, vt_stream s) {
+  if (N < 1 || Ci < 1 || Ci > CW_MAXCI || H < 1 || W < 1) return VT_EUNSUPPORTED;
+  const int ld = C1 * Ci * 9 + C1;
+  hipLaunchKernelGGL(k_conv_wgrad, dim3(N), dim3(TPB), 0, (hipStream_t)s, x, dy, bn_coef, gslab, Ci, H, W, ld);
   VT_CHECK_LAUNCH();
   return 0;
 }
