@@ -23,6 +23,7 @@
 namespace vt {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
+constexpr int PF = 3;  // tiles of load look-ahead per wave in the streaming pixel kernels
 
 __device__ __forceinline__ f4 mfma16(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
@@ -101,25 +102,38 @@ __global__ __launch_bounds__(TPB) void k_proj_fwd(const float *__restrict__ conv
   bn.init(st, g, b, gq);
   float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
   const int ntiles = (P + 15) >> 4;
-  for (int t = wave; t < ntiles; t += NW) {
+  // The wave's tiles are independent; with only four waves per SIMD resident the HBM latency of a
+  // tile's load would be paid once per tile, so the loads run PF tiles ahead of the arithmetic.
+  const float *__restrict__ xin = conv + (size_t)n * P * C1 + 2 * gq;
+  float2 ring[PF];
+#pragma unroll
+  for (int u = 0; u < PF; ++u) {
+    const int p = (wave + NW * u) * 16 + j;
+    ring[u] = p < P ? *reinterpret_cast<const float2 *>(xin + (size_t)p * C1) : make_float2(0.f, 0.f);
+  }
+  for (int t0 = wave; t0 < ntiles; t0 += NW * PF) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+    const int t = t0 + NW * u;
+    if (t >= ntiles) break;
     const int p = t * 16 + j;
     const bool ok = p < P;
-    float x0 = 0.f, x1 = 0.f;
-    if (ok) {
-      const float2 raw = *reinterpret_cast<const float2 *>(conv + ((size_t)n * P + p) * C1 + 2 * gq);
-      x0 = bn.apply(raw.x, 0);
-      x1 = bn.apply(raw.y, 1);
+    const float2 raw = ring[u];
+    {
+      const int pn = p + NW * PF * 16;
+      ring[u] = pn < P ? *reinterpret_cast<const float2 *>(xin + (size_t)pn * C1) : make_float2(0.f, 0.f);
     }
+    const float x0 = ok ? bn.apply(raw.x, 0) : 0.f, x1 = ok ? bn.apply(raw.y, 1) : 0.f;
     f4 sc = {0.f, 0.f, 0.f, 0.f};
     sc = mfma16(amq[0], x0, sc);
     sc = mfma16(amq[1], x1, sc);
     const float mx = gmax(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])));
     f4 a;
 #pragma unroll
-    for (int v = 0; v < 4; ++v) a[v] = expf(sc[v] - mx);
-    const float sum = gsum((a[0] + a[1]) + (a[2] + a[3]));
+    for (int v = 0; v < 4; ++v) a[v] = __expf(sc[v] - mx);
+    const float rsum = __builtin_amdgcn_rcpf(gsum((a[0] + a[1]) + (a[2] + a[3])));
 #pragma unroll
-    for (int v = 0; v < 4; ++v) a[v] = a[v] / sum;
+    for (int v = 0; v < 4; ++v) a[v] = a[v] * rsum;
     f4 zc = cinit;
     zc = mfma16(awd[0], x0, zc);
     zc = mfma16(awd[1], x1, zc);
@@ -134,6 +148,7 @@ __global__ __launch_bounds__(TPB) void k_proj_fwd(const float *__restrict__ conv
         s1[v] += dlt;
         s2[v] += dlt * dlt;
       }
+    }
     }
   }
   if (part_pn == nullptr) return;
@@ -235,10 +250,10 @@ __global__ __launch_bounds__(TPB) void k_proj_bwd(const float *__restrict__ du, 
     const float mx = gmax(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])));
     f4 a;
 #pragma unroll
-    for (int v = 0; v < 4; ++v) a[v] = expf(sc[v] - mx);
-    const float sum = gsum((a[0] + a[1]) + (a[2] + a[3]));
+    for (int v = 0; v < 4; ++v) a[v] = __expf(sc[v] - mx);
+    const float rsum = __builtin_amdgcn_rcpf(gsum((a[0] + a[1]) + (a[2] + a[3])));
 #pragma unroll
-    for (int v = 0; v < 4; ++v) a[v] = a[v] / sum;
+    for (int v = 0; v < 4; ++v) a[v] = a[v] * rsum;
     f4 da = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int v = 0; v < 4; ++v) da = mfma16(av[v], dz[v], da);
@@ -383,7 +398,7 @@ __global__ __launch_bounds__(TPB) void k_tokenizer_fwd(const float *__restrict__
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
       const bool valid = t < ntiles && t * 16 + 4 * gq + v < P;
-      const float e = valid ? expf(S[i][v] - cm) : 0.f;
+      const float e = valid ? __expf(S[i][v] - cm) : 0.f;
       S[i][v] = e;
       cs += e;
     }
@@ -397,6 +412,7 @@ __global__ __launch_bounds__(TPB) void k_tokenizer_fwd(const float *__restrict__
     tok_stat[(size_t)n * 2 * L + L + tid] = cs;
   }
   // T0[l][c] = sum_p A[p][l] * x[p][c]  (a^T . x, tokenizer.hpp:39-40): D[token][channel]
+  const float rcs = 1.0f / cs;
   const int ch = j & (C1 - 1);
   const float nmean = st[ch], ninv = st[C1 + ch], ngam = g[ch], nbet = b[ch];
   f4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -407,7 +423,7 @@ __global__ __launch_bounds__(TPB) void k_tokenizer_fwd(const float *__restrict__
     for (int v = 0; v < 4; ++v) {
       const int pr = t * 16 + 4 * gq + v;
       const bool valid = t < ntiles && pr < P;
-      const float av = S[i][v] / cs;
+      const float av = S[i][v] * rcs;
       float xn = 0.f;
       if (valid && j < C1) xn = ((conv[((size_t)n * P + pr) * C1 + j] - nmean) * ninv) * ngam + nbet;
       acc = mfma16(av, xn, acc);
@@ -484,7 +500,7 @@ __global__ __launch_bounds__(TPB) void k_tokenizer_bwd(const float *__restrict__
     a2[v] = j < C1 ? W1[j * L + 4 * gq + v] : 0.f;     // A[channel j][token 4g+v]
     cS[v] = b1[4 * gq + v];
     cmv[v] = ts[4 * gq + v];
-    csv[v] = ts[L + 4 * gq + v];
+    csv[v] = 1.0f / ts[L + 4 * gq + v];
     const int c = (4 * gq + v) & (C1 - 1);
     hm[v] = st[c];
     hi[v] = st[C1 + c];
@@ -514,7 +530,7 @@ __global__ __launch_bounds__(TPB) void k_tokenizer_bwd(const float *__restrict__
     dA = mfma16(adt[1], x1, dA);
     f4 A;
 #pragma unroll
-    for (int v = 0; v < 4; ++v) A[v] = ok ? expf(sc[v] - cmv[v]) / csv[v] : 0.f;
+    for (int v = 0; v < 4; ++v) A[v] = ok ? __expf(sc[v] - cmv[v]) * csv[v] : 0.f;
     const float dot = gsum((dA[0] * A[0] + dA[1] * A[1]) + (dA[2] * A[2] + dA[3] * A[3]));
     f4 dS;
 #pragma unroll
