@@ -23,9 +23,29 @@
 namespace vt {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
-constexpr int PF = 3;  // tiles of load look-ahead per wave in the streaming pixel kernels
+constexpr int TK_MAXT = 13;  // tiles per wave: P <= 16 * NW * TK_MAXT = 832
 
 __device__ __forceinline__ f4 mfma16(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+// Forces a value loaded in a kernel's prologue to have arrived (the compiler places the wait for
+// its load here).  Without it the wait lands at the first use inside the tile loop, behind that
+// tile's stores, and since stores share the loads' counter the wave would then sit out the
+// acknowledgement of its own stores once per tile.
+template <class T>
+__device__ __forceinline__ void settle(T &x) { asm volatile("" : "+v"(x)); }
+template <class T, int N>
+__device__ __forceinline__ void settle(T (&x)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) asm volatile("" : "+v"(x[i]));
+}
+__device__ __forceinline__ void settle(f4 &x) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float t = x[i];
+    asm volatile("" : "+v"(t));
+    x[i] = t;
+  }
+}
 
 // sum / max over the four lane groups g (lanes j, j+16, j+32, j+48)
 __device__ __forceinline__ float gsum(float x) {
@@ -60,6 +80,12 @@ struct BnPair {
       gam[s] = g[ch];
       bet[s] = b[ch];
     }
+  }
+  __device__ __forceinline__ void settle_all() {
+    settle(mean);
+    settle(inv);
+    settle(gam);
+    settle(bet);
   }
   __device__ __forceinline__ float apply(float raw, int s) const { return ((raw - mean[s]) * inv[s]) * gam[s] + bet[s]; }
 };
@@ -102,27 +128,32 @@ __global__ __launch_bounds__(TPB) void k_proj_fwd(const float *__restrict__ conv
   bn.init(st, g, b, gq);
   float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
   const int ntiles = (P + 15) >> 4;
-  // The wave's tiles are independent; with only four waves per SIMD resident the HBM latency of a
-  // tile's load would be paid once per tile, so the loads run PF tiles ahead of the arithmetic.
+  // The wave's tiles are independent, and with only four waves per SIMD resident the HBM latency
+  // of a tile's load would be paid once per tile: all loads of the wave are issued up front
+  // (unconditional, clamped addresses; 2 registers per tile), the arithmetic then drains them.
   const float *__restrict__ xin = conv + (size_t)n * P * C1 + 2 * gq;
-  float2 ring[PF];
+  float2 raws[TK_MAXT];
 #pragma unroll
-  for (int u = 0; u < PF; ++u) {
-    const int p = (wave + NW * u) * 16 + j;
-    ring[u] = p < P ? *reinterpret_cast<const float2 *>(xin + (size_t)p * C1) : make_float2(0.f, 0.f);
+  for (int i = 0; i < TK_MAXT; ++i)
+    raws[i] = *reinterpret_cast<const float2 *>(xin + (size_t)min((wave + NW * i) * 16 + j, P - 1) * C1);
+  settle(amq);
+  settle(awd);
+  settle(av);
+  settle(pv);
+  settle(cinit);
+  bn.settle_all();
+#pragma unroll
+  for (int i = 0; i < TK_MAXT; ++i) {
+    settle(raws[i].x);
+    settle(raws[i].y);
   }
-  for (int t0 = wave; t0 < ntiles; t0 += NW * PF) {
 #pragma unroll
-    for (int u = 0; u < PF; ++u) {
-    const int t = t0 + NW * u;
+  for (int i = 0; i < TK_MAXT; ++i) {
+    const int t = wave + NW * i;
     if (t >= ntiles) break;
     const int p = t * 16 + j;
     const bool ok = p < P;
-    const float2 raw = ring[u];
-    {
-      const int pn = p + NW * PF * 16;
-      ring[u] = pn < P ? *reinterpret_cast<const float2 *>(xin + (size_t)pn * C1) : make_float2(0.f, 0.f);
-    }
+    const float2 raw = raws[i];
     const float x0 = ok ? bn.apply(raw.x, 0) : 0.f, x1 = ok ? bn.apply(raw.y, 1) : 0.f;
     f4 sc = {0.f, 0.f, 0.f, 0.f};
     sc = mfma16(amq[0], x0, sc);
@@ -148,7 +179,6 @@ __global__ __launch_bounds__(TPB) void k_proj_fwd(const float *__restrict__ conv
         s1[v] += dlt;
         s2[v] += dlt * dlt;
       }
-    }
     }
   }
   if (part_pn == nullptr) return;
@@ -346,7 +376,6 @@ __global__ __launch_bounds__(TPB) void k_proj_bwd(const float *__restrict__ du, 
 // tok_stat[n] = (max_l[L], sum_l[L]) lets the backward pass rebuild A in a single sweep; tokA is
 // written only when non-null (debug / tests).
 // ---------------------------------------------------------------------------------------------
-constexpr int TK_MAXT = 13;  // tiles per wave: P <= 16 * NW * TK_MAXT = 832
 __global__ __launch_bounds__(TPB) void k_tokenizer_fwd(const float *__restrict__ conv, const float *__restrict__ st,
                                                        const float *__restrict__ g, const float *__restrict__ b,
                                                        const float *__restrict__ W1, const float *__restrict__ b1,
@@ -648,7 +677,7 @@ using namespace vt;
 extern "C" int vt_projector_fwd(const float *conv_out, const float *bn_stat, const float *bn_gamma, const float *bn_beta,
                                 const float *pk, const float *wd, const float *bd, const float *pivot, float *proj_a,
                                 float *z, float *part_pn, int N, int P, vt_stream s) {
-  if (N < 1 || P < 1 || !pivot) return VT_EUNSUPPORTED;
+  if (N < 1 || P < 1 || P > 16 * NW * TK_MAXT || !pivot) return VT_EUNSUPPORTED;
   hipLaunchKernelGGL(k_proj_fwd, dim3(N), dim3(TPB), 0, (hipStream_t)s, conv_out, bn_stat, bn_gamma, bn_beta, pk, wd,
                      bd, pivot, proj_a, z, part_pn, P);
   VT_CHECK_LAUNCH();
