@@ -67,6 +67,40 @@ __global__ __launch_bounds__(1024) void k_reduce_rows(const float *__restrict__ 
   }
 }
 
+// The same reduction for up to MAX_REDUCE_JOBS slabs in one launch: workgroup b serves the job
+// whose [first_block, next first_block) range contains b.
+__global__ __launch_bounds__(1024) void k_reduce_multi(const ReduceBatch batch) {
+  __shared__ float sh[16][65];
+  int ji = 0;
+#pragma unroll 1
+  for (int k = 1; k < batch.n; ++k)
+    if ((int)blockIdx.x >= batch.job[k].first_block) ji = k;
+  const float *__restrict__ slab = batch.job[ji].slab;
+  const long rows = batch.job[ji].rows;
+  const int cols = batch.job[ji].cols, ld = batch.job[ji].ld;
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = ((int)blockIdx.x - batch.job[ji].first_block) * 64 + cl;
+  float s = 0.f;
+  if (c < cols) {
+    long r = rl;
+    for (; r + 7 * 16 < rows; r += 8 * 16) {  // 8 independent loads in flight
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = slab[(r + 16 * k) * ld + c];
+      s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    }
+    for (; r < rows; r += 16) s += slab[r * ld + c];
+  }
+  sh[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0 && c < cols) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += sh[k][cl];
+    batch.job[ji].out[c] = t;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // BatchNorm backward reduction step (reference layers/batch_normalization_layer.hpp:187-199 and
 // 316-326).  From S1 = sum delta, S2 = sum delta*xhat per channel:
@@ -448,7 +482,29 @@ __global__ __launch_bounds__(TPB) void k_dense_bwd_rows(const float *__restrict_
 // ---------------------------------------------------------------------------------------------
 using namespace vt;
 
-static int reduce_rows(const float *slab, long rows, int cols, int ld, float *out, hipStream_t s) {
+static thread_local ReduceBatch *g_reduce_batch = nullptr;
+
+void vt::reduce_batch_begin(ReduceBatch *b) {
+  b->n = 0;
+  b->blocks = 0;
+  g_reduce_batch = b;
+}
+void vt::reduce_batch_abandon() { g_reduce_batch = nullptr; }
+int vt::reduce_batch_flush(hipStream_t s) {
+  ReduceBatch *b = g_reduce_batch;
+  g_reduce_batch = nullptr;
+  if (!b || b->n == 0) return 0;
+  hipLaunchKernelGGL(k_reduce_multi, dim3(b->blocks), dim3(1024), 0, s, *b);
+  VT_CHECK_LAUNCH();
+  return 0;
+}
+int vt::reduce_rows(const float *slab, long rows, int cols, int ld, float *out, hipStream_t s) {
+  ReduceBatch *b = g_reduce_batch;
+  if (b && b->n < MAX_REDUCE_JOBS) {
+    b->job[b->n++] = ReduceJob{slab, out, rows, cols, ld, b->blocks};
+    b->blocks += (cols + 63) / 64;
+    return 0;
+  }
   hipLaunchKernelGGL(k_reduce_rows, dim3((cols + 63) / 64), dim3(1024), 0, s, slab, rows, cols, ld, out);
   VT_CHECK_LAUNCH();
   return 0;

@@ -128,6 +128,26 @@ __device__ __forceinline__ void load_x(const float *__restrict__ conv, size_t re
 }
 
 
+// Column reductions of partial-gradient slabs (out[c] = sum_r slab[r][c]).  A launcher that needs
+// one calls reduce_rows(); while a ReduceBatch is open on the calling host thread the request is
+// only queued, and reduce_batch_flush() then performs every queued reduction in ONE launch.  The
+// model opens a batch around its backward pass: nine 5-microsecond launches become one.
+struct ReduceJob {
+  const float *slab;
+  float *out;
+  long rows;
+  int cols, ld, first_block;
+};
+constexpr int MAX_REDUCE_JOBS = 16;
+struct ReduceBatch {
+  ReduceJob job[MAX_REDUCE_JOBS];
+  int n = 0, blocks = 0;
+};
+int reduce_rows(const float *slab, long rows, int cols, int ld, float *out, hipStream_t s);
+void reduce_batch_begin(ReduceBatch *b);         // b must outlive the matching flush / abandon
+int reduce_batch_flush(hipStream_t s);           // launches the queued jobs and closes the batch
+void reduce_batch_abandon();                     // closes the batch without launching
+
 }  // namespace vt
 
 #define VT_CHECK_LAUNCH()                      \

@@ -241,8 +241,6 @@ __global__ __launch_bounds__(TPB) void k_mha_wgrad(const float *__restrict__ yz,
 
 using namespace vt;
 
-extern "C" int vt_reduce_rows(const float *slab, long rows, int cols, int ld, float *out, vt_stream s);
-
 // How many j ranges each row tile is split into so that the launch has ~2 waves per SIMD.
 static int mha_splits(int N, int groups) {
   const int itiles = (N + 31) / 32;
@@ -281,8 +279,8 @@ extern "C" int vt_mha_bwd_wgrad(const float *qkv, const float *dc, const float *
                      ns);
   VT_CHECK_LAUNCH();
   for (int h = 0; h < HEADS; ++h) {
-    const int rc = vt_reduce_rows(slab + (size_t)h * nrb * MH_STRIDE, nrb, MH_STRIDE, MH_STRIDE,
-                                  g_qkv + (size_t)h * MH_STRIDE, s);
+    const int rc = reduce_rows(slab + (size_t)h * nrb * MH_STRIDE, nrb, MH_STRIDE, MH_STRIDE,
+                               g_qkv + (size_t)h * MH_STRIDE, (hipStream_t)s);
     if (rc) return rc;
   }
   return 0;

@@ -43,7 +43,8 @@ struct vt_model {
   float *part, *stat_bn, *stat_n1, *stat_n2, *stat_pn;
   const float *last_images = nullptr;
   // backward workspace
-  float *dlogits, *du, *pdx, *pdt, *dv, *dk, *d0, *ds2, *dh, *da, *dr, *dc, *dT0, *dy, *qkv, *gslab, *rowscratch;
+  float *dlogits, *du, *pdx, *pdt, *dv, *dk, *d0, *ds2, *dh, *da, *dr, *dc, *dT0, *dy, *qkv, *gslab, *gslab_conv;
+  float *sc_fc, *sc_pt, *sc_ffn, *sc_mha;  // partial-gradient slabs, one per launcher: they stay live until the fused reduction
   float *coef_pn, *coef_n2, *coef_n1, *coef_bn;
   float *loss_buf;
   // optional per-launcher timing with HIP events on the caller's stream
@@ -136,13 +137,13 @@ extern "C" int vt_model_create(const vt_dims *dims, int max_batch, int device, f
   rc |= dalloc(m, &m->dT0, NL * C1, "bwd.tok_dT0");
   rc |= dalloc(m, &m->dy, N * P * C1, "bwd.tok_dx");
   rc |= dalloc(m, &m->qkv, 3 * NL * D, "bwd.mha_qkv");
-  rc |= dalloc(m, &m->gslab, N * 512, "bwd.gslab");
-  {
-    // largest partial slab any backward launcher needs (see the scratch notes in vtcnn_hip.h)
-    const size_t need_ffn = nrb * 2112, need_fc = ((N + 31) / 32) * (Q * K + K);
-    const size_t need_mha = (size_t)HEADS * 4 * (2 * D + 2) * NL + (size_t)HEADS * nrb * 1536;
-    rc |= dalloc(m, &m->rowscratch, std::max(need_ffn, std::max(need_fc, need_mha)));
-  }
+  rc |= dalloc(m, &m->gslab, N * 400, "bwd.gslab");
+  rc |= dalloc(m, &m->gslab_conv, N * (C1 * 9 * dims->image_channels + C1));
+  // partial slabs of the row-matrix launchers (sizes: see the scratch notes in vtcnn_hip.h)
+  rc |= dalloc(m, &m->sc_ffn, nrb * 2112);
+  rc |= dalloc(m, &m->sc_pt, nrb * 1552);
+  rc |= dalloc(m, &m->sc_fc, ((N + 31) / 32) * (Q * K + K));
+  rc |= dalloc(m, &m->sc_mha, (size_t)HEADS * 4 * (2 * D + 2) * NL + (size_t)HEADS * nrb * 1536);
   rc |= dalloc(m, &m->coef_pn, 2 * C2, "coef.proj.norm");
   rc |= dalloc(m, &m->coef_n2, 2 * D, "coef.norm2");
   rc |= dalloc(m, &m->coef_n1, 2 * D, "coef.norm1");
@@ -583,30 +584,36 @@ extern "C" int vt_model_backward(vt_model *m, const int *d_labels, vt_stream s) 
   const long NL = (long)n * L;
   const int nrb = (int)((NL + RB - 1) / RB);
   hipStream_t hs = (hipStream_t)s;
+  // every weight-gradient slab reduction requested below is queued and runs as one launch at the end
+  struct BatchScope {
+    ReduceBatch b;
+    BatchScope() { reduce_batch_begin(&b); }
+    ~BatchScope() { reduce_batch_abandon(); }
+  } batch;
   // head: softmax/fc/pool/relu backward + projector BatchNorm1D backward sums
   STEP("head_bwd", vt_head_bwd(m->probs, d_labels, m->P_("fc.W"), m->pool_idx, m->z, m->stat_pn, m->P_("proj.norm.gamma"),
                     m->P_("proj.norm.beta"), m->dlogits, m->du, m->part, n, H, K, s));
   STEP("bn_bwd_finalize", vt_bn_bwd_finalize(m->part, n, C2, (long)n * P, m->P_("proj.norm.gamma"), m->stat_pn, m->z,
                            m->G_("proj.norm.gamma"), m->G_("proj.norm.beta"), m->coef_pn, s));
-  STEP("fc_wgrad", vt_fc_wgrad(m->pooled, m->dlogits, m->G_("fc.W"), m->G_("fc.b"), m->rowscratch, n, Q, K, s));
+  STEP("fc_wgrad", vt_fc_wgrad(m->pooled, m->dlogits, m->G_("fc.W"), m->G_("fc.b"), m->sc_fc, n, Q, K, s));
   // projector
   STEP("projector_bwd", vt_projector_bwd(m->du, m->coef_pn, m->conv, m->stat_bn, m->P_("bn.gamma"), m->P_("bn.beta"), m->pk,
                          m->P_("proj.linear1.W"), m->P_("proj.downsample.W"), m->pdx, m->dv, m->dk, m->gslab, n, P, s));
-  STEP("reduce_rows", vt_reduce_rows(m->gslab, n, C1 * D, 400, m->G_("proj.linear1.W"), s));
-  STEP("reduce_rows", vt_reduce_rows(m->gslab + C1 * D, n, C1 * C2 + C2, 400, m->G_("proj.downsample.W"), s));
+  VTCHK(vt_reduce_rows(m->gslab, n, C1 * D, 400, m->G_("proj.linear1.W"), s));  // queued
+  VTCHK(vt_reduce_rows(m->gslab + C1 * D, n, C1 * C2 + C2, 400, m->G_("proj.downsample.W"), s));
   STEP("projector_tokens_bwd", vt_projector_tokens_bwd(m->o, m->dv, m->dk, m->P_("proj.linear3.W"), m->P_("proj.linear2.W"), m->pdt,
-                                m->G_("proj.linear2.W"), m->rowscratch, NL, s));
+                                m->G_("proj.linear2.W"), m->sc_pt, NL, s));
   // transformer (targets = projector token delta, same bytes: visual_transformer.hpp:153-157)
   STEP("transformer_bwd_a", vt_transformer_bwd_a(m->o, m->pdt, m->s2, m->stat_n2, m->P_("tok.linear2.W"), m->part, m->dT0, NL, s));
   STEP("bn_bwd_finalize", vt_bn_bwd_finalize(m->part, nrb, D, NL, m->P_("norm2.gamma"), m->stat_n2, m->s2, m->G_("norm2.gamma"),
                            m->G_("norm2.beta"), m->coef_n2, s));
   STEP("transformer_bwd_b", vt_transformer_bwd_b(m->o, m->pdt, m->coef_n2, m->hdn, m->a, m->tok, m->stat_n1, m->P_("ffn.linear1.W"),
-                             m->P_("ffn.linear2.W"), m->ds2, m->da, m->G_("ffn.linear1.W"), m->rowscratch, m->part, NL, s));
+                             m->P_("ffn.linear2.W"), m->ds2, m->da, m->G_("ffn.linear1.W"), m->sc_ffn, m->part, NL, s));
   STEP("bn_bwd_finalize", vt_bn_bwd_finalize(m->part, nrb, D, NL, m->P_("norm1.gamma"), m->stat_n1, m->tok, m->G_("norm1.gamma"),
                            m->G_("norm1.beta"), m->coef_n1, s));
   STEP("transformer_bwd_c", vt_transformer_bwd_c(m->da, m->coef_n1, m->P_("mha.o.W"), m->tok, m->P_("mha.q0.W"), m->dr, m->dc, m->qkv, NL, s));
-  STEP("mha_bwd_rows", vt_mha_bwd_rows(m->qkv, m->dc, m->tok, m->rowscratch, n, L, s));
-  STEP("mha_bwd_wgrad", vt_mha_bwd_wgrad(m->qkv, m->dc, m->tok, m->P_("mha.q0.W"), m->G_("mha.q0.W"), m->rowscratch, n, L, s));
+  STEP("mha_bwd_rows", vt_mha_bwd_rows(m->qkv, m->dc, m->tok, m->sc_mha, n, L, s));
+  STEP("mha_bwd_wgrad", vt_mha_bwd_wgrad(m->qkv, m->dc, m->tok, m->P_("mha.q0.W"), m->G_("mha.q0.W"), m->sc_mha, n, L, s));
   // the output projection's cached input is the zero concat: its gradient is exactly zero
   HIPCHK(hipMemsetAsync(m->G_("mha.o.W"), 0, sizeof(float) * D * D, hs));
   // tokenizer.backward2(projector token delta, projector input delta) + BatchNorm2D + conv
@@ -614,8 +621,9 @@ extern "C" int vt_model_backward(vt_model *m, const int *d_labels, vt_stream s) 
                          m->P_("tok.linear1.W"), m->P_("tok.linear1.b"), m->pdx, m->dy, m->part, n, P, s));
   STEP("bn_bwd_finalize", vt_bn_bwd_finalize(m->part, n, C1, (long)n * P, m->P_("bn.gamma"), m->stat_bn, m->conv, m->G_("bn.gamma"),
                            m->G_("bn.beta"), m->coef_bn, s));
-  STEP("conv3x3_wgrad", vt_conv3x3_wgrad(m->last_images, m->dy, m->coef_bn, m->gslab, n, Ci, H, H, s));
-  STEP("reduce_rows", vt_reduce_rows(m->gslab, n, C1 * Ci * 9 + C1, C1 * Ci * 9 + C1, m->G_("conv.W"), s));
+  STEP("conv3x3_wgrad", vt_conv3x3_wgrad(m->last_images, m->dy, m->coef_bn, m->gslab_conv, n, Ci, H, H, s));
+  VTCHK(vt_reduce_rows(m->gslab_conv, n, C1 * Ci * 9 + C1, C1 * Ci * 9 + C1, m->G_("conv.W"), s));
+  STEP("reduce_rows", reduce_batch_flush(hs));
   return 0;
 }
 
