@@ -45,22 +45,68 @@ struct TileRegs {
   float xa[16];
 };
 
-__device__ __forceinline__ void load_tile(TileRegs &r, const float *__restrict__ Qm, const float *__restrict__ Vm,
-                                          const float *__restrict__ tok, long gbase, int jt, int T, int h, int c,
-                                          int hh) {
-  const int j = jt + c;
-  const long row_j = gbase + (j < T ? j : T - 1);
-  r.q0 = *reinterpret_cast<const float4 *>(Qm + row_j * D + h * HD + 8 * hh);
-  r.q1 = *reinterpret_cast<const float4 *>(Qm + row_j * D + h * HD + 8 * hh + 4);
-  r.v0 = *reinterpret_cast<const float4 *>(Vm + row_j * D + h * HD + 8 * hh);
-  r.v1 = *reinterpret_cast<const float4 *>(Vm + row_j * D + h * HD + 8 * hh + 4);
+// FULL: T is a multiple of 32, so no row of any tile needs a mask or a clamped address and the
+// sixteen token-row loads of a tile are one base pointer plus immediate offsets.
+template <bool FULL>
+__device__ __forceinline__ void load_tile(TileRegs &r, const float *__restrict__ qp, const float *__restrict__ vp,
+                                          const float *__restrict__ xp, int jt, int T, int c, int hh) {
+  if (FULL) {
+    const float *q = qp + (long)jt * D, *vv = vp + (long)jt * D, *x = xp + (long)jt * D;
+    r.q0 = *reinterpret_cast<const float4 *>(q);
+    r.q1 = *reinterpret_cast<const float4 *>(q + 4);
+    r.v0 = *reinterpret_cast<const float4 *>(vv);
+    r.v1 = *reinterpret_cast<const float4 *>(vv + 4);
 #pragma unroll
-  for (int v = 0; v < 16; ++v) {
-    const int jr = jt + acc_row(v, hh);
-    r.xa[v] = tok[(gbase + (jr < T ? jr : T - 1)) * D + c];
+    for (int v = 0; v < 16; ++v) r.xa[v] = x[((v & 3) + 8 * (v >> 2)) * D];
+  } else {
+    const long dj = (jt + c < T ? jt + c : T - 1) - c;  // row offset of this lane's Q / V row
+    r.q0 = *reinterpret_cast<const float4 *>(qp + dj * D);
+    r.q1 = *reinterpret_cast<const float4 *>(qp + dj * D + 4);
+    r.v0 = *reinterpret_cast<const float4 *>(vp + dj * D);
+    r.v1 = *reinterpret_cast<const float4 *>(vp + dj * D + 4);
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const int jr = jt + acc_row(v, hh);
+      r.xa[v] = xp[((long)(jr < T ? jr : T - 1) - 4 * hh) * D];
+    }
   }
 }
 
+// One 32 x 32 tile pair: 16 MFMAs for the transposed score and dattn tiles, the softmax numerators
+// on the vector ALU, 32 MFMAs that contract the tile with the token rows.
+template <bool FULL>
+__device__ __forceinline__ void tile_step(const TileRegs &cur, const float (&kb)[8], const float (&db)[8], float scale,
+                                          float mx, int jt, int T, int hh, floatx16 &accY, floatx16 &accW, float &ssum,
+                                          float &tsum) {
+  const float qa[8] = {cur.q0.x, cur.q0.y, cur.q0.z, cur.q0.w, cur.q1.x, cur.q1.y, cur.q1.z, cur.q1.w};
+  const float va[8] = {cur.v0.x, cur.v0.y, cur.v0.z, cur.v0.w, cur.v1.x, cur.v1.y, cur.v1.z, cur.v1.w};
+  floatx16 accS, accD;
+#pragma unroll
+  for (int v = 0; v < 16; ++v) { accS[v] = 0.f; accD[v] = 0.f; }
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    accS = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[t], kb[t], accS, 0, 0, 0);
+    accD = __builtin_amdgcn_mfma_f32_32x32x2f32(va[t], db[t], accD, 0, 0, 0);
+  }
+  const float nmx = -mx;
+#pragma unroll
+  for (int v = 0; v < 16; ++v) {
+    float ev = __expf(fmaf(accS[v], scale, nmx));
+    if (!FULL) ev = (jt + acc_row(v, hh) < T) ? ev : 0.f;
+    const float ed = ev * accD[v];
+    ssum += ev;
+    tsum += ed;
+    accS[v] = ev;
+    accD[v] = ed;
+  }
+#pragma unroll
+  for (int v = 0; v < 16; ++v) {
+    accY = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.xa[v], accS[v], accY, 0, 0, 0);
+    accW = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.xa[v], accD[v], accW, 0, 0, 0);
+  }
+}
+
+template <bool FULL>
 __global__ __launch_bounds__(64) void k_mha_rows(const float *__restrict__ qkv, const float *__restrict__ dc,
                                                  const float *__restrict__ tok, float *__restrict__ yz,
                                                  float *__restrict__ st, int T, long rows, int groups, int nsplit) {
@@ -75,11 +121,15 @@ __global__ __launch_bounds__(64) void k_mha_rows(const float *__restrict__ qkv, 
   const float *__restrict__ Qm = qkv, *__restrict__ Km = qkv + rows * D, *__restrict__ Vm = qkv + 2 * rows * D;
   const float scale = 1.0f / sqrtf((float)HD);
   const int i = itile * 32 + c;
-  const bool ok_i = i < T;
+  const bool ok_i = FULL || i < T;
   const long row_i = gbase + (ok_i ? i : T - 1);
   // this split's j range, in whole tiles
   const int tps = (itiles + nsplit - 1) / nsplit;
   const int jbeg = sp * tps * 32, jend = min(T, (sp + 1) * tps * 32);
+  // per-lane bases of the tile loads (row jt + c of Q and V; row jt + 4*hh, column c of the tokens)
+  const float *__restrict__ qp = Qm + (gbase + c) * D + h * HD + 8 * hh;
+  const float *__restrict__ vp = Vm + (gbase + c) * D + h * HD + 8 * hh;
+  const float *__restrict__ xp = tok + (gbase + 4 * hh) * D + c;
 
   // B operands of the score products: element t of lane half hh is head column e = 8*hh + t
   // (the order of the contraction index is free as long as A and B agree).
@@ -92,8 +142,8 @@ __global__ __launch_bounds__(64) void k_mha_rows(const float *__restrict__ qkv, 
     kb[0] = k0.x; kb[1] = k0.y; kb[2] = k0.z; kb[3] = k0.w; kb[4] = k1.x; kb[5] = k1.y; kb[6] = k1.z; kb[7] = k1.w;
     db[0] = d0.x; db[1] = d0.y; db[2] = d0.z; db[3] = d0.w; db[4] = d1.x; db[5] = d1.y; db[6] = d1.z; db[7] = d1.w;
   }
-  TileRegs nxt;
-  if (jbeg < jend) load_tile(nxt, Qm, Vm, tok, gbase, jbeg, T, h, c, hh);
+  TileRegs ta, tb;  // ping-pong: the next tile's loads are in flight during the current tile's MFMAs
+  if (jbeg < jend) load_tile<FULL>(ta, qp, vp, xp, jbeg, T, c, hh);
   float kn2 = 0.f;
 #pragma unroll
   for (int t = 0; t < 8; ++t) kn2 += kb[t] * kb[t];
@@ -117,34 +167,17 @@ __global__ __launch_bounds__(64) void k_mha_rows(const float *__restrict__ qkv, 
   for (int v = 0; v < 16; ++v) { accY[v] = 0.f; accW[v] = 0.f; }
   float ssum = 0.f, tsum = 0.f;
 
-  for (int jt = jbeg; jt < jend; jt += 32) {
-    const TileRegs cur = nxt;
-    if (jt + 32 < jend) load_tile(nxt, Qm, Vm, tok, gbase, jt + 32, T, h, c, hh);  // in flight during the MFMAs
-    const float qa[8] = {cur.q0.x, cur.q0.y, cur.q0.z, cur.q0.w, cur.q1.x, cur.q1.y, cur.q1.z, cur.q1.w};
-    const float va[8] = {cur.v0.x, cur.v0.y, cur.v0.z, cur.v0.w, cur.v1.x, cur.v1.y, cur.v1.z, cur.v1.w};
-    floatx16 accS, accD;
-#pragma unroll
-    for (int v = 0; v < 16; ++v) { accS[v] = 0.f; accD[v] = 0.f; }
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      accS = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[t], kb[t], accS, 0, 0, 0);
-      accD = __builtin_amdgcn_mfma_f32_32x32x2f32(va[t], db[t], accD, 0, 0, 0);
-    }
-#pragma unroll
-    for (int v = 0; v < 16; ++v) {
-      const bool ok_j = jt + acc_row(v, hh) < T;
-      const float ev = ok_j ? __expf(accS[v] * scale - mx) : 0.f;
-      const float ed = ev * accD[v];
-      ssum += ev;
-      tsum += ed;
-      accS[v] = ev;
-      accD[v] = ed;
-    }
-#pragma unroll
-    for (int v = 0; v < 16; ++v) {
-      accY = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.xa[v], accS[v], accY, 0, 0, 0);
-      accW = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.xa[v], accD[v], accW, 0, 0, 0);
-    }
+  // The look-ahead loads are unconditional (the last ones re-read the final tile): a load under a
+  // branch would force the wait in front of the MFMAs to cover it as well.
+  const int jlast = jbeg < jend ? jbeg + ((jend - jbeg - 1) & ~31) : jbeg;
+  for (int jt = jbeg; jt < jend; jt += 64) {
+    load_tile<FULL>(tb, qp, vp, xp, min(jt + 32, jlast), T, c, hh);
+    __builtin_amdgcn_sched_barrier(0);  // keep the loads in front of the tile's arithmetic
+    tile_step<FULL>(ta, kb, db, scale, mx, jt, T, hh, accY, accW, ssum, tsum);
+    if (jt + 32 >= jend) break;
+    load_tile<FULL>(ta, qp, vp, xp, min(jt + 64, jlast), T, c, hh);
+    __builtin_amdgcn_sched_barrier(0);
+    tile_step<FULL>(tb, kb, db, scale, mx, jt + 32, T, hh, accY, accW, ssum, tsum);
   }
   ssum += __shfl_xor(ssum, 32);
   tsum += __shfl_xor(tsum, 32);
@@ -259,8 +292,12 @@ extern "C" int vt_mha_bwd_rows(const float *qkv, const float *dc, const float *t
   const long rows = (long)N * groups;
   float *yz = scratch;
   float *st = yz + (size_t)HEADS * ns * 2 * D * rows;
-  hipLaunchKernelGGL(k_mha_rows, dim3(HEADS * groups * itiles * ns), dim3(64), 0, (hipStream_t)s, qkv, dc, tok, yz, st,
-                     N, rows, groups, ns);
+  if (N % 32 == 0)
+    hipLaunchKernelGGL(k_mha_rows<true>, dim3(HEADS * groups * itiles * ns), dim3(64), 0, (hipStream_t)s, qkv, dc, tok,
+                       yz, st, N, rows, groups, ns);
+  else
+    hipLaunchKernelGGL(k_mha_rows<false>, dim3(HEADS * groups * itiles * ns), dim3(64), 0, (hipStream_t)s, qkv, dc, tok,
+                       yz, st, N, rows, groups, ns);
   VT_CHECK_LAUNCH();
   return 0;
 }
