@@ -45,33 +45,6 @@ struct TileRegs {
   float xa[16];
 };
 
-// FULL: T is a multiple of 32, so no row of any tile needs a mask or a clamped address and the
-// sixteen token-row loads of a tile are one base pointer plus immediate offsets.
-template <bool FULL>
-__device__ __forceinline__ void load_tile(TileRegs &r, const float *__restrict__ qp, const float *__restrict__ vp,
-                                          const float *__restrict__ xp, int jt, int T, int c, int hh) {
-  if (FULL) {
-    const float *q = qp + (long)jt * D, *vv = vp + (long)jt * D, *x = xp + (long)jt * D;
-    r.q0 = *reinterpret_cast<const float4 *>(q);
-    r.q1 = *reinterpret_cast<const float4 *>(q + 4);
-    r.v0 = *reinterpret_cast<const float4 *>(vv);
-    r.v1 = *reinterpret_cast<const float4 *>(vv + 4);
-#pragma unroll
-    for (int v = 0; v < 16; ++v) r.xa[v] = x[((v & 3) + 8 * (v >> 2)) * D];
-  } else {
-    const long dj = (jt + c < T ? jt + c : T - 1) - c;  // row offset of this lane's Q / V row
-    r.q0 = *reinterpret_cast<const float4 *>(qp + dj * D);
-    r.q1 = *reinterpret_cast<const float4 *>(qp + dj * D + 4);
-    r.v0 = *reinterpret_cast<const float4 *>(vp + dj * D);
-    r.v1 = *reinterpret_cast<const float4 *>(vp + dj * D + 4);
-#pragma unroll
-    for (int v = 0; v < 16; ++v) {
-      const int jr = jt + acc_row(v, hh);
-      r.xa[v] = xp[((long)(jr < T ? jr : T - 1) - 4 * hh) * D];
-    }
-  }
-}
-
 // One 32 x 32 tile pair: 16 MFMAs for the transposed score and dattn tiles, the softmax numerators
 // on the vector ALU, 32 MFMAs that contract the tile with the token rows.
 template <bool FULL>
@@ -106,30 +79,40 @@ __device__ __forceinline__ void tile_step(const TileRegs &cur, const float (&kb)
   }
 }
 
+constexpr int MR_WAVES = 4;  // row tiles (waves) per workgroup sharing the staged j tiles
+constexpr int QS = 20;       // LDS row stride of the staged Q / V tiles (floats; keeps b128 reads aligned)
+
+// FULL: T is a multiple of 32, so no row of any tile needs a mask.
+// Workgroup = MR_WAVES row tiles of one (head, group, j range).  The j tile (32 token rows, their
+// Q and V head slices: 8 KB) is fetched once per workgroup, two 16-byte loads per thread, and
+// double-buffered in LDS: the global loads of tile k+1 are issued before the arithmetic of tile k
+// and land in LDS after it, so their latency never reaches the matrix pipe.
 template <bool FULL>
-__global__ __launch_bounds__(64) void k_mha_rows(const float *__restrict__ qkv, const float *__restrict__ dc,
-                                                 const float *__restrict__ tok, float *__restrict__ yz,
-                                                 float *__restrict__ st, int T, long rows, int groups, int nsplit) {
-  static_assert(HD == 16 && D == 32, "tile shapes are written for head_dim 16, token channels 32");
-  const int itiles = (T + 31) / 32;
+__global__ __launch_bounds__(64 * MR_WAVES) void k_mha_rows(const float *__restrict__ qkv, const float *__restrict__ dc,
+                                                            const float *__restrict__ tok, float *__restrict__ yz,
+                                                            float *__restrict__ st, int T, long rows, int groups,
+                                                            int nsplit) {
+  static_assert(HD == 16 && D == 32 && MR_WAVES == 4, "tile shapes are written for head_dim 16, token channels 32");
+  __shared__ __attribute__((aligned(16))) float sX[2][32 * D];
+  __shared__ __attribute__((aligned(16))) float sQ[2][32 * QS];
+  __shared__ __attribute__((aligned(16))) float sV[2][32 * QS];
+  __shared__ float sred[MR_WAVES];
+  const int itiles = (T + 31) / 32, iblocks = (itiles + MR_WAVES - 1) / MR_WAVES;
   int bi = blockIdx.x;
   const int sp = bi % nsplit; bi /= nsplit;
-  const int itile = bi % itiles; bi /= itiles;
+  const int ib = bi % iblocks; bi /= iblocks;
   const int bgrp = bi % groups, h = bi / groups;
-  const int lane = threadIdx.x, c = lane & 31, hh = lane >> 5;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 31, hh = lane >> 5;
   const long gbase = (long)bgrp * T;
   const float *__restrict__ Qm = qkv, *__restrict__ Km = qkv + rows * D, *__restrict__ Vm = qkv + 2 * rows * D;
   const float scale = 1.0f / sqrtf((float)HD);
-  const int i = itile * 32 + c;
-  const bool ok_i = FULL || i < T;
+  const int i = (ib * MR_WAVES + wave) * 32 + c;
+  const bool ok_i = i < T;
   const long row_i = gbase + (ok_i ? i : T - 1);
   // this split's j range, in whole tiles
   const int tps = (itiles + nsplit - 1) / nsplit;
   const int jbeg = sp * tps * 32, jend = min(T, (sp + 1) * tps * 32);
-  // per-lane bases of the tile loads (row jt + c of Q and V; row jt + 4*hh, column c of the tokens)
-  const float *__restrict__ qp = Qm + (gbase + c) * D + h * HD + 8 * hh;
-  const float *__restrict__ vp = Vm + (gbase + c) * D + h * HD + 8 * hh;
-  const float *__restrict__ xp = tok + (gbase + 4 * hh) * D + c;
+  const int ntile = jbeg < jend ? (jend - jbeg + 31) / 32 : 0;
 
   // B operands of the score products: element t of lane half hh is head column e = 8*hh + t
   // (the order of the contraction index is free as long as A and B agree).
@@ -142,24 +125,42 @@ __global__ __launch_bounds__(64) void k_mha_rows(const float *__restrict__ qkv, 
     kb[0] = k0.x; kb[1] = k0.y; kb[2] = k0.z; kb[3] = k0.w; kb[4] = k1.x; kb[5] = k1.y; kb[6] = k1.z; kb[7] = k1.w;
     db[0] = d0.x; db[1] = d0.y; db[2] = d0.z; db[3] = d0.w; db[4] = d1.x; db[5] = d1.y; db[6] = d1.z; db[7] = d1.w;
   }
-  TileRegs ta, tb;  // ping-pong: the next tile's loads are in flight during the current tile's MFMAs
-  if (jbeg < jend) load_tile<FULL>(ta, qp, vp, xp, jbeg, T, c, hh);
+  // staging roles: thread -> one float4 of the token tile and one of the Q (threads 0..127) or V tile
+  const int xr = tid >> 3, xc = (tid & 7) * 4, t2 = tid & 127, qr = t2 >> 2, qc = (t2 & 3) * 4;
+  const float *__restrict__ gx = tok + gbase * D + xc;
+  const float *__restrict__ gq = (tid < 128 ? Qm : Vm) + gbase * D + h * HD + qc;
+  float *const sqv = tid < 128 ? &sQ[0][0] : &sV[0][0];
+  float4 rx, rq;
+  auto gload = [&](int jt) {
+    rx = *reinterpret_cast<const float4 *>(gx + (long)min(jt + xr, T - 1) * D);
+    rq = *reinterpret_cast<const float4 *>(gq + (long)min(jt + qr, T - 1) * D);
+  };
+  auto sstore = [&](int buf) {
+    *reinterpret_cast<float4 *>(&sX[buf][xr * D + xc]) = rx;
+    *reinterpret_cast<float4 *>(sqv + buf * 32 * QS + qr * QS + qc) = rq;
+  };
+  if (ntile > 0) gload(jbeg);
+
   float kn2 = 0.f;
 #pragma unroll
   for (int t = 0; t < 8; ++t) kn2 += kb[t] * kb[t];
   kn2 += __shfl_xor(kn2, 32);
-  // largest |Q_j|^2 of the whole group (identical in every split)
+  // largest |Q_j|^2 of the whole group (identical in every split and row tile)
   float qn2 = 0.f;
-  for (int j = lane; j < T; j += 64) {
-    float s = 0.f;
+  for (int j = tid; j < T; j += 64 * MR_WAVES) {
+    float sq = 0.f;
 #pragma unroll
     for (int q = 0; q < HD / 4; ++q) {
       const float4 v = *reinterpret_cast<const float4 *>(Qm + (gbase + j) * D + h * HD + 4 * q);
-      s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+      sq += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
     }
-    qn2 = fmaxf(qn2, s);
+    qn2 = fmaxf(qn2, sq);
   }
   qn2 = wave_max(qn2);
+  if (lane == 0) sred[wave] = qn2;
+  if (ntile > 0) sstore(0);
+  __syncthreads();
+  qn2 = fmaxf(fmaxf(sred[0], sred[1]), fmaxf(sred[2], sred[3]));
   const float mx = scale * sqrtf(kn2) * sqrtf(qn2);  // >= every scaled score of row i
 
   floatx16 accY, accW;
@@ -167,17 +168,19 @@ __global__ __launch_bounds__(64) void k_mha_rows(const float *__restrict__ qkv, 
   for (int v = 0; v < 16; ++v) { accY[v] = 0.f; accW[v] = 0.f; }
   float ssum = 0.f, tsum = 0.f;
 
-  // The look-ahead loads are unconditional (the last ones re-read the final tile): a load under a
-  // branch would force the wait in front of the MFMAs to cover it as well.
-  const int jlast = jbeg < jend ? jbeg + ((jend - jbeg - 1) & ~31) : jbeg;
-  for (int jt = jbeg; jt < jend; jt += 64) {
-    load_tile<FULL>(tb, qp, vp, xp, min(jt + 32, jlast), T, c, hh);
-    __builtin_amdgcn_sched_barrier(0);  // keep the loads in front of the tile's arithmetic
-    tile_step<FULL>(ta, kb, db, scale, mx, jt, T, hh, accY, accW, ssum, tsum);
-    if (jt + 32 >= jend) break;
-    load_tile<FULL>(ta, qp, vp, xp, min(jt + 64, jlast), T, c, hh);
-    __builtin_amdgcn_sched_barrier(0);
-    tile_step<FULL>(tb, kb, db, scale, mx, jt + 32, T, hh, accY, accW, ssum, tsum);
+  for (int k = 0; k < ntile; ++k) {
+    const int jt = jbeg + 32 * k, b = k & 1;
+    gload(jbeg + 32 * min(k + 1, ntile - 1));  // unconditional: the last one re-reads the final tile
+    TileRegs cur;
+    cur.q0 = *reinterpret_cast<const float4 *>(&sQ[b][c * QS + 8 * hh]);
+    cur.q1 = *reinterpret_cast<const float4 *>(&sQ[b][c * QS + 8 * hh + 4]);
+    cur.v0 = *reinterpret_cast<const float4 *>(&sV[b][c * QS + 8 * hh]);
+    cur.v1 = *reinterpret_cast<const float4 *>(&sV[b][c * QS + 8 * hh + 4]);
+#pragma unroll
+    for (int v = 0; v < 16; ++v) cur.xa[v] = sX[b][acc_row(v, hh) * D + c];
+    tile_step<FULL>(cur, kb, db, scale, mx, jt, T, hh, accY, accW, ssum, tsum);
+    sstore(b ^ 1);
+    __syncthreads();
   }
   ssum += __shfl_xor(ssum, 32);
   tsum += __shfl_xor(tsum, 32);
@@ -277,7 +280,7 @@ using namespace vt;
 // How many j ranges each row tile is split into so that the launch has ~2 waves per SIMD.
 static int mha_splits(int N, int groups) {
   const int itiles = (N + 31) / 32;
-  const long waves = (long)HEADS * groups * itiles;
+  const long waves = (long)HEADS * groups * ((itiles + MR_WAVES - 1) / MR_WAVES) * MR_WAVES;
   int ns = (int)((2048 + waves - 1) / waves);
   if (ns > 4) ns = 4;
   if (ns > itiles) ns = itiles;
@@ -292,12 +295,13 @@ extern "C" int vt_mha_bwd_rows(const float *qkv, const float *dc, const float *t
   const long rows = (long)N * groups;
   float *yz = scratch;
   float *st = yz + (size_t)HEADS * ns * 2 * D * rows;
+  const int iblocks = (itiles + MR_WAVES - 1) / MR_WAVES;
   if (N % 32 == 0)
-    hipLaunchKernelGGL(k_mha_rows<true>, dim3(HEADS * groups * itiles * ns), dim3(64), 0, (hipStream_t)s, qkv, dc, tok,
-                       yz, st, N, rows, groups, ns);
+    hipLaunchKernelGGL(k_mha_rows<true>, dim3(HEADS * groups * iblocks * ns), dim3(64 * MR_WAVES), 0, (hipStream_t)s,
+                       qkv, dc, tok, yz, st, N, rows, groups, ns);
   else
-    hipLaunchKernelGGL(k_mha_rows<false>, dim3(HEADS * groups * itiles * ns), dim3(64), 0, (hipStream_t)s, qkv, dc, tok,
-                       yz, st, N, rows, groups, ns);
+    hipLaunchKernelGGL(k_mha_rows<false>, dim3(HEADS * groups * iblocks * ns), dim3(64 * MR_WAVES), 0, (hipStream_t)s,
+                       qkv, dc, tok, yz, st, N, rows, groups, ns);
   VT_CHECK_LAUNCH();
   return 0;
 }
