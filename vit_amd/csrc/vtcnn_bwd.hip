@@ -8,37 +8,6 @@
 
 namespace vt {
 
-// ---------------------------------------------------------------------------------------------
-// fc DenseLayer::backward weight / bias gradients (reference layers/dense_layer.hpp:92-96):
-// gW[f][k] = sum_n pooled[n][f] * delta[n][k], gb[k] = sum_n delta[n][k].  Thread = one input
-// feature f, loop over a chunk of samples; chunks are summed by k_reduce_rows.
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(TPB) void k_fc_wgrad(const float *__restrict__ pooled, const float *__restrict__ dl,
-                                                  float *__restrict__ out, int N, int Q, int K, int chunk, int ld) {
-  const int f = blockIdx.x * TPB + threadIdx.x;
-  const int n0 = blockIdx.y * chunk, n1 = min(N, n0 + chunk);
-  float *row = out + (size_t)blockIdx.y * ld;
-  if (f < Q) {
-    float acc[KMAX];
-#pragma unroll
-    for (int k = 0; k < KMAX; ++k) acc[k] = 0.f;
-    for (int n = n0; n < n1; ++n) {
-      const float pv = pooled[(size_t)n * Q + f];
-#pragma unroll
-      for (int k = 0; k < KMAX; ++k)
-        if (k < K) acc[k] += pv * dl[(size_t)n * K + k];
-    }
-#pragma unroll
-    for (int k = 0; k < KMAX; ++k)
-      if (k < K) row[(size_t)f * K + k] = acc[k];
-  }
-  if (blockIdx.x == 0 && threadIdx.x < K) {
-    float s = 0.f;
-    for (int n = n0; n < n1; ++n) s += dl[(size_t)n * K + threadIdx.x];
-    row[(size_t)Q * K + threadIdx.x] = s;
-  }
-}
-
 // Column sums of a [rows][ld] slab: out[c] = sum_r slab[r][c], c < cols.  1024 threads =
 // 64 columns x 16 row lanes; fixed order => reproducible.
 __global__ __launch_bounds__(1024) void k_reduce_rows(const float *__restrict__ slab, long rows, int cols, int ld,
@@ -513,26 +482,6 @@ int vt::reduce_rows(const float *slab, long rows, int cols, int ld, float *out, 
 extern "C" int vt_reduce_rows(const float *slab, long rows, int cols, int ld, float *out, vt_stream s) {
   if (rows < 1 || cols < 1 || ld < cols) return VT_EINVAL;
   return reduce_rows(slab, rows, cols, ld, out, (hipStream_t)s);
-}
-
-// scratch: at least ceil(N/32) * (Q*K + K) floats (unused when N <= 32).
-extern "C" int vt_fc_wgrad(const float *pooled, const float *d_logits, float *gw, float *gb, float *scratch, int N,
-                           int Q, int K, vt_stream s) {
-  if (N < 1 || Q < 1 || K < 1 || K > KMAX) return VT_EUNSUPPORTED;
-  const int chunk = 32, ns = (N + chunk - 1) / chunk, ld = Q * K + K;
-  const bool direct = (ns == 1 && gb == gw + (size_t)Q * K);
-  if (!direct && !scratch) return VT_EINVAL;
-  float *dst = direct ? gw : scratch;
-  hipLaunchKernelGGL(k_fc_wgrad, dim3((Q + TPB - 1) / TPB, ns), dim3(TPB), 0, (hipStream_t)s, pooled, d_logits, dst, N,
-                     Q, K, chunk, ld);
-  VT_CHECK_LAUNCH();
-  if (!direct) {
-    int rc = reduce_rows(scratch, ns, Q * K, ld, gw, (hipStream_t)s);
-    if (rc) return rc;
-    rc = reduce_rows(scratch + (size_t)Q * K, ns, K, ld, gb, (hipStream_t)s);
-    if (rc) return rc;
-  }
-  return 0;
 }
 
 extern "C" int vt_bn_bwd_finalize(const float *part, int nblocks, int C, long rows_total, const float *gamma,

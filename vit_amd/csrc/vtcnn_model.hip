@@ -142,7 +142,7 @@ extern "C" int vt_model_create(const vt_dims *dims, int max_batch, int device, f
   // partial slabs of the row-matrix launchers (sizes: see the scratch notes in vtcnn_hip.h)
   rc |= dalloc(m, &m->sc_ffn, nrb * 2112);
   rc |= dalloc(m, &m->sc_pt, nrb * 1552);
-  rc |= dalloc(m, &m->sc_fc, ((N + 31) / 32) * (Q * K + K));
+  rc |= dalloc(m, &m->sc_fc, ((N + 127) / 128) * (Q * K + K));
   rc |= dalloc(m, &m->sc_mha, (size_t)HEADS * 4 * (2 * D + 2) * NL + (size_t)HEADS * nrb * 1536);
   rc |= dalloc(m, &m->coef_pn, 2 * C2, "coef.proj.norm");
   rc |= dalloc(m, &m->coef_n2, 2 * D, "coef.norm2");

@@ -670,6 +670,47 @@ __global__ __launch_bounds__(TPB) void k_conv_wgrad(const float *__restrict__ X,
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// fc DenseLayer::backward weight / bias gradients (reference layers/dense_layer.hpp:92-96):
+// gW[f][k] = sum_n pooled[n][f] * delta[n][k], gb[k] = sum_n delta[n][k].
+// A contraction over samples: D[k][f] += A[k][n] . B[n][f] with the delta as the A operand (lane =
+// class) and 16 consecutive features of the pooled rows as the B operand.  One wave owns a tile of
+// 16 features and a chunk of FCW_CH samples; all of its 2 * FCW_CH/4 loads are issued before the
+// first MFMA.  One extra tile whose B operand is all ones yields the bias gradient.  Chunks are
+// summed afterwards (partial slab + column reduction).
+// ---------------------------------------------------------------------------------------------
+constexpr int FCW_CH = 128;
+__global__ __launch_bounds__(TPB) void k_fc_wgrad(const float *__restrict__ pooled, const float *__restrict__ dl,
+                                                  float *__restrict__ out, int N, int Q, int K, int ld) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, gq = lane >> 4;
+  const int qt = (Q + 15) >> 4, tile = blockIdx.x * NW + wave;
+  if (tile > qt) return;
+  const bool bias_tile = tile == qt;
+  const int n0 = blockIdx.y * FCW_CH, f = tile * 16 + j;
+  const bool fok = !bias_tile && f < Q;
+  float a[FCW_CH / 4], b[FCW_CH / 4];
+#pragma unroll
+  for (int s = 0; s < FCW_CH / 4; ++s) {
+    const int n = n0 + 4 * s + gq, nn = min(n, N - 1);
+    a[s] = j < K ? dl[(size_t)nn * K + j] : 0.f;
+    b[s] = fok ? pooled[(size_t)nn * Q + f] : 1.f;
+    if (n >= N) a[s] = 0.f;
+  }
+  f4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < FCW_CH / 4; ++s) acc = mfma16(a[s], b[s], acc);
+  float *row = out + (size_t)blockIdx.y * ld;
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    const int k = 4 * gq + v;
+    if (k < K) {
+      if (fok) row[(size_t)f * K + k] = acc[v];
+      else if (bias_tile && j == 0) row[(size_t)Q * K + k] = acc[v];
+    }
+  }
+}
+
 }  // namespace vt
 
 using namespace vt;
@@ -724,5 +765,27 @@ extern "C" int vt_conv3x3_wgrad(const float *x, const float *dy, const float *bn
   const int ld = C1 * Ci * 9 + C1;
   hipLaunchKernelGGL(k_conv_wgrad, dim3(N), dim3(TPB), 0, (hipStream_t)s, x, dy, bn_coef, gslab, Ci, H, W, ld);
   VT_CHECK_LAUNCH();
+  return 0;
+}
+
+
+// scratch: at least ceil(N/128) * (Q*K + K) floats (unused when N <= 128 and gb follows gw).
+extern "C" int vt_fc_wgrad(const float *pooled, const float *d_logits, float *gw, float *gb, float *scratch, int N,
+                           int Q, int K, vt_stream s) {
+  if (N < 1 || Q < 1 || K < 1 || K > KMAX) return VT_EUNSUPPORTED;
+  const int ns = (N + FCW_CH - 1) / FCW_CH, ld = Q * K + K;
+  const bool direct = (ns == 1 && gb == gw + (size_t)Q * K);
+  if (!direct && !scratch) return VT_EINVAL;
+  float *dst = direct ? gw : scratch;
+  const int tiles = (Q + 15) / 16 + 1;
+  hipLaunchKernelGGL(k_fc_wgrad, dim3((tiles + NW - 1) / NW, ns), dim3(TPB), 0, (hipStream_t)s, pooled, d_logits, dst, N,
+                     Q, K, ld);
+  VT_CHECK_LAUNCH();
+  if (!direct) {
+    int rc = reduce_rows(scratch, ns, Q * K, ld, gw, (hipStream_t)s);
+    if (rc) return rc;
+    rc = reduce_rows(scratch + (size_t)Q * K, ns, K, ld, gb, (hipStream_t)s);
+    if (rc) return rc;
+  }
   return 0;
 }
