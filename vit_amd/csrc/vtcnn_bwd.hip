@@ -122,251 +122,6 @@ __global__ __launch_bounds__(FIN_T) void k_bn_bwd_finalize(const float *__restri
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// ProjectorLayer::backward, token side (reference projector_layer.hpp:186-202): Dense backward of
-// linear3 (values) and linear2 (keys) over the N*L token rows.
-//   gWv = o^T dv, gbv = sum dv, gWk = o^T dk, token delta = dv.Wv^T + dk.Wk^T
-// Per-workgroup partials: gWk[D*D] | gWv[D*C2] | gbv[C2]  (PT_STRIDE floats), summed afterwards.
-// ---------------------------------------------------------------------------------------------
-constexpr int PT_STRIDE = D * D + D * C2 + C2;  // 1552
-__global__ __launch_bounds__(TPB) void k_projtok_bwd(const float *__restrict__ o, const float *__restrict__ dv,
-                                                     const float *__restrict__ dk, const float *__restrict__ Wv,
-                                                     const float *__restrict__ Wk, float *__restrict__ pdt,
-                                                     float *__restrict__ scratch, long rows) {
-  __shared__ float so[RB][D + 1], sdk[RB][D + 1], sdv[RB][C2 + 1];
-  __shared__ float sWk[D * D], sWv[D * C2];
-  const int tid = threadIdx.x;
-  const long r0 = (long)blockIdx.x * RB;
-  const int cnt = (int)min((long)RB, rows - r0);
-  for (int i = tid; i < RB * D; i += TPB) {
-    const int r = i / D, d = i % D;
-    const bool ok = r < cnt;
-    so[r][d] = ok ? o[(r0 + r) * D + d] : 0.f;
-    sdk[r][d] = ok ? dk[(r0 + r) * D + d] : 0.f;
-  }
-  for (int i = tid; i < RB * C2; i += TPB) {
-    const int r = i / C2, c = i % C2;
-    sdv[r][c] = r < cnt ? dv[(r0 + r) * C2 + c] : 0.f;
-  }
-  for (int i = tid; i < D * D; i += TPB) sWk[i] = Wk[i];
-  for (int i = tid; i < D * C2; i += TPB) sWv[i] = Wv[i];
-  __syncthreads();
-  float *row = scratch + (size_t)blockIdx.x * PT_STRIDE;
-  for (int idx = tid; idx < D * D; idx += TPB) {
-    const int d = idx / D, e = idx % D;
-    float s = 0.f;
-    for (int r = 0; r < RB; ++r) s += so[r][d] * sdk[r][e];
-    row[idx] = s;
-  }
-  for (int idx = tid; idx < D * C2; idx += TPB) {
-    const int d = idx / C2, c = idx % C2;
-    float s = 0.f;
-    for (int r = 0; r < RB; ++r) s += so[r][d] * sdv[r][c];
-    row[D * D + idx] = s;
-  }
-  if (tid < C2) {
-    float s = 0.f;
-    for (int r = 0; r < RB; ++r) s += sdv[r][tid];
-    row[D * D + D * C2 + tid] = s;
-  }
-  for (int idx = tid; idx < RB * D; idx += TPB) {
-    const int r = idx / D, d = idx % D;
-    if (r < cnt) {
-      float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-      for (int c = 0; c < C2; ++c) s1 += sdv[r][c] * sWv[d * C2 + c];
-#pragma unroll 8
-      for (int e = 0; e < D; ++e) s2 += sdk[r][e] * sWk[d * D + e];
-      pdt[(r0 + r) * D + d] = s1 + s2;
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// TransformerLayer::backward, step A (reference layers/transformer_layer.hpp:142-161):
-//   d0 = last_output - targets  with targets = projector token delta (visual_transformer.hpp:156-157)
-//   partial sums of the second BatchNorm1D backward.
-// Also the tokenizer's linear2 input delta dT0 = token_delta . W2tok^T (tokenizer.hpp:73-75), which
-// reads the same rows.
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(TPB) void k_tr_bwd_a(const float *__restrict__ o, const float *__restrict__ pdt,
-                                                  const float *__restrict__ s2, const float *__restrict__ st2,
-                                                  const float *__restrict__ W2tok, float *__restrict__ part,
-                                                  float *__restrict__ dT0, long rows) {
-  __shared__ float sd[RB][D + 1], sxh[RB][D + 1], sp[RB][D + 1];
-  const int tid = threadIdx.x;
-  const long r0 = (long)blockIdx.x * RB;
-  const int cnt = (int)min((long)RB, rows - r0);
-  for (int i = tid; i < RB * D; i += TPB) {
-    const int r = i / D, d = i % D;
-    const bool ok = r < cnt;
-    const float pv = ok ? pdt[(r0 + r) * D + d] : 0.f;
-    sp[r][d] = pv;
-    sd[r][d] = ok ? o[(r0 + r) * D + d] - pv : 0.f;
-    sxh[r][d] = ok ? (s2[(r0 + r) * D + d] - st2[d]) * st2[D + d] : 0.f;
-  }
-  __syncthreads();
-  if (tid < 2 * D) {
-    const int d = tid % D;
-    float s = 0.f;
-    if (tid < D) for (int r = 0; r < RB; ++r) s += sd[r][d];
-    else for (int r = 0; r < RB; ++r) s += sd[r][d] * sxh[r][d];
-    part[(size_t)blockIdx.x * 2 * D + tid] = s;
-  }
-  for (int idx = tid; idx < RB * C1; idx += TPB) {
-    const int r = idx / C1, c = idx % C1;
-    if (r < cnt) {
-      float s = 0.f;
-#pragma unroll 8
-      for (int d = 0; d < D; ++d) s += sp[r][d] * W2tok[c * D + d];
-      dT0[(r0 + r) * C1 + c] = s;
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// TransformerLayer::backward, step B (reference transformer_layer.hpp:161-189):
-//   ds2 = BN2.backward(d0);  linear2 backward (its cached input is relu(hdn));
-//   linear1 backward WITHOUT the ReLU derivative (:174-181);  da = dh.W1^T + ds2;
-//   partial sums of the first BatchNorm1D backward.
-// Per-workgroup partials: gW1[D*D] | gb1[D] | gW2[D*D] | gb2[D]  (FF_STRIDE, arena order).
-// ---------------------------------------------------------------------------------------------
-constexpr int FF_STRIDE = 2 * (D * D + D);  // 2112
-__global__ __launch_bounds__(TPB) void k_tr_bwd_b(const float *__restrict__ o, const float *__restrict__ pdt,
-                                                  const float *__restrict__ coef2, const float *__restrict__ hdn,
-                                                  const float *__restrict__ a, const float *__restrict__ tok,
-                                                  const float *__restrict__ st1, const float *__restrict__ W1,
-                                                  const float *__restrict__ W2, float *__restrict__ ds2_out,
-                                                  float *__restrict__ da_out, float *__restrict__ scratch,
-                                                  float *__restrict__ part, long rows) {
-  __shared__ float sds2[RB][D + 1], srl[RB][D + 1], sa[RB][D + 1], sdh[RB][D + 1];
-  __shared__ float sW1[D * D], sW2[D * D];
-  const int tid = threadIdx.x;
-  const long r0 = (long)blockIdx.x * RB;
-  const int cnt = (int)min((long)RB, rows - r0);
-  for (int i = tid; i < RB * D; i += TPB) {
-    const int r = i / D, d = i % D;
-    const bool ok = r < cnt;
-    const float d0 = ok ? o[(r0 + r) * D + d] - pdt[(r0 + r) * D + d] : 0.f;
-    const float v = ok ? d0 * coef2[d] + coef2[D + d] : 0.f;
-    sds2[r][d] = v;
-    if (ok) ds2_out[(r0 + r) * D + d] = v;
-    const float hv = ok ? hdn[(r0 + r) * D + d] : 0.f;
-    srl[r][d] = hv > 0.f ? hv : 0.f;
-    sa[r][d] = ok ? a[(r0 + r) * D + d] : 0.f;
-  }
-  for (int i = tid; i < D * D; i += TPB) {
-    sW1[i] = W1[i];
-    sW2[i] = W2[i];
-  }
-  __syncthreads();
-  float *row = scratch + (size_t)blockIdx.x * FF_STRIDE;
-  // dh = ds2 . W2^T
-  for (int idx = tid; idx < RB * D; idx += TPB) {
-    const int r = idx / D, i = idx % D;
-    float s = 0.f;
-#pragma unroll 8
-    for (int e = 0; e < D; ++e) s += sds2[r][e] * sW2[i * D + e];
-    sdh[r][i] = s;
-  }
-  // gW2 = relu(hdn)^T ds2 ; gb2 = sum ds2
-  for (int idx = tid; idx < D * D; idx += TPB) {
-    const int i = idx / D, e = idx % D;
-    float s = 0.f;
-    for (int r = 0; r < RB; ++r) s += srl[r][i] * sds2[r][e];
-    row[D * D + D + idx] = s;
-  }
-  if (tid < D) {
-    float s = 0.f;
-    for (int r = 0; r < RB; ++r) s += sds2[r][tid];
-    row[2 * D * D + D + tid] = s;
-  }
-  __syncthreads();
-  // gW1 = a^T dh ; gb1 = sum dh
-  for (int idx = tid; idx < D * D; idx += TPB) {
-    const int i = idx / D, e = idx % D;
-    float s = 0.f;
-    for (int r = 0; r < RB; ++r) s += sa[r][i] * sdh[r][e];
-    row[idx] = s;
-  }
-  if (tid < D) {
-    float s = 0.f;
-    for (int r = 0; r < RB; ++r) s += sdh[r][tid];
-    row[D * D + tid] = s;
-  }
-  // da = dh . W1^T + ds2   (reuse srl for da)
-  __syncthreads();
-  for (int idx = tid; idx < RB * D; idx += TPB) {
-    const int r = idx / D, i = idx % D;
-    float s = 0.f;
-#pragma unroll 8
-    for (int e = 0; e < D; ++e) s += sdh[r][e] * sW1[i * D + e];
-    s += sds2[r][i];
-    srl[r][i] = (r < cnt) ? s : 0.f;
-    if (r < cnt) da_out[(r0 + r) * D + i] = s;
-  }
-  __syncthreads();
-  if (tid < 2 * D) {
-    const int d = tid % D;
-    float s = 0.f;
-    if (tid < D) {
-      for (int r = 0; r < cnt; ++r) s += srl[r][d];
-    } else {
-      for (int r = 0; r < cnt; ++r) s += srl[r][d] * ((tok[(r0 + r) * D + d] - st1[d]) * st1[D + d]);
-    }
-    part[(size_t)blockIdx.x * 2 * D + tid] = s;
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// TransformerLayer::backward, step C (reference transformer_layer.hpp:189-200 and the first part
-// of MultiHeadAttention::backward, multi_head_attention.hpp:131-152):
-//   dr = BN1.backward(da);  dc = dr . Wo^T  (delta of the zero "concat");
-//   per head q = X.Wq, k = X.Wk, v = X.Wv recomputed from the layer input X = token rows.
-// qkv layout: three [rows][D] matrices (q | k | v), head h in columns h*HD..h*HD+HD-1.
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(TPB) void k_tr_bwd_c(const float *__restrict__ da, const float *__restrict__ coef1,
-                                                  const float *__restrict__ Wo, const float *__restrict__ tok,
-                                                  const float *__restrict__ Wqkv, float *__restrict__ dr_out,
-                                                  float *__restrict__ dc, float *__restrict__ qkv, long rows) {
-  __shared__ float sdr[RB][D + 1], sx[RB][D + 1];
-  __shared__ float sWo[D * D], sW[3 * D * D];  // sW[m][i][h*HD+e] = W_{m,h}[i][e]
-  const int tid = threadIdx.x;
-  const long r0 = (long)blockIdx.x * RB;
-  const int cnt = (int)min((long)RB, rows - r0);
-  for (int i = tid; i < RB * D; i += TPB) {
-    const int r = i / D, d = i % D;
-    const bool ok = r < cnt;
-    const float v = ok ? da[(r0 + r) * D + d] * coef1[d] + coef1[D + d] : 0.f;
-    sdr[r][d] = v;
-    if (ok) dr_out[(r0 + r) * D + d] = v;
-    sx[r][d] = ok ? tok[(r0 + r) * D + d] : 0.f;
-  }
-  for (int i = tid; i < D * D; i += TPB) sWo[i] = Wo[i];
-  // arena order: q0,k0,v0,q1,k1,v1, each [D][HD]
-  for (int i = tid; i < 3 * D * D; i += TPB) {
-    const int m = i / (D * D), rem = i % (D * D), ii = rem / D, col = rem % D, h = col / HD, e = col % HD;
-    sW[i] = Wqkv[(size_t)(h * 3 + m) * D * HD + ii * HD + e];
-  }
-  __syncthreads();
-  for (int idx = tid; idx < RB * D; idx += TPB) {
-    const int r = idx / D, jx = idx % D;
-    if (r < cnt) {
-      float s = 0.f;
-#pragma unroll 8
-      for (int i = 0; i < D; ++i) s += sdr[r][i] * sWo[jx * D + i];
-      dc[(r0 + r) * D + jx] = s;
-#pragma unroll
-      for (int m = 0; m < 3; ++m) {
-        float t = 0.f;
-#pragma unroll 8
-        for (int i = 0; i < D; ++i) t += sx[r][i] * sW[m * D * D + i * D + jx];
-        qkv[(size_t)m * rows * D + (r0 + r) * D + jx] = t;
-      }
-    }
-  }
-}
-
 // update_weights + SGD::update (reference e.g. layers/dense_layer.hpp:102-112,
 // utils/optimizer.hpp:22-28):  g <- g * (1/divisor);  w <- w - g * lr.  Two roundings, as there.
 __global__ __launch_bounds__(TPB) void k_sgd(float *__restrict__ w, float *__restrict__ gr, int n, float lr,
@@ -490,48 +245,6 @@ extern "C" int vt_bn_bwd_finalize(const float *part, int nblocks, int C, long ro
   if (C < 1 || FIN_T % (2 * C) != 0 || nblocks < 1 || rows_total < 1) return VT_EUNSUPPORTED;
   hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(1), dim3(FIN_T), 0, (hipStream_t)s, part, nblocks, C, rows_total, gamma,
                      stat, in_row0, ggamma, gbeta, coef);
-  VT_CHECK_LAUNCH();
-  return 0;
-}
-
-// Token side of the projector backward; scratch >= ceil(rows/64) * 1552 floats.
-extern "C" int vt_projector_tokens_bwd(const float *o, const float *dv, const float *dk, const float *wv,
-                                       const float *wk, float *pdt, float *g_wk_wv_bv, float *scratch, long rows,
-                                       vt_stream s) {
-  if (rows < 1) return VT_EINVAL;
-  const int nb = (int)((rows + RB - 1) / RB);
-  hipLaunchKernelGGL(k_projtok_bwd, dim3(nb), dim3(TPB), 0, (hipStream_t)s, o, dv, dk, wv, wk, pdt, scratch, rows);
-  VT_CHECK_LAUNCH();
-  return reduce_rows(scratch, nb, PT_STRIDE, PT_STRIDE, g_wk_wv_bv, (hipStream_t)s);
-}
-
-extern "C" int vt_transformer_bwd_a(const float *o, const float *pdt, const float *s2, const float *n2_stat,
-                                    const float *tok_w2, float *part, float *dT0, long rows, vt_stream s) {
-  if (rows < 1) return VT_EINVAL;
-  const int nb = (int)((rows + RB - 1) / RB);
-  hipLaunchKernelGGL(k_tr_bwd_a, dim3(nb), dim3(TPB), 0, (hipStream_t)s, o, pdt, s2, n2_stat, tok_w2, part, dT0, rows);
-  VT_CHECK_LAUNCH();
-  return 0;
-}
-
-// g_ffn: gradient block [gW1 | gb1 | gW2 | gb2] (2112 floats, arena order); scratch >= nb*2112.
-extern "C" int vt_transformer_bwd_b(const float *o, const float *pdt, const float *n2_coef, const float *hdn,
-                                    const float *a, const float *tok, const float *n1_stat, const float *w1,
-                                    const float *w2, float *ds2, float *da, float *g_ffn, float *scratch, float *part,
-                                    long rows, vt_stream s) {
-  if (rows < 1) return VT_EINVAL;
-  const int nb = (int)((rows + RB - 1) / RB);
-  hipLaunchKernelGGL(k_tr_bwd_b, dim3(nb), dim3(TPB), 0, (hipStream_t)s, o, pdt, n2_coef, hdn, a, tok, n1_stat, w1, w2,
-                     ds2, da, scratch, part, rows);
-  VT_CHECK_LAUNCH();
-  return reduce_rows(scratch, nb, FF_STRIDE, FF_STRIDE, g_ffn, (hipStream_t)s);
-}
-
-extern "C" int vt_transformer_bwd_c(const float *da, const float *n1_coef, const float *wo, const float *tok,
-                                    const float *wqkv, float *dr, float *dc, float *qkv, long rows, vt_stream s) {
-  if (rows < 1) return VT_EINVAL;
-  const int nb = (int)((rows + RB - 1) / RB);
-  hipLaunchKernelGGL(k_tr_bwd_c, dim3(nb), dim3(TPB), 0, (hipStream_t)s, da, n1_coef, wo, tok, wqkv, dr, dc, qkv, rows);
   VT_CHECK_LAUNCH();
   return 0;
 }

@@ -164,136 +164,6 @@ __global__ void k_bn_stats_eval(const float *__restrict__ run_mean, const float 
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// TransformerLayer::forward (reference layers/transformer_layer.hpp:43-120) over the flat
-// [N*L, D] token matrix (Tensor::permute does not move data, tensor_cpu.hpp:719-747).
-// The attention branch is identically zero in the reference (Tensor::concat returns zeros,
-// tensor_cpu.hpp:251; no bias on the output projection), so residual = tokens.
-//   a = BN1(tok);  hdn = a.W1 + b1;  s2 = a + relu(hdn).W2 + b2   (+ partial stats of s2)
-// RB rows per workgroup; thread = (row, group of 8 columns); weights in LDS.
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(TPB) void k_tr_ffn_fwd(const float *__restrict__ tok, const float *__restrict__ st,
-                                                    const float *__restrict__ g, const float *__restrict__ b,
-                                                    const float *__restrict__ W1, const float *__restrict__ b1,
-                                                    const float *__restrict__ W2, const float *__restrict__ b2,
-                                                    float *__restrict__ a_out, float *__restrict__ hdn_out,
-                                                    float *__restrict__ s2_out, float *__restrict__ part_n2,
-                                                    long rows) {
-  __shared__ float sW1[D * D], sW2[D * D];
-  __shared__ float sa[RB][D + 1], sr[RB][D + 1];
-  const int tid = threadIdx.x, r = tid >> 2, cg = (tid & 3) * 8;
-  const long row = (long)blockIdx.x * RB + r;
-  const bool ok = row < rows;
-  for (int i = tid; i < D * D; i += TPB) {
-    sW1[i] = W1[i];
-    sW2[i] = W2[i];
-  }
-  float av[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int c = cg + j;
-    const float tv = ok ? tok[row * D + c] : 0.f;
-    av[j] = ((tv - st[c]) * st[D + c]) * g[c] + b[c];
-    sa[r][c] = av[j];
-    if (ok) a_out[row * D + c] = av[j];
-  }
-  __syncthreads();
-  float h[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) h[j] = 0.f;
-#pragma unroll 8
-  for (int i = 0; i < D; ++i) {
-    const float ai = sa[r][i];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) h[j] += ai * sW1[i * D + cg + j];
-  }
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    h[j] += b1[cg + j];
-    if (ok) hdn_out[row * D + cg + j] = h[j];
-    sr[r][cg + j] = h[j] > 0.f ? h[j] : 0.f;
-  }
-  __syncthreads();
-  float o[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) o[j] = 0.f;
-#pragma unroll 8
-  for (int i = 0; i < D; ++i) {
-    const float ri = sr[r][i];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] += ri * sW2[i * D + cg + j];
-  }
-  __syncthreads();
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const float v = av[j] + (o[j] + b2[cg + j]);
-    if (ok) s2_out[row * D + cg + j] = v;
-    sa[r][cg + j] = v;
-  }
-  __syncthreads();
-  if (tid < D && part_n2 != nullptr) {
-    const long left = rows - (long)blockIdx.x * RB;
-    const int cnt = left < RB ? (int)left : RB;
-    float s = 0.f;
-    for (int rr = 0; rr < cnt; ++rr) s += sa[rr][tid];
-    const float mu = s / (float)cnt;
-    float q = 0.f;
-    for (int rr = 0; rr < cnt; ++rr) {
-      const float dlt = sa[rr][tid] - mu;
-      q += dlt * dlt;
-    }
-    part_n2[(size_t)blockIdx.x * 2 * D + tid] = s;
-    part_n2[(size_t)blockIdx.x * 2 * D + D + tid] = q;
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Transformer output o = BN2(s2) and the token side of ProjectorLayer::forward
-// (reference layers/projector_layer.hpp:72-88): k = o.Wk, v = o.Wv + bv, plus the folded score
-// matrix Mq[c][l] = sum_d Wq[c][d] k[l][d], so that the per-pixel score x.Wq.k^T becomes x.Mq
-// (8 MACs per token instead of 8*32 + 32).  One workgroup per image, everything in LDS.
-// pk record per image: Mq[C1][L] | v[L][C2] | k[L][D].
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(TPB) void k_proj_tokens_fwd(const float *__restrict__ s2, const float *__restrict__ st,
-                                                         const float *__restrict__ g, const float *__restrict__ b,
-                                                         const float *__restrict__ Wq, const float *__restrict__ Wk,
-                                                         const float *__restrict__ Wv, const float *__restrict__ bv,
-                                                         float *__restrict__ o_out, float *__restrict__ pk) {
-  __shared__ float so[L][D + 1], sk[L][D + 1];
-  const int n = blockIdx.x, tid = threadIdx.x;
-  for (int i = tid; i < L * D; i += TPB) {
-    const int l = i / D, d = i % D;
-    const float v = ((s2[(size_t)n * L * D + i] - st[d]) * st[D + d]) * g[d] + b[d];
-    so[l][d] = v;
-    o_out[(size_t)n * L * D + i] = v;
-  }
-  __syncthreads();
-  float *rec = pk + (size_t)n * PK_STRIDE;
-  for (int i = tid; i < L * D; i += TPB) {
-    const int l = i / D, e = i % D;
-    float s = 0.f;
-#pragma unroll 8
-    for (int d = 0; d < D; ++d) s += so[l][d] * Wk[d * D + e];
-    sk[l][e] = s;
-    rec[C1 * L + L * C2 + i] = s;
-  }
-  for (int i = tid; i < L * C2; i += TPB) {
-    const int l = i / C2, c = i % C2;
-    float s = 0.f;
-#pragma unroll 8
-    for (int d = 0; d < D; ++d) s += so[l][d] * Wv[d * C2 + c];
-    rec[C1 * L + i] = s + bv[c];
-  }
-  __syncthreads();
-  for (int i = tid; i < C1 * L; i += TPB) {
-    const int c = i / L, l = i % L;
-    float s = 0.f;
-#pragma unroll 8
-    for (int d = 0; d < D; ++d) s += Wq[c * D + d] * sk[l][d];
-    rec[i] = s;
-  }
-}
-
 // Tensor::argmax_batch (first maximum, tensor_cpu.hpp:1294-1307) and the cross-entropy terms of
 // Tensor::compute_loss (tensor_cpu.hpp:1155-1173).  One workgroup; fixed order => reproducible.
 __global__ __launch_bounds__(TPB) void k_metrics(const float *__restrict__ probs, const int *__restrict__ labels, int N,
@@ -347,28 +217,6 @@ extern "C" int vt_bn_stats_finalize(const float *part, int nblocks, int C, long 
 extern "C" int vt_bn_stats_eval(const float *running_mean, const float *running_var, int C, float *stat, vt_stream s) {
   if (C < 1 || C > 64) return VT_EUNSUPPORTED;
   hipLaunchKernelGGL(k_bn_stats_eval, dim3(1), dim3(64), 0, (hipStream_t)s, running_mean, running_var, C, stat);
-  VT_CHECK_LAUNCH();
-  return 0;
-}
-
-extern "C" int vt_transformer_ffn_fwd(const float *tokens, const float *n1_stat, const float *n1_gamma,
-                                      const float *n1_beta, const float *w1, const float *b1, const float *w2,
-                                      const float *b2, float *a, float *hdn, float *s2, float *part_n2, long rows,
-                                      vt_stream s) {
-  if (rows < 1) return VT_EINVAL;
-  const int nb = (int)((rows + RB - 1) / RB);
-  hipLaunchKernelGGL(k_tr_ffn_fwd, dim3(nb), dim3(TPB), 0, (hipStream_t)s, tokens, n1_stat, n1_gamma, n1_beta, w1, b1,
-                     w2, b2, a, hdn, s2, part_n2, rows);
-  VT_CHECK_LAUNCH();
-  return 0;
-}
-
-extern "C" int vt_projector_tokens_fwd(const float *s2, const float *n2_stat, const float *n2_gamma,
-                                       const float *n2_beta, const float *wq, const float *wk, const float *wv,
-                                       const float *bv, float *o, float *pk, int N, vt_stream s) {
-  if (N < 1) return VT_EINVAL;
-  hipLaunchKernelGGL(k_proj_tokens_fwd, dim3(N), dim3(TPB), 0, (hipStream_t)s, s2, n2_stat, n2_gamma, n2_beta, wq, wk,
-                     wv, bv, o, pk);
   VT_CHECK_LAUNCH();
   return 0;
 }

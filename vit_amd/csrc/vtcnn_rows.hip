@@ -1,0 +1,638 @@
+// Token-row kernels of the VTCNN hot path on the gfx950 matrix cores: everything that works on
+// the flat [N*L, D] token matrix (transformer FFN forward / backward, the projector's token side,
+// the weight-gradient part of the attention backward).  D = 32, so every product is a 32-wide
+// contraction: v_mfma_f32_16x16x4_f32 tiles of 16 token rows, one tile per wave, weights loaded
+// once per wave as MFMA operands (they are 4 KB and live in L2).
+//
+// Layouts (lane = 16*g + j; see vtcnn_pix.hip for the instruction's register layout):
+//   T tile: lane j = token row, registers t[tt][v] = feature 16*tt + 4*g + v   ("D order": what
+//           an accumulator holds after D'[feature][row] products, and what two 16-byte loads at
+//           columns 4g and 16+4g of a row give).  It is the B operand of a product that
+//           contracts over features and keeps rows as columns, or, unchanged, the A operand of
+//           the same product with rows as output ROWS (which yields the N layout).
+//   N tile: lane j = feature (column j + 16*tile), registers = rows 4*g + v.  Operand of products
+//           that contract over rows (weight gradients).
+// Weight operands: for y = x.W (W row-major [in][ldw]) the A operand of output tile n0 is
+// W[(16*tt + 4*g + v)*ldw + n0 + j]; for dx = dy.W^T it is W[(i0 + j)*ldw + 16*tt + 4*g + v]
+// (one 16-byte load per tt).
+#include "vtcnn_common.h"
+
+namespace vt {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f4 mfma16(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f4 f4zero() { return f4{0.f, 0.f, 0.f, 0.f}; }
+
+__device__ __forceinline__ float gsum(float x) {  // over the four lane groups g
+  x += __shfl_xor(x, 16);
+  x += __shfl_xor(x, 32);
+  return x;
+}
+__device__ __forceinline__ float jsum(float x) {  // over the 16 lanes j of a group
+  x += __shfl_xor(x, 1);
+  x += __shfl_xor(x, 2);
+  x += __shfl_xor(x, 4);
+  x += __shfl_xor(x, 8);
+  return x;
+}
+
+struct Lane {
+  int j, g;
+  __device__ __forceinline__ Lane() : j(threadIdx.x & 15), g((threadIdx.x & 63) >> 4) {}
+};
+
+// T tile of a [rows][ld] matrix with 16*TT feature columns starting at col0; rows past nvalid are 0.
+template <int TT>
+struct TTile {
+  f4 t[TT];
+  __device__ __forceinline__ void load(const float *__restrict__ base, long row0, int nvalid, int ld, int col0, Lane ln) {
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt)
+      t[tt] = ln.j < nvalid ? *reinterpret_cast<const f4 *>(base + (row0 + ln.j) * ld + col0 + 16 * tt + 4 * ln.g) : f4zero();
+  }
+  __device__ __forceinline__ void store(float *__restrict__ base, long row0, int nvalid, int ld, int col0, Lane ln) const {
+    if (ln.j < nvalid) {
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) *reinterpret_cast<f4 *>(base + (row0 + ln.j) * ld + col0 + 16 * tt + 4 * ln.g) = t[tt];
+    }
+  }
+};
+
+// per-lane constants of a per-feature vector in D order: c[tt][v] = vec[16*tt + 4*g + v]
+template <int TT>
+__device__ __forceinline__ void load_fvec(const float *__restrict__ vec, f4 (&c)[TT], Lane ln) {
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt) c[tt] = *reinterpret_cast<const f4 *>(vec + 16 * tt + 4 * ln.g);
+}
+
+// A operand of y = x.W for output columns n0..n0+15 (W row-major [16*TT][ldw]); zero past ncols.
+template <int TT>
+__device__ __forceinline__ void load_w(const float *__restrict__ W, int ldw, int n0, int ncols, f4 (&a)[TT], Lane ln) {
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) a[tt][v] = (n0 + ln.j < ncols) ? W[(16 * tt + 4 * ln.g + v) * ldw + n0 + ln.j] : 0.f;
+}
+// A operand of dx = dy.W^T for output features i0..i0+15 (W row-major [..][ldw], 16*TT columns used from col0)
+template <int TT>
+__device__ __forceinline__ void load_wt(const float *__restrict__ W, int ldw, int i0, int nrows, int col0, f4 (&a)[TT], Lane ln) {
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt)
+    a[tt] = (i0 + ln.j < nrows) ? *reinterpret_cast<const f4 *>(W + (size_t)(i0 + ln.j) * ldw + col0 + 16 * tt + 4 * ln.g) : f4zero();
+}
+// acc[feature][row] += sum over the tile's features  a . x   (T layout out)
+template <int TT>
+__device__ __forceinline__ f4 mm_t(const f4 (&a)[TT], const f4 (&x)[TT], f4 acc) {
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) acc = mfma16(a[tt][v], x[tt][v], acc);
+  return acc;
+}
+// acc[row][feature] += the same product with the roles swapped (N layout out)
+template <int TT>
+__device__ __forceinline__ f4 mm_n(const f4 (&x)[TT], const f4 (&w)[TT], f4 acc) {
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) acc = mfma16(x[tt][v], w[tt][v], acc);
+  return acc;
+}
+// N tile from memory: n[v] = base[(row0 + 4g + v)*ld + col]; rows past nvalid are 0
+__device__ __forceinline__ f4 load_n(const float *__restrict__ base, long row0, int nvalid, int ld, int col, Lane ln) {
+  f4 n;
+#pragma unroll
+  for (int v = 0; v < 4; ++v) n[v] = (4 * ln.g + v < nvalid) ? base[(row0 + 4 * ln.g + v) * ld + col] : 0.f;
+  return n;
+}
+// acc[i][e] += sum over the 16 rows  a_n[i][row] . b_n[row][e]
+__device__ __forceinline__ f4 mm_rows(f4 a_n, f4 b_n, f4 acc) {
+#pragma unroll
+  for (int v = 0; v < 4; ++v) acc = mfma16(a_n[v], b_n[v], acc);
+  return acc;
+}
+
+// Sums a D tile (rows i = 4g+v, columns j) held by each of the NW waves and writes the workgroup
+// total to dst[i*ld + j] for i < ni, j < nj.  sbuf: NW*256 floats of LDS.  Ends with a barrier.
+__device__ __forceinline__ void block_tile_out(f4 acc, float *sbuf, float *__restrict__ dst, int ld, int ni, int nj) {
+  const int tid = threadIdx.x, wave = tid >> 6;
+  const Lane ln;
+  __syncthreads();
+#pragma unroll
+  for (int v = 0; v < 4; ++v) sbuf[wave * 256 + (4 * ln.g + v) * 16 + ln.j] = acc[v];
+  __syncthreads();
+  const int i = tid >> 4, jj = tid & 15;
+  if (i < ni && jj < nj) dst[i * ld + jj] = (sbuf[tid] + sbuf[256 + tid]) + (sbuf[512 + tid] + sbuf[768 + tid]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// TransformerLayer::forward (reference layers/transformer_layer.hpp:43-120) over the flat
+// [N*L, D] token matrix (Tensor::permute does not move data, tensor_cpu.hpp:719-747).
+// The attention branch is identically zero in the reference (Tensor::concat returns zeros,
+// tensor_cpu.hpp:251; no bias on the output projection), so residual = tokens.
+//   a = BN1(tok);  hdn = a.W1 + b1;  s2 = a + relu(hdn).W2 + b2   (+ partial stats of s2)
+// RB = 64 rows per workgroup = one 16-row tile per wave; 32 MFMAs per tile.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void k_tr_ffn_fwd(const float *__restrict__ tok, const float *__restrict__ st,
+                                                    const float *__restrict__ g, const float *__restrict__ b,
+                                                    const float *__restrict__ W1, const float *__restrict__ b1,
+                                                    const float *__restrict__ W2, const float *__restrict__ b2,
+                                                    float *__restrict__ a_out, float *__restrict__ hdn_out,
+                                                    float *__restrict__ s2_out, float *__restrict__ part_n2,
+                                                    long rows) {
+  __shared__ float sred[NW][D];
+  const Lane ln;
+  const int wave = threadIdx.x >> 6;
+  const long row0 = ((long)blockIdx.x * NW + wave) * 16;
+  const int nv = (int)max(0L, min(16L, rows - row0));
+  f4 mean[2], inv[2], gam[2], bet[2], bb1[2], bb2[2];
+  load_fvec<2>(st, mean, ln);
+  load_fvec<2>(st + D, inv, ln);
+  load_fvec<2>(g, gam, ln);
+  load_fvec<2>(b, bet, ln);
+  load_fvec<2>(b1, bb1, ln);
+  load_fvec<2>(b2, bb2, ln);
+  TTile<2> x;
+  x.load(tok, row0, nv, D, 0, ln);
+  TTile<2> a;
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) a.t[tt][v] = ((x.t[tt][v] - mean[tt][v]) * inv[tt][v]) * gam[tt][v] + bet[tt][v];
+  a.store(a_out, row0, nv, D, 0, ln);
+  TTile<2> h, r, s2;
+#pragma unroll
+  for (int to = 0; to < 2; ++to) {
+    f4 w[2];
+    load_w<2>(W1, D, 16 * to, D, w, ln);
+    h.t[to] = mm_t<2>(w, a.t, bb1[to]);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) r.t[to][v] = h.t[to][v] > 0.f ? h.t[to][v] : 0.f;
+  }
+  h.store(hdn_out, row0, nv, D, 0, ln);
+#pragma unroll
+  for (int to = 0; to < 2; ++to) {
+    f4 w[2];
+    load_w<2>(W2, D, 16 * to, D, w, ln);
+    const f4 o = mm_t<2>(w, r.t, bb2[to]);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) s2.t[to][v] = a.t[to][v] + o[v];
+  }
+  s2.store(s2_out, row0, nv, D, 0, ln);
+  if (part_n2 == nullptr) return;
+  // per-workgroup (sum, centred M2) of s2 per feature over the workgroup's valid rows
+  const long left = rows - (long)blockIdx.x * RB;
+  const float cnt = (float)(left < RB ? left : RB);
+  const bool ok = ln.j < nv;
+  f4 sm[2];
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) sm[tt][v] = jsum(ok ? s2.t[tt][v] : 0.f);
+  if (ln.j == 0) {
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) sred[wave][16 * tt + 4 * ln.g + v] = sm[tt][v];
+  }
+  __syncthreads();
+  f4 mu[2];
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int f = 16 * tt + 4 * ln.g + v;
+      sm[tt][v] = (sred[0][f] + sred[1][f]) + (sred[2][f] + sred[3][f]);
+      mu[tt][v] = sm[tt][v] / cnt;
+    }
+  __syncthreads();
+  f4 q[2];
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const float dlt = s2.t[tt][v] - mu[tt][v];
+      q[tt][v] = jsum(ok ? dlt * dlt : 0.f);
+    }
+  if (ln.j == 0) {
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) sred[wave][16 * tt + 4 * ln.g + v] = q[tt][v];
+  }
+  __syncthreads();
+  if (threadIdx.x < D) {
+    const int f = threadIdx.x;
+    // every lane holds the workgroup sums of its own features; lanes (wave 0, j == 0) write them
+    part_n2[(size_t)blockIdx.x * 2 * D + D + f] = (sred[0][f] + sred[1][f]) + (sred[2][f] + sred[3][f]);
+  }
+  if (wave == 0 && ln.j == 0) {
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) part_n2[(size_t)blockIdx.x * 2 * D + 16 * tt + 4 * ln.g + v] = sm[tt][v];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Transformer output o = BN2(s2) and the token side of ProjectorLayer::forward
+// (reference layers/projector_layer.hpp:72-88): k = o.Wk, v = o.Wv + bv, plus the folded score
+// matrix Mq[c][l] = sum_d Wq[c][d] k[l][d], so that the per-pixel score x.Wq.k^T becomes x.Mq
+// (8 MACs per token instead of 8*32 + 32).  The L = 16 tokens of a sample are exactly one tile:
+// one wave per image.  pk record per image: Mq[C1][L] | v[L][C2] | k[L][D].
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void k_proj_tokens_fwd(const float *__restrict__ s2, const float *__restrict__ st,
+                                                         const float *__restrict__ g, const float *__restrict__ b,
+                                                         const float *__restrict__ Wq, const float *__restrict__ Wk,
+                                                         const float *__restrict__ Wv, const float *__restrict__ bv,
+                                                         float *__restrict__ o_out, float *__restrict__ pk, int N) {
+  static_assert(L == 16, "one 16-row tile per image");
+  const Lane ln;
+  const int n = blockIdx.x * NW + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const long row0 = (long)n * L;
+  f4 mean[2], inv[2], gam[2], bet[2];
+  load_fvec<2>(st, mean, ln);
+  load_fvec<2>(st + D, inv, ln);
+  load_fvec<2>(g, gam, ln);
+  load_fvec<2>(b, bet, ln);
+  TTile<2> x, o;
+  x.load(s2, row0, 16, D, 0, ln);
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) o.t[tt][v] = ((x.t[tt][v] - mean[tt][v]) * inv[tt][v]) * gam[tt][v] + bet[tt][v];
+  o.store(o_out, row0, 16, D, 0, ln);
+  float *rec = pk + (size_t)n * PK_STRIDE;
+  TTile<2> k;
+#pragma unroll
+  for (int to = 0; to < 2; ++to) {
+    f4 w[2];
+    load_w<2>(Wk, D, 16 * to, D, w, ln);
+    k.t[to] = mm_t<2>(w, o.t, f4zero());
+  }
+  k.store(rec + C1 * L + L * C2, 0, 16, D, 0, ln);
+  {
+    f4 w[2], bias;
+    load_w<2>(Wv, C2, 0, C2, w, ln);
+    bias = *reinterpret_cast<const f4 *>(bv + 4 * ln.g);
+    TTile<1> v;
+    v.t[0] = mm_t<2>(w, o.t, bias);
+    v.store(rec + C1 * L, 0, 16, C2, 0, ln);
+  }
+  {
+    // Mq[c][l]: A = Wq rows c (8 of the 16 output rows are used), B = k in T layout
+    f4 w[2];
+    load_wt<2>(Wq, D, 0, C1, 0, w, ln);
+    const f4 mq = mm_t<2>(w, k.t, f4zero());
+    if (ln.g < 2) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) rec[(4 * ln.g + v) * L + ln.j] = mq[v];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// ProjectorLayer::backward, token side (reference projector_layer.hpp:186-202): Dense backward of
+// linear3 (values) and linear2 (keys) over the N*L token rows.
+//   gWv = o^T dv, gbv = sum dv, gWk = o^T dk, token delta = dv.Wv^T + dk.Wk^T
+// Per-workgroup partials: gWk[D*D] | gWv[D*C2] | gbv[C2]  (PT_STRIDE floats), summed afterwards.
+// ---------------------------------------------------------------------------------------------
+constexpr int PT_STRIDE = D * D + D * C2 + C2;  // 1552
+__global__ __launch_bounds__(TPB) void k_projtok_bwd(const float *__restrict__ o, const float *__restrict__ dv,
+                                                     const float *__restrict__ dk, const float *__restrict__ Wv,
+                                                     const float *__restrict__ Wk, float *__restrict__ pdt,
+                                                     float *__restrict__ scratch, long rows) {
+  __shared__ float sbuf[NW * 256];
+  const Lane ln;
+  const int wave = threadIdx.x >> 6;
+  const long row0 = ((long)blockIdx.x * NW + wave) * 16;
+  const int nv = (int)max(0L, min(16L, rows - row0));
+  // token delta, T layout
+  TTile<1> dvt;
+  TTile<2> dkt, out;
+  dvt.load(dv, row0, nv, C2, 0, ln);
+  dkt.load(dk, row0, nv, D, 0, ln);
+#pragma unroll
+  for (int to = 0; to < 2; ++to) {
+    f4 wv[1], wk[2];
+    load_wt<1>(Wv, C2, 16 * to, D, 0, wv, ln);
+    load_wt<2>(Wk, D, 16 * to, D, 0, wk, ln);
+    out.t[to] = mm_t<2>(wk, dkt.t, mm_t<1>(wv, dvt.t, f4zero()));
+  }
+  out.store(pdt, row0, nv, D, 0, ln);
+  // weight gradients: contraction over the tile's rows, N-layout operands from memory
+  f4 on[2], dkn[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    on[t] = load_n(o, row0, nv, D, ln.j + 16 * t, ln);
+    dkn[t] = load_n(dk, row0, nv, D, ln.j + 16 * t, ln);
+  }
+  const f4 dvn = load_n(dv, row0, nv, C2, ln.j, ln);
+  float *row = scratch + (size_t)blockIdx.x * PT_STRIDE;
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti) {
+#pragma unroll
+    for (int te = 0; te < 2; ++te)
+      block_tile_out(mm_rows(on[ti], dkn[te], f4zero()), sbuf, row + (16 * ti) * D + 16 * te, D, 16, 16);
+    block_tile_out(mm_rows(on[ti], dvn, f4zero()), sbuf, row + D * D + (16 * ti) * C2, C2, 16, 16);
+  }
+  {
+    const float s = gsum((dvn[0] + dvn[1]) + (dvn[2] + dvn[3]));  // lane j: sum over the tile's rows of dv[.][j]
+    __syncthreads();
+    if (ln.g == 0) sbuf[wave * 16 + ln.j] = s;
+    __syncthreads();
+    if (threadIdx.x < C2) row[D * D + D * C2 + threadIdx.x] = (sbuf[threadIdx.x] + sbuf[16 + threadIdx.x]) + (sbuf[32 + threadIdx.x] + sbuf[48 + threadIdx.x]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// TransformerLayer::backward, step A (reference layers/transformer_layer.hpp:142-161):
+//   d0 = last_output - targets  with targets = projector token delta (visual_transformer.hpp:156-157)
+//   partial sums of the second BatchNorm1D backward.
+// Also the tokenizer's linear2 input delta dT0 = token_delta . W2tok^T (tokenizer.hpp:73-75), which
+// reads the same rows.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void k_tr_bwd_a(const float *__restrict__ o, const float *__restrict__ pdt,
+                                                  const float *__restrict__ s2, const float *__restrict__ st2,
+                                                  const float *__restrict__ W2tok, float *__restrict__ part,
+                                                  float *__restrict__ dT0, long rows) {
+  __shared__ float sred[NW][2 * D];
+  const Lane ln;
+  const int wave = threadIdx.x >> 6;
+  const long row0 = ((long)blockIdx.x * NW + wave) * 16;
+  const int nv = (int)max(0L, min(16L, rows - row0));
+  f4 mean[2], inv[2];
+  load_fvec<2>(st2, mean, ln);
+  load_fvec<2>(st2 + D, inv, ln);
+  TTile<2> ot, pt, xt;
+  ot.load(o, row0, nv, D, 0, ln);
+  pt.load(pdt, row0, nv, D, 0, ln);
+  xt.load(s2, row0, nv, D, 0, ln);
+  const bool ok = ln.j < nv;
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const float d0 = ok ? ot.t[tt][v] - pt.t[tt][v] : 0.f;
+      const float xh = (xt.t[tt][v] - mean[tt][v]) * inv[tt][v];
+      const float s1 = jsum(d0), s2v = jsum(ok ? d0 * xh : 0.f);
+      if (ln.j == 0) {
+        sred[wave][16 * tt + 4 * ln.g + v] = s1;
+        sred[wave][D + 16 * tt + 4 * ln.g + v] = s2v;
+      }
+    }
+  {
+    // dT0[row][c] = sum_d pdt[row][d] W2tok[c][d]: 8 output features
+    f4 w[2];
+    load_wt<2>(W2tok, D, 0, C1, 0, w, ln);
+    const f4 r = mm_t<2>(w, pt.t, f4zero());
+    if (ok && ln.g < 2) *reinterpret_cast<f4 *>(dT0 + (row0 + ln.j) * C1 + 4 * ln.g) = r;
+  }
+  __syncthreads();
+  if (threadIdx.x < 2 * D) {
+    const int f = threadIdx.x;
+    part[(size_t)blockIdx.x * 2 * D + f] = (sred[0][f] + sred[1][f]) + (sred[2][f] + sred[3][f]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// TransformerLayer::backward, step B (reference transformer_layer.hpp:161-189):
+//   ds2 = BN2.backward(d0);  linear2 backward (its cached input is relu(hdn));
+//   linear1 backward WITHOUT the ReLU derivative (:174-181);  da = dh.W1^T + ds2;
+//   partial sums of the first BatchNorm1D backward.
+// Per-workgroup partials: gW1[D*D] | gb1[D] | gW2[D*D] | gb2[D]  (FF_STRIDE, arena order).
+// dh is produced twice, in T layout (feeds da) and in N layout (feeds gW1), by the same MFMAs with
+// the operand roles swapped; nothing is transposed through memory.
+// ---------------------------------------------------------------------------------------------
+constexpr int FF_STRIDE = 2 * (D * D + D);  // 2112
+__global__ __launch_bounds__(TPB) void k_tr_bwd_b(const float *__restrict__ o, const float *__restrict__ pdt,
+                                                  const float *__restrict__ coef2, const float *__restrict__ hdn,
+                                                  const float *__restrict__ a, const float *__restrict__ tok,
+                                                  const float *__restrict__ st1, const float *__restrict__ W1,
+                                                  const float *__restrict__ W2, float *__restrict__ ds2_out,
+                                                  float *__restrict__ da_out, float *__restrict__ scratch,
+                                                  float *__restrict__ part, long rows) {
+  __shared__ float sbuf[NW * 256];
+  __shared__ float sred[NW][2 * D];
+  const Lane ln;
+  const int wave = threadIdx.x >> 6;
+  const long row0 = ((long)blockIdx.x * NW + wave) * 16;
+  const int nv = (int)max(0L, min(16L, rows - row0));
+  const bool ok = ln.j < nv;
+  f4 c0[2], c1[2];
+  load_fvec<2>(coef2, c0, ln);
+  load_fvec<2>(coef2 + D, c1, ln);
+  TTile<2> ot, pt, ds2;
+  ot.load(o, row0, nv, D, 0, ln);
+  pt.load(pdt, row0, nv, D, 0, ln);
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) ds2.t[tt][v] = ok ? (ot.t[tt][v] - pt.t[tt][v]) * c0[tt][v] + c1[tt][v] : 0.f;
+  ds2.store(ds2_out, row0, nv, D, 0, ln);
+  // dh = ds2 . W2^T in both layouts; da = dh . W1^T + ds2
+  TTile<2> dh, da;
+  f4 dhn[2];
+#pragma unroll
+  for (int to = 0; to < 2; ++to) {
+    f4 w[2];
+    load_wt<2>(W2, D, 16 * to, D, 0, w, ln);
+    dh.t[to] = mm_t<2>(w, ds2.t, f4zero());
+    dhn[to] = mm_n<2>(ds2.t, w, f4zero());
+  }
+#pragma unroll
+  for (int to = 0; to < 2; ++to) {
+    f4 w[2];
+    load_wt<2>(W1, D, 16 * to, D, 0, w, ln);
+    da.t[to] = mm_t<2>(w, dh.t, ds2.t[to]);
+  }
+  da.store(da_out, row0, nv, D, 0, ln);
+  // partial sums of the first BatchNorm1D backward: sum da, sum da * xhat(tok)
+  {
+    f4 mean[2], inv[2];
+    load_fvec<2>(st1, mean, ln);
+    load_fvec<2>(st1 + D, inv, ln);
+    TTile<2> xt;
+    xt.load(tok, row0, nv, D, 0, ln);
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const float dv = ok ? da.t[tt][v] : 0.f;
+        const float xh = (xt.t[tt][v] - mean[tt][v]) * inv[tt][v];
+        const float s1 = jsum(dv), s2v = jsum(ok ? dv * xh : 0.f);
+        if (ln.j == 0) {
+          sred[wave][16 * tt + 4 * ln.g + v] = s1;
+          sred[wave][D + 16 * tt + 4 * ln.g + v] = s2v;
+        }
+      }
+  }
+  // weight gradients over the tile's rows (N-layout operands: lane = feature, registers = rows)
+  f4 an[2], rn[2], dsn[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int col = ln.j + 16 * t;
+    an[t] = load_n(a, row0, nv, D, col, ln);
+    const f4 hn = load_n(hdn, row0, nv, D, col, ln);
+    const f4 on = load_n(o, row0, nv, D, col, ln), pn = load_n(pdt, row0, nv, D, col, ln);
+    const float k0 = coef2[col], k1 = coef2[D + col];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      rn[t][v] = hn[v] > 0.f ? hn[v] : 0.f;
+      dsn[t][v] = (4 * ln.g + v < nv) ? (on[v] - pn[v]) * k0 + k1 : 0.f;
+    }
+  }
+  float *row = scratch + (size_t)blockIdx.x * FF_STRIDE;
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+    for (int te = 0; te < 2; ++te) {
+      block_tile_out(mm_rows(an[ti], dhn[te], f4zero()), sbuf, row + (16 * ti) * D + 16 * te, D, 16, 16);               // gW1 = a^T dh
+      block_tile_out(mm_rows(rn[ti], dsn[te], f4zero()), sbuf, row + D * D + D + (16 * ti) * D + 16 * te, D, 16, 16);   // gW2 = relu(hdn)^T ds2
+    }
+  {
+    float sb1[2], sb2[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      sb1[t] = gsum((dhn[t][0] + dhn[t][1]) + (dhn[t][2] + dhn[t][3]));  // gb1[j+16t] over the tile's rows
+      sb2[t] = gsum((dsn[t][0] + dsn[t][1]) + (dsn[t][2] + dsn[t][3]));  // gb2
+    }
+    __syncthreads();
+    if (ln.g == 0) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        sbuf[wave * 64 + 16 * t + ln.j] = sb1[t];
+        sbuf[wave * 64 + 32 + 16 * t + ln.j] = sb2[t];
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * D) {
+      const int f = threadIdx.x;
+      const float s = (sbuf[f] + sbuf[64 + f]) + (sbuf[128 + f] + sbuf[192 + f]);
+      if (f < D) row[D * D + f] = s;
+      else row[2 * D * D + D + (f - D)] = s;
+      part[(size_t)blockIdx.x * 2 * D + f] = (sred[0][f] + sred[1][f]) + (sred[2][f] + sred[3][f]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// TransformerLayer::backward, step C (reference transformer_layer.hpp:189-200 and the first part
+// of MultiHeadAttention::backward, multi_head_attention.hpp:131-152):
+//   dr = BN1.backward(da);  dc = dr . Wo^T  (delta of the zero "concat");
+//   per head q = X.Wq, k = X.Wk, v = X.Wv recomputed from the layer input X = token rows.
+// qkv layout: three [rows][D] matrices (q | k | v), head h in columns h*HD..h*HD+HD-1.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void k_tr_bwd_c(const float *__restrict__ da, const float *__restrict__ coef1,
+                                                  const float *__restrict__ Wo, const float *__restrict__ tok,
+                                                  const float *__restrict__ Wqkv, float *__restrict__ dr_out,
+                                                  float *__restrict__ dc, float *__restrict__ qkv, long rows) {
+  static_assert(HD == 16, "one output tile per head");
+  const Lane ln;
+  const int wave = threadIdx.x >> 6;
+  const long row0 = ((long)blockIdx.x * NW + wave) * 16;
+  const int nv = (int)max(0L, min(16L, rows - row0));
+  if (nv == 0) return;
+  f4 c0[2], c1[2];
+  load_fvec<2>(coef1, c0, ln);
+  load_fvec<2>(coef1 + D, c1, ln);
+  TTile<2> dat, dr, x;
+  dat.load(da, row0, nv, D, 0, ln);
+  x.load(tok, row0, nv, D, 0, ln);
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) dr.t[tt][v] = dat.t[tt][v] * c0[tt][v] + c1[tt][v];
+  dr.store(dr_out, row0, nv, D, 0, ln);
+  TTile<2> out;
+#pragma unroll
+  for (int to = 0; to < 2; ++to) {
+    f4 w[2];
+    load_wt<2>(Wo, D, 16 * to, D, 0, w, ln);
+    out.t[to] = mm_t<2>(w, dr.t, f4zero());
+  }
+  out.store(dc, row0, nv, D, 0, ln);
+  // arena order of the six per-head matrices: q0,k0,v0,q1,k1,v1, each [D][HD]
+#pragma unroll
+  for (int m = 0; m < 3; ++m) {
+#pragma unroll
+    for (int h = 0; h < HEADS; ++h) {
+      f4 w[2];
+      load_w<2>(Wqkv + (size_t)(h * 3 + m) * D * HD, HD, 0, HD, w, ln);
+      out.t[h] = mm_t<2>(w, x.t, f4zero());
+    }
+    out.store(qkv + (size_t)m * rows * D, row0, nv, D, 0, ln);
+  }
+}
+
+}  // namespace vt
+
+// ---------------------------------------------------------------------------------------------
+// extern "C" launchers
+// ---------------------------------------------------------------------------------------------
+using namespace vt;
+
+extern "C" int vt_transformer_ffn_fwd(const float *tokens, const float *n1_stat, const float *n1_gamma,
+                                      const float *n1_beta, const float *w1, const float *b1, const float *w2,
+                                      const float *b2, float *a, float *hdn, float *s2, float *part_n2, long rows,
+                                      vt_stream s) {
+  if (rows < 1) return VT_EINVAL;
+  const int nb = (int)((rows + RB - 1) / RB);
+  hipLaunchKernelGGL(k_tr_ffn_fwd, dim3(nb), dim3(TPB), 0, (hipStream_t)s, tokens, n1_stat, n1_gamma, n1_beta, w1, b1,
+                     w2, b2, a, hdn, s2, part_n2, rows);
+  VT_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int vt_projector_tokens_fwd(const float *s2, const float *n2_stat, const float *n2_gamma,
+                                       const float *n2_beta, const float *wq, const float *wk, const float *wv,
+                                       const float *bv, float *o, float *pk, int N, vt_stream s) {
+  if (N < 1) return VT_EINVAL;
+  hipLaunchKernelGGL(k_proj_tokens_fwd, dim3((N + NW - 1) / NW), dim3(TPB), 0, (hipStream_t)s, s2, n2_stat, n2_gamma,
+                     n2_beta, wq, wk, wv, bv, o, pk, N);
+  VT_CHECK_LAUNCH();
+  return 0;
+}
+
+// Token side of the projector backward; scratch >= ceil(rows/64) * 1552 floats.
+extern "C" int vt_projector_tokens_bwd(const float *o, const float *dv, const float *dk, const float *wv,
+                                       const float *wk, float *pdt, float *g_wk_wv_bv, float *scratch, long rows,
+                                       vt_stream s) {
+  if (rows < 1) return VT_EINVAL;
+  const int nb = (int)((rows + RB - 1) / RB);
+  hipLaunchKernelGGL(k_projtok_bwd, dim3(nb), dim3(TPB), 0, (hipStream_t)s, o, dv, dk, wv, wk, pdt, scratch, rows);
+  VT_CHECK_LAUNCH();
+  return reduce_rows(scratch, nb, PT_STRIDE, PT_STRIDE, g_wk_wv_bv, (hipStream_t)s);
+}
+
+extern "C" int vt_transformer_bwd_a(const float *o, const float *pdt, const float *s2, const float *n2_stat,
+                                    const float *tok_w2, float *part, float *dT0, long rows, vt_stream s) {
+  if (rows < 1) return VT_EINVAL;
+  const int nb = (int)((rows + RB - 1) / RB);
+  hipLaunchKernelGGL(k_tr_bwd_a, dim3(nb), dim3(TPB), 0, (hipStream_t)s, o, pdt, s2, n2_stat, tok_w2, part, dT0, rows);
+  VT_CHECK_LAUNCH();
+  return 0;
+}
+
+// g_ffn: gradient block [gW1 | gb1 | gW2 | gb2] (2112 floats, arena order); scratch >= nb*2112.
+extern "C" int vt_transformer_bwd_b(const float *o, const float *pdt, const float *n2_coef, const float *hdn,
+                                    const float *a, const float *tok, const float *n1_stat, const float *w1,
+                                    const float *w2, float *ds2, float *da, float *g_ffn, float *scratch, float *part,
+                                    long rows, vt_stream s) {
+  if (rows < 1) return VT_EINVAL;
+  const int nb = (int)((rows + RB - 1) / RB);
+  hipLaunchKernelGGL(k_tr_bwd_b, dim3(nb), dim3(TPB), 0, (hipStream_t)s, o, pdt, n2_coef, hdn, a, tok, n1_stat, w1, w2,
+                     ds2, da, scratch, part, rows);
+  VT_CHECK_LAUNCH();
+  return reduce_rows(scratch, nb, FF_STRIDE, FF_STRIDE, g_ffn, (hipStream_t)s);
+}
+
+extern "C" int vt_transformer_bwd_c(const float *da, const float *n1_coef, const float *wo, const float *tok,
+                                    const float *wqkv, float *dr, float *dc, float *qkv, long rows, vt_stream s) {
+  if (rows < 1) return VT_EINVAL;
+  const int nb = (int)((rows + RB - 1) / RB);
+  hipLaunchKernelGGL(k_tr_bwd_c, dim3(nb), dim3(TPB), 0, (hipStream_t)s, da, n1_coef, wo, tok, wqkv, dr, dc, qkv, rows);
+  VT_CHECK_LAUNCH();
+  return 0;
+}
