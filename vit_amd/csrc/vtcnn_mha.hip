@@ -203,73 +203,125 @@ __global__ __launch_bounds__(64 * MR_WAVES) void k_mha_rows(const float *__restr
 
 // Merges the splits (Y = Y~/s, Z = W~/s - (t/s) Y) and forms, over a block of RB rows of one head,
 //   gq = Z^T K,  gk = X^T (Z Wq),  gv = Y^T dhead.
+// One 16-row tile per wave, v_mfma_f32_16x16x4_f32.  The three products contract over rows, so
+// their operands are wanted with the feature on the lane and the rows in registers: that is how
+// yz is stored (row index fastest), one 16-byte load per feature and split.  dK = Z.Wq contracts
+// over features instead and takes Z with the row on the lane (plain coalesced loads of the same
+// array); with Z as the A operand its result lands in the registers-are-rows layout that gk needs.
+typedef float f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f4 mfma16(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
 __global__ __launch_bounds__(TPB) void k_mha_wgrad(const float *__restrict__ yz, const float *__restrict__ st,
                                                    const float *__restrict__ qkv, const float *__restrict__ dc,
                                                    const float *__restrict__ tok, const float *__restrict__ Wqkv,
                                                    float *__restrict__ slab, long rows, int nsplit) {
-  __shared__ float sY[D][RB + 1], sZ[D][RB + 1], sX[RB][D + 1];
-  __shared__ float sK[RB][HD + 1], sdH[RB][HD + 1], sdK[RB][HD + 1], sWq[D * HD];
-  __shared__ float sInv[RB], sDot[RB];
-  const int tid = threadIdx.x, h = blockIdx.y;
-  const long r0 = (long)blockIdx.x * RB;
-  const int cnt = (int)min((long)RB, rows - r0);
+  __shared__ float sbuf[NW * 256];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4, h = blockIdx.y;
+  const long row0 = ((long)blockIdx.x * NW + wave) * 16;
+  const int nv = (int)max(0L, min(16L, rows - row0));
   const float *__restrict__ Km = qkv + rows * D;
-  if (tid < RB) {
-    float s = 0.f, t = 0.f;
-    if (tid < cnt)
-      for (int sp = 0; sp < nsplit; ++sp) {
-        s += st[(((size_t)h * nsplit + sp) * 2 + 0) * rows + r0 + tid];
-        t += st[(((size_t)h * nsplit + sp) * 2 + 1) * rows + r0 + tid];
+  const f4 zero = {0.f, 0.f, 0.f, 0.f};
+  // per-row softmax normalisers: for the registers-are-rows operands (rows 4g+v) and for row j
+  f4 inv4 = zero, dot4 = zero;
+  float invj = 0.f, dotj = 0.f;
+  {
+    f4 s4 = zero, t4 = zero;
+    float sj = 0.f, tj = 0.f;
+    for (int sp = 0; sp < nsplit; ++sp) {
+      const float *s0 = st + (((size_t)h * nsplit + sp) * 2 + 0) * rows, *s1 = s0 + rows;
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        if (4 * g + v < nv) {
+          s4[v] += s0[row0 + 4 * g + v];
+          t4[v] += s1[row0 + 4 * g + v];
+        }
+      if (j < nv) {
+        sj += s0[row0 + j];
+        tj += s1[row0 + j];
       }
-    const float inv = tid < cnt ? 1.0f / s : 0.f;
-    sInv[tid] = inv;
-    sDot[tid] = t * inv;
-  }
-  for (int idx = tid; idx < RB * D; idx += TPB) {
-    const int r = idx / D, d = idx % D;
-    sX[r][d] = r < cnt ? tok[(r0 + r) * D + d] : 0.f;
-  }
-  for (int idx = tid; idx < RB * HD; idx += TPB) {
-    const int r = idx / HD, e = idx % HD;
-    const bool ok = r < cnt;
-    sK[r][e] = ok ? Km[(r0 + r) * D + h * HD + e] : 0.f;
-    sdH[r][e] = ok ? dc[(r0 + r) * D + h * HD + e] : 0.f;
-  }
-  for (int idx = tid; idx < D * HD; idx += TPB) sWq[idx] = Wqkv[(size_t)(h * 3 + 0) * D * HD + idx];
-  __syncthreads();
-  for (int idx = tid; idx < D * RB; idx += TPB) {
-    const int d = idx / RB, r = idx % RB;
-    float y = 0.f, w = 0.f;
-    if (r < cnt)
-      for (int sp = 0; sp < nsplit; ++sp) {
-        y += yz[((((size_t)h * nsplit + sp) * 2 + 0) * D + d) * rows + r0 + r];
-        w += yz[((((size_t)h * nsplit + sp) * 2 + 1) * D + d) * rows + r0 + r];
-      }
-    y *= sInv[r];
-    sY[d][r] = y;
-    sZ[d][r] = w * sInv[r] - sDot[r] * y;
-  }
-  __syncthreads();
-  for (int idx = tid; idx < RB * HD; idx += TPB) {  // dK = Z . Wq_h
-    const int r = idx / HD, e = idx % HD;
-    float s = 0.f;
-#pragma unroll 8
-    for (int d = 0; d < D; ++d) s += sZ[d][r] * sWq[d * HD + e];
-    sdK[r][e] = s;
-  }
-  __syncthreads();
-  float *row = slab + ((size_t)h * gridDim.x + blockIdx.x) * MH_STRIDE;
-  for (int idx = tid; idx < D * HD; idx += TPB) {
-    const int d = idx / HD, e = idx % HD;
-    float gq = 0.f, gk = 0.f, gv = 0.f;
-    for (int r = 0; r < RB; ++r) {
-      gq += sZ[d][r] * sK[r][e];
-      gk += sX[r][d] * sdK[r][e];
-      gv += sY[d][r] * sdH[r][e];
     }
-    row[idx] = gq;
-    row[D * HD + idx] = gk;
-    row[2 * D * HD + idx] = gv;
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+      if (4 * g + v < nv) {
+        inv4[v] = 1.0f / s4[v];
+        dot4[v] = t4[v] * inv4[v];
+      }
+    if (j < nv) {
+      invj = 1.0f / sj;
+      dotj = tj * invj;
+    }
+  }
+  // Y, Z with the feature on the lane (feature j + 16t, rows 4g+v), and Z with the row on the lane
+  f4 yn[2], zn[2], zt[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    f4 y = zero, w = zero;
+    for (int sp = 0; sp < nsplit; ++sp) {
+      const float *yb = yz + ((((size_t)h * nsplit + sp) * 2 + 0) * D + (j + 16 * t)) * rows + row0 + 4 * g;
+      const float *wb = yb + (size_t)D * rows;
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        if (4 * g + v < nv) {
+          y[v] += yb[v];
+          w[v] += wb[v];
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      yn[t][v] = y[v] * inv4[v];
+      zn[t][v] = w[v] * inv4[v] - dot4[v] * yn[t][v];
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      float y1 = 0.f, w1 = 0.f;
+      if (j < nv)
+        for (int sp = 0; sp < nsplit; ++sp) {
+          const size_t o = ((((size_t)h * nsplit + sp) * 2 + 0) * D + (16 * t + 4 * g + v)) * rows + row0 + j;
+          y1 += yz[o];
+          w1 += yz[o + (size_t)D * rows];
+        }
+      y1 *= invj;
+      zt[t][v] = w1 * invj - dotj * y1;
+    }
+  }
+  // dK[row][e] = sum_d Z[d][row] Wq[d][e]  (rows in registers)
+  f4 dkn = zero;
+  {
+    const float *__restrict__ Wq = Wqkv + (size_t)(h * 3 + 0) * D * HD;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) dkn = mfma16(zt[t][v], Wq[(16 * t + 4 * g + v) * HD + j], dkn);
+  }
+  f4 kn, dhn, xn[2];
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    const bool ok = 4 * g + v < nv;
+    const long r = row0 + 4 * g + v;
+    kn[v] = ok ? Km[r * D + h * HD + j] : 0.f;
+    dhn[v] = ok ? dc[r * D + h * HD + j] : 0.f;
+    xn[0][v] = ok ? tok[r * D + j] : 0.f;
+    xn[1][v] = ok ? tok[r * D + 16 + j] : 0.f;
+  }
+  float *row = slab + ((size_t)h * gridDim.x + blockIdx.x) * MH_STRIDE;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    f4 gq = zero, gk = zero, gv = zero;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      gq = mfma16(zn[t][v], kn[v], gq);
+      gk = mfma16(xn[t][v], dkn[v], gk);
+      gv = mfma16(yn[t][v], dhn[v], gv);
+    }
+    const f4 acc[3] = {gq, gk, gv};
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      __syncthreads();
+#pragma unroll
+      for (int v = 0; v < 4; ++v) sbuf[wave * 256 + (4 * g + v) * 16 + j] = acc[m][v];
+      __syncthreads();
+      row[m * D * HD + (16 * t) * HD + tid] = (sbuf[tid] + sbuf[256 + tid]) + (sbuf[512 + tid] + sbuf[768 + tid]);
+    }
   }
 }
 
