@@ -147,7 +147,7 @@ int vt_bn_stats_eval(const float *running_mean, const float *running_var, int C,
  * (layers/tokenizer.hpp:22-48).  Writes tokens [N*L,D], the per-sample softmax statistics
  * tok_stat [N][2][L] = (max, sum over pixels per token) the backward pass rebuilds A from, the
  * per-sample partial statistics of the tokens for the transformer's first BatchNorm1D, and,
- * when tok_A is non-null, the attention map [N,P,L] itself.  P <= 832. */
+ * when tok_A is non-null, the attention map [N,P,L] itself. */
 int vt_tokenizer_fwd(const float *conv_out, const float *bn_stat, const float *bn_gamma, const float *bn_beta,
                      const float *w1, const float *b1, const float *w2, const float *b2, float *tok_A,
                      float *tok_stat, float *tokens, float *part_n1, int N, int P, vt_stream s);

@@ -370,18 +370,37 @@ __global__ __launch_bounds__(TPB) void k_proj_bwd(const float *__restrict__ du, 
 // and the NCHW->[N,P,C] transpose (model/vit_cnn.hpp:127-134).  One workgroup per image.
 //   S = x.W1 + b1;  A = softmax over the P pixels per token;  T0 = A^T.x;  t = T0.W2 + b2
 // S is produced in N layout (lane = token, registers = pixels), so the softmax over pixels reduces
-// inside the lane first and crosses lanes once per workgroup; all tiles of S stay in registers
-// between the three phases (maximum, sum, A^T.x).  A^T.x contracts over pixels with the N-layout
-// registers as the A operand and accumulates in one D tile per wave.
+// inside the lane first and crosses lanes once per workgroup.  Two sweeps over the image's pixels
+// (25 KB, L2-resident), S recomputed in the second one (2 MFMAs per tile are cheaper than 52
+// registers per lane, which would halve the occupancy):
+//   sweep 1: per-token maximum;   sweep 2: e = exp(S - max), sum e, and T0~ = e^T.x accumulated
+//   in one D tile per wave; T0 = T0~ / sum at the end.
 // tok_stat[n] = (max_l[L], sum_l[L]) lets the backward pass rebuild A in a single sweep; tokA is
-// written only when non-null (debug / tests).
+// written only when non-null (debug / tests), by a third sweep.
 // ---------------------------------------------------------------------------------------------
+template <int NT>  // tiles handled together (their loads are issued before the first is used)
+__device__ __forceinline__ void tok_scores(const float *__restrict__ xin, int t0, int ntiles, int P, int j, const BnPair &bn,
+                                           const float (&bw)[2], float bias, f4 (&sc)[NT]) {
+  float2 raw[NT];
+#pragma unroll
+  for (int u = 0; u < NT; ++u) raw[u] = *reinterpret_cast<const float2 *>(xin + (size_t)min((t0 + NW * u) * 16 + j, P - 1) * C1);
+#pragma unroll
+  for (int u = 0; u < NT; ++u) {
+    const bool ok = t0 + NW * u < ntiles && (t0 + NW * u) * 16 + j < P;
+    const float x0 = ok ? bn.apply(raw[u].x, 0) : 0.f, x1 = ok ? bn.apply(raw[u].y, 1) : 0.f;
+    sc[u] = f4{bias, bias, bias, bias};
+    sc[u] = mfma16(x0, bw[0], sc[u]);
+    sc[u] = mfma16(x1, bw[1], sc[u]);
+  }
+}
+
 __global__ __launch_bounds__(TPB) void k_tokenizer_fwd(const float *__restrict__ conv, const float *__restrict__ st,
                                                        const float *__restrict__ g, const float *__restrict__ b,
                                                        const float *__restrict__ W1, const float *__restrict__ b1,
                                                        const float *__restrict__ W2, const float *__restrict__ b2,
                                                        float *__restrict__ tokA, float *__restrict__ tok_stat,
                                                        float *__restrict__ tok, float *__restrict__ part_n1, int P) {
+  constexpr int NT = 4;
   __shared__ float redm[NW][L], reds[NW][L];
   __shared__ float sT[NW][256];
   __shared__ float sT0[L * C1];
@@ -394,77 +413,77 @@ __global__ __launch_bounds__(TPB) void k_tokenizer_fwd(const float *__restrict__
   const float bias = b1[j];
   BnPair bn;
   bn.init(st, g, b, gq);
-  float S[TK_MAXT][4];
+  const float *__restrict__ xin = conv + (size_t)n * P * C1 + 2 * gq;
+  // sweep 1: maximum over the pixels, per token (lane j)
   float cm = -INFINITY;
+  for (int t0 = wave; t0 < ntiles; t0 += NW * NT) {
+    f4 sc[NT];
+    tok_scores<NT>(xin, t0, ntiles, P, j, bn, bw, bias, sc);
 #pragma unroll
-  for (int i = 0; i < TK_MAXT; ++i) {
-    const int t = wave + NW * i;
-    const int p = t * 16 + j;
-    float x0 = 0.f, x1 = 0.f;
-    if (t < ntiles && p < P) {
-      const float2 raw = *reinterpret_cast<const float2 *>(conv + ((size_t)n * P + p) * C1 + 2 * gq);
-      x0 = bn.apply(raw.x, 0);
-      x1 = bn.apply(raw.y, 1);
-    }
-    f4 sc = {bias, bias, bias, bias};
-    sc = mfma16(x0, bw[0], sc);
-    sc = mfma16(x1, bw[1], sc);
+    for (int u = 0; u < NT; ++u)
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      const bool valid = t < ntiles && t * 16 + 4 * gq + v < P;
-      S[i][v] = sc[v];
-      cm = valid ? fmaxf(cm, sc[v]) : cm;
-    }
+      for (int v = 0; v < 4; ++v) {
+        const bool valid = t0 + NW * u < ntiles && (t0 + NW * u) * 16 + 4 * gq + v < P;
+        cm = valid ? fmaxf(cm, sc[u][v]) : cm;
+      }
   }
   cm = gmax(cm);
   if (gq == 0) redm[wave][j] = cm;
   __syncthreads();
   cm = fmaxf(fmaxf(redm[0][j], redm[1][j]), fmaxf(redm[2][j], redm[3][j]));
+  // sweep 2: e = exp(S - max), its sum, and T0~[l][c] = sum_p e[p][l] x[p][c] (D[token][channel])
+  const int ch = j & (C1 - 1);
+  const float nmean = st[ch], ninv = st[C1 + ch], ngam = g[ch], nbet = b[ch];
+  const float *__restrict__ cb = conv + (size_t)n * P * C1;
   float cs = 0.f;
+  f4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int t0 = wave; t0 < ntiles; t0 += NW * NT) {
+    float xr[NT][4];
 #pragma unroll
-  for (int i = 0; i < TK_MAXT; ++i) {
-    const int t = wave + NW * i;
+    for (int u = 0; u < NT; ++u)
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      const bool valid = t < ntiles && t * 16 + 4 * gq + v < P;
-      const float e = valid ? __expf(S[i][v] - cm) : 0.f;
-      S[i][v] = e;
-      cs += e;
-    }
+      for (int v = 0; v < 4; ++v) xr[u][v] = cb[(size_t)min((t0 + NW * u) * 16 + 4 * gq + v, P - 1) * C1 + ch];
+    f4 sc[NT];
+    tok_scores<NT>(xin, t0, ntiles, P, j, bn, bw, bias, sc);
+#pragma unroll
+    for (int u = 0; u < NT; ++u)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const bool valid = t0 + NW * u < ntiles && (t0 + NW * u) * 16 + 4 * gq + v < P;
+        const float e = valid ? __expf(sc[u][v] - cm) : 0.f;
+        const float xn = (valid && j < C1) ? ((xr[u][v] - nmean) * ninv) * ngam + nbet : 0.f;
+        cs += e;
+        acc = mfma16(e, xn, acc);
+      }
   }
   cs = gsum(cs);
   if (gq == 0) reds[wave][j] = cs;
+#pragma unroll
+  for (int v = 0; v < 4; ++v) sT[wave][(4 * gq + v) * 16 + j] = acc[v];
   __syncthreads();
   cs = (reds[0][j] + reds[1][j]) + (reds[2][j] + reds[3][j]);
   if (tid < L) {
     tok_stat[(size_t)n * 2 * L + tid] = cm;
     tok_stat[(size_t)n * 2 * L + L + tid] = cs;
   }
-  // T0[l][c] = sum_p A[p][l] * x[p][c]  (a^T . x, tokenizer.hpp:39-40): D[token][channel]
-  const float rcs = 1.0f / cs;
-  const int ch = j & (C1 - 1);
-  const float nmean = st[ch], ninv = st[C1 + ch], ngam = g[ch], nbet = b[ch];
-  f4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int i = 0; i < TK_MAXT; ++i) {
-    const int t = wave + NW * i;
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      const int pr = t * 16 + 4 * gq + v;
-      const bool valid = t < ntiles && pr < P;
-      const float av = S[i][v] * rcs;
-      float xn = 0.f;
-      if (valid && j < C1) xn = ((conv[((size_t)n * P + pr) * C1 + j] - nmean) * ninv) * ngam + nbet;
-      acc = mfma16(av, xn, acc);
-      if (tokA != nullptr && valid) tokA[((size_t)n * P + pr) * L + j] = av;
-    }
-  }
-#pragma unroll
-  for (int v = 0; v < 4; ++v) sT[wave][(4 * gq + v) * 16 + j] = acc[v];
-  __syncthreads();
   {
     const int l = tid >> 4, c = tid & 15;
-    if (c < C1) sT0[l * C1 + c] = (sT[0][tid] + sT[1][tid]) + (sT[2][tid] + sT[3][tid]);
+    const float tot = (reds[0][l] + reds[1][l]) + (reds[2][l] + reds[3][l]);
+    if (c < C1) sT0[l * C1 + c] = ((sT[0][tid] + sT[1][tid]) + (sT[2][tid] + sT[3][tid])) * (1.0f / tot);
+  }
+  if (tokA != nullptr) {  // debug sweep: the attention map itself
+    const float rcs = 1.0f / cs;
+    for (int t0 = wave; t0 < ntiles; t0 += NW * NT) {
+      f4 sc[NT];
+      tok_scores<NT>(xin, t0, ntiles, P, j, bn, bw, bias, sc);
+#pragma unroll
+      for (int u = 0; u < NT; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int pr = (t0 + NW * u) * 16 + 4 * gq + v;
+          if (t0 + NW * u < ntiles && pr < P) tokA[((size_t)n * P + pr) * L + j] = __expf(sc[u][v] - cm) * rcs;
+        }
+    }
   }
   __syncthreads();
   // t = T0 . W2 + b2  (linear2, tokenizer.hpp:42-44)
@@ -741,7 +760,7 @@ extern "C" int vt_projector_bwd(const float *du, const float *pn_coef, const flo
 extern "C" int vt_tokenizer_fwd(const float *conv_out, const float *bn_stat, const float *bn_gamma, const float *bn_beta,
                                 const float *w1, const float *b1, const float *w2, const float *b2, float *tok_A,
                                 float *tok_stat, float *tokens, float *part_n1, int N, int P, vt_stream s) {
-  if (N < 1 || P < 1 || P > 16 * NW * TK_MAXT || !tok_stat) return VT_EUNSUPPORTED;
+  if (N < 1 || P < 1 || !tok_stat) return VT_EUNSUPPORTED;
   hipLaunchKernelGGL(k_tokenizer_fwd, dim3(N), dim3(TPB), 0, (hipStream_t)s, conv_out, bn_stat, bn_gamma, bn_beta, w1,
                      b1, w2, b2, tok_A, tok_stat, tokens, part_n1, P);
   VT_CHECK_LAUNCH();
