@@ -624,6 +624,9 @@ __global__ __launch_bounds__(TPB) void k_tokenizer_bwd(const float *__restrict__
 // Per-image partials [C1*Ci*9 | C1].
 // ---------------------------------------------------------------------------------------------
 constexpr int CW_MAXCI = 4;
+// W4: the row length is a multiple of 4, so the 4 pixels a lane owns in a tile (4g .. 4g+3) lie in
+// one image row: one row/column split per tile instead of four, one base address per operand.
+template <bool W4>
 __global__ __launch_bounds__(TPB) void k_conv_wgrad(const float *__restrict__ X, const float *__restrict__ dy,
                                                     const float *__restrict__ coef, float *__restrict__ gslab, int Ci,
                                                     int H, int W, int ld) {
@@ -636,31 +639,65 @@ __global__ __launch_bounds__(TPB) void k_conv_wgrad(const float *__restrict__ X,
   f4 acc[CW_MAXCI];
 #pragma unroll
   for (int ci = 0; ci < CW_MAXCI; ++ci) acc[ci] = f4{0.f, 0.f, 0.f, 0.f};
+  const float *__restrict__ dyb = dy + (size_t)n * P * C1 + (j < C1 ? j : 0);
+  const float *__restrict__ xb = X + (size_t)n * Ci * P;
   for (int t = wave; t < ntiles; t += NW) {
     float dv[4];
-    int hh[4], ww[4];
-    bool inb[4];
+    if (W4) {
+      const int p4 = t * 16 + 4 * gq;  // P is a multiple of 4 too: the 4 pixels are valid together
+      const bool valid = p4 < P;
+      int h = (int)(((float)p4 + 0.5f) * invW);
+      h -= (h * W > p4) ? 1 : 0;
+      h += ((h + 1) * W <= p4) ? 1 : 0;
+      const int w0 = p4 - h * W, hr = h + kh, wc = w0 + kw;
+      const bool rowok = valid && j < 9 && hr >= 0 && hr < H;
+      const int pc = valid ? p4 : 0;
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      const int pr = t * 16 + 4 * gq + v;
-      const bool valid = pr < P;
-      int h = (int)(((float)pr + 0.5f) * invW);
-      h -= (h * W > pr) ? 1 : 0;
-      h += ((h + 1) * W <= pr) ? 1 : 0;
-      const int w = pr - h * W;
-      hh[v] = h + kh;
-      ww[v] = w + kw;
-      inb[v] = valid && j < 9 && hh[v] >= 0 && hh[v] < H && ww[v] >= 0 && ww[v] < W;
-      dv[v] = (valid && j < C1) ? dy[((size_t)n * P + pr) * C1 + j] * c0 + c1 : 0.f;
-    }
+      for (int v = 0; v < 4; ++v) {
+        const float d = dyb[(size_t)(pc + v) * C1];
+        dv[v] = (valid && j < C1) ? d * c0 + c1 : 0.f;
+      }
+      // clamped, unconditional image loads; the mask is applied to the value
+      const int hc = min(max(hr, 0), H - 1);
 #pragma unroll
-    for (int ci = 0; ci < CW_MAXCI; ++ci) {
-      if (ci < Ci) {
+      for (int ci = 0; ci < CW_MAXCI; ++ci) {
+        if (ci < Ci) {
+          const float *__restrict__ xr = xb + (size_t)ci * P + hc * W;
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          float xv = inb[v] ? X[((size_t)(n * Ci + ci) * H + hh[v]) * W + ww[v]] : 0.f;
-          if (j == 9) xv = 1.f;  // invalid pixels have a zero delta, so the ones row needs no mask
-          acc[ci] = mfma16(xv, dv[v], acc[ci]);
+          for (int v = 0; v < 4; ++v) {
+            const int wv = wc + v;
+            float xv = xr[min(max(wv, 0), W - 1)];
+            xv = (rowok && wv >= 0 && wv < W) ? xv : 0.f;
+            if (j == 9) xv = 1.f;  // invalid pixels have a zero delta, so the ones row needs no mask
+            acc[ci] = mfma16(xv, dv[v], acc[ci]);
+          }
+        }
+      }
+    } else {
+      int hh[4], ww[4];
+      bool inb[4];
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int pr = t * 16 + 4 * gq + v;
+        const bool valid = pr < P;
+        int h = (int)(((float)pr + 0.5f) * invW);
+        h -= (h * W > pr) ? 1 : 0;
+        h += ((h + 1) * W <= pr) ? 1 : 0;
+        const int w = pr - h * W;
+        hh[v] = h + kh;
+        ww[v] = w + kw;
+        inb[v] = valid && j < 9 && hh[v] >= 0 && hh[v] < H && ww[v] >= 0 && ww[v] < W;
+        dv[v] = (valid && j < C1) ? dy[((size_t)n * P + pr) * C1 + j] * c0 + c1 : 0.f;
+      }
+#pragma unroll
+      for (int ci = 0; ci < CW_MAXCI; ++ci) {
+        if (ci < Ci) {
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            float xv = inb[v] ? X[((size_t)(n * Ci + ci) * H + hh[v]) * W + ww[v]] : 0.f;
+            if (j == 9) xv = 1.f;
+            acc[ci] = mfma16(xv, dv[v], acc[ci]);
+          }
         }
       }
     }
@@ -782,7 +819,10 @@ extern "C" int vt_conv3x3_wgrad(const float *x, const float *dy, const float *bn
                                 int H, int W, vt_stream s) {
   if (N < 1 || Ci < 1 || Ci > CW_MAXCI || H < 1 || W < 1) return VT_EUNSUPPORTED;
   const int ld = C1 * Ci * 9 + C1;
-  hipLaunchKernelGGL(k_conv_wgrad, dim3(N), dim3(TPB), 0, (hipStream_t)s, x, dy, bn_coef, gslab, Ci, H, W, ld);
+  if (W % 4 == 0)
+    hipLaunchKernelGGL(k_conv_wgrad<true>, dim3(N), dim3(TPB), 0, (hipStream_t)s, x, dy, bn_coef, gslab, Ci, H, W, ld);
+  else
+    hipLaunchKernelGGL(k_conv_wgrad<false>, dim3(N), dim3(TPB), 0, (hipStream_t)s, x, dy, bn_coef, gslab, Ci, H, W, ld);
   VT_CHECK_LAUNCH();
   return 0;
 }
