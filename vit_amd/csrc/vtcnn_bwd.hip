@@ -83,42 +83,58 @@ __global__ __launch_bounds__(1024) void k_reduce_multi(const ReduceBatch batch) 
 // small[1,C] * big[R,C] and Tensor::operator* keeps the left operand's shape
 // (tensor_cpu.hpp:1050-1084).  coef = (scale, shift) with delta_in = delta*scale + shift.
 // ---------------------------------------------------------------------------------------------
-constexpr int FIN_T = 1024;
+// One workgroup per channel; a thread takes every FIN_T-th block with eight loads in flight.
+constexpr int FIN_T = 256;
 __global__ __launch_bounds__(FIN_T) void k_bn_bwd_finalize(const float *__restrict__ part, int nb, int C, long rows_total,
                                                            const float *__restrict__ gamma, const float *__restrict__ stat,
                                                            const float *__restrict__ in_row0, float *__restrict__ ggamma,
                                                            float *__restrict__ gbeta, float *__restrict__ coef) {
-  __shared__ double sh[FIN_T];
-  const int tid = threadIdx.x;
-  const int C2x = 2 * C;  // (S1, S2) pairs
-  const int c = tid % C2x, j = tid / C2x, ns = FIN_T / C2x;
-  double s = 0.0;
-  int b = j;
-  for (; b + 3 * ns < nb; b += 4 * ns) {  // 4 independent loads in flight
-    const float v0 = part[(size_t)b * C2x + c], v1 = part[(size_t)(b + ns) * C2x + c];
-    const float v2 = part[(size_t)(b + 2 * ns) * C2x + c], v3 = part[(size_t)(b + 3 * ns) * C2x + c];
-    s += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
-  }
-  for (; b < nb; b += ns) s += (double)part[(size_t)b * C2x + c];
-  sh[tid] = s;
-  __syncthreads();
-  if (tid < C) {
-    double s1 = 0.0, s2 = 0.0;
-    for (int k = 0; k < ns; ++k) {
-      s1 += sh[k * C2x + tid];
-      s2 += sh[k * C2x + C + tid];
+  __shared__ double sh[2][FIN_T / 64];
+  const int tid = threadIdx.x, c = blockIdx.x;
+  double s1 = 0.0, s2 = 0.0;
+  for (int b0 = tid; b0 < nb; b0 += 8 * FIN_T) {
+    float a[8], q[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int b = min(b0 + k * FIN_T, nb - 1);
+      a[k] = part[(size_t)b * 2 * C + c];
+      q[k] = part[(size_t)b * 2 * C + C + c];
     }
-    const float S1 = (float)s1, S2 = (float)s2;
-    const float gm = gamma[tid], mean = stat[tid], inv = stat[C + tid];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (b0 + k * FIN_T < nb) {
+        s1 += (double)a[k];
+        s2 += (double)q[k];
+      }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s1 += __shfl_xor(s1, o);
+    s2 += __shfl_xor(s2, o);
+  }
+  if ((tid & 63) == 0) {
+    sh[0][tid >> 6] = s1;
+    sh[1][tid >> 6] = s2;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < FIN_T / 64; ++k) {
+      t1 += sh[0][k];
+      t2 += sh[1][k];
+    }
+    const float S1 = (float)t1, S2 = (float)t2;
+    const float gm = gamma[c], mean = stat[c], inv = stat[C + c];
     const float R = (float)rows_total;
-    ggamma[tid] = S2;
-    gbeta[tid] = S1;
+    ggamma[c] = S2;
+    gbeta[c] = S1;
     const float dvar = -0.5f * gm * inv * inv * S2;
     const float dmean = -gm * inv * S1;
-    const float k1 = ((dvar * 2.0f) * (1.0f / R)) * (in_row0[tid] - mean);
+    const float k1 = ((dvar * 2.0f) * (1.0f / R)) * (in_row0[c] - mean);
     const float k2 = dmean * (1.0f / R);
-    coef[tid] = gm * inv;
-    coef[C + tid] = k1 + k2;
+    coef[c] = gm * inv;
+    coef[C + c] = k1 + k2;
   }
 }
 
@@ -242,8 +258,8 @@ extern "C" int vt_reduce_rows(const float *slab, long rows, int cols, int ld, fl
 extern "C" int vt_bn_bwd_finalize(const float *part, int nblocks, int C, long rows_total, const float *gamma,
                                   const float *stat, const float *in_row0, float *ggamma, float *gbeta, float *coef,
                                   vt_stream s) {
-  if (C < 1 || FIN_T % (2 * C) != 0 || nblocks < 1 || rows_total < 1) return VT_EUNSUPPORTED;
-  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(1), dim3(FIN_T), 0, (hipStream_t)s, part, nblocks, C, rows_total, gamma,
+  if (C < 1 || C > 1024 || nblocks < 1 || rows_total < 1) return VT_EUNSUPPORTED;
+  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(C), dim3(FIN_T), 0, (hipStream_t)s, part, nblocks, C, rows_total, gamma,
                      stat, in_row0, ggamma, gbeta, coef);
   VT_CHECK_LAUNCH();
   return 0;

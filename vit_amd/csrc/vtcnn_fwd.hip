@@ -91,55 +91,61 @@ __global__ __launch_bounds__(TPB) void k_conv_fwd(const float *__restrict__ X, c
 // BatchNorm statistics finalisation (reference batch_normalization_layer.hpp:152-159, 274-283):
 // merges per-block (sum, centred M2) partials with Chan's formula in double precision, writes
 // stat = (mean, 1/sqrt(var+eps)) and updates running = 0.1*batch + 0.9*running (biased var).
-// One workgroup.
+//   S = sum_b sum_b, Q = sum_b M2_b, U = sum_b sum_b^2/cnt_b;  mean = S/R,  M2 = Q + U - S^2/R
+// One workgroup per channel: a thread takes every FIN_T-th block, its loads are independent (eight
+// in flight), 1/cnt_b is a constant except for the last block, so the loop has no division; the
+// three sums then cross the workgroup through wave shuffles and one LDS hop.
 // ---------------------------------------------------------------------------------------------
-constexpr int FIN_T = 1024;  // threads of the single finalisation workgroup
+constexpr int FIN_T = 256;
+__device__ __forceinline__ double wave_sum_d(double x) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+  return x;
+}
 __global__ __launch_bounds__(FIN_T) void k_bn_stats_finalize(const float *__restrict__ part, int nb, int C,
                                                              long rows_per_block, long rows_total,
                                                              float *__restrict__ run_mean, float *__restrict__ run_var,
                                                              float *__restrict__ stat) {
-  // One pass: S = sum_b sum_b, Q = sum_b M2_b, U = sum_b sum_b^2/cnt_b; then
-  //   mean = S/R,  M2 = Q + U - S^2/R   (Chan's merge summed over all blocks; doubles absorb the
-  //   cancellation).  Thread = (channel, slice of blocks); independent loads are unrolled so the
-  //   global-load latency is paid once per 4 blocks, not once per block.
-  __shared__ double sh[3][FIN_T];
-  const int tid = threadIdx.x;
-  const int c = tid % C, j = tid / C, ns = FIN_T / C;
+  __shared__ double sh[3][FIN_T / 64];
+  const int tid = threadIdx.x, c = blockIdx.x;
   const long last_cnt = rows_total - (long)(nb - 1) * rows_per_block;
+  const double rc = 1.0 / (double)rows_per_block, rc_last = 1.0 / (double)last_cnt;
   double S = 0.0, Q = 0.0, U = 0.0;
-  int b = j;
-  for (; b + 3 * ns < nb; b += 4 * ns) {
-    float sv[4], qv[4];
+  for (int b0 = tid; b0 < nb; b0 += 8 * FIN_T) {
+    float sv[8], qv[8];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      sv[k] = part[(size_t)(b + k * ns) * 2 * C + c];
-      qv[k] = part[(size_t)(b + k * ns) * 2 * C + C + c];
+    for (int k = 0; k < 8; ++k) {
+      const int b = min(b0 + k * FIN_T, nb - 1);
+      sv[k] = part[(size_t)b * 2 * C + c];
+      qv[k] = part[(size_t)b * 2 * C + C + c];
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const double cnt = (double)((b + k * ns == nb - 1) ? last_cnt : rows_per_block);
-      S += (double)sv[k];
-      Q += (double)qv[k];
-      U += (double)sv[k] * (double)sv[k] / cnt;
+    for (int k = 0; k < 8; ++k) {
+      const int b = b0 + k * FIN_T;
+      if (b < nb) {
+        const double s = (double)sv[k];
+        S += s;
+        Q += (double)qv[k];
+        U += s * s * (b == nb - 1 ? rc_last : rc);
+      }
     }
   }
-  for (; b < nb; b += ns) {
-    const double sv = (double)part[(size_t)b * 2 * C + c], qv = (double)part[(size_t)b * 2 * C + C + c];
-    const double cnt = (double)((b == nb - 1) ? last_cnt : rows_per_block);
-    S += sv;
-    Q += qv;
-    U += sv * sv / cnt;
+  S = wave_sum_d(S);
+  Q = wave_sum_d(Q);
+  U = wave_sum_d(U);
+  if ((tid & 63) == 0) {
+    sh[0][tid >> 6] = S;
+    sh[1][tid >> 6] = Q;
+    sh[2][tid >> 6] = U;
   }
-  sh[0][tid] = S;
-  sh[1][tid] = Q;
-  sh[2][tid] = U;
   __syncthreads();
-  if (tid < C) {
+  if (tid == 0) {
     double s = 0.0, q = 0.0, u = 0.0;
-    for (int k = 0; k < ns; ++k) {
-      s += sh[0][k * C + tid];
-      q += sh[1][k * C + tid];
-      u += sh[2][k * C + tid];
+#pragma unroll
+    for (int k = 0; k < FIN_T / 64; ++k) {
+      s += sh[0][k];
+      q += sh[1][k];
+      u += sh[2][k];
     }
     const double R = (double)rows_total;
     const double mu = s / R;
@@ -147,10 +153,10 @@ __global__ __launch_bounds__(FIN_T) void k_bn_stats_finalize(const float *__rest
     if (m2 < 0.0) m2 = 0.0;
     const float mean = (float)mu;
     const float var = (float)(m2 / R);
-    stat[tid] = mean;
-    stat[C + tid] = 1.0f / sqrtf(var + BN_EPS);
-    run_mean[tid] = mean * BN_MOM + run_mean[tid] * (1 - BN_MOM);
-    run_var[tid] = var * BN_MOM + run_var[tid] * (1 - BN_MOM);
+    stat[c] = mean;
+    stat[C + c] = 1.0f / sqrtf(var + BN_EPS);
+    run_mean[c] = mean * BN_MOM + run_mean[c] * (1 - BN_MOM);
+    run_var[c] = var * BN_MOM + run_var[c] * (1 - BN_MOM);
   }
 }
 
@@ -206,9 +212,9 @@ extern "C" int vt_conv3x3_fwd(const float *x, const float *w, const float *b, fl
 
 extern "C" int vt_bn_stats_finalize(const float *part, int nblocks, int C, long rows_per_block, long rows_total,
                                     float *running_mean, float *running_var, float *stat, vt_stream s) {
-  if (C < 1 || C > 64 || FIN_T % C != 0 || nblocks < 1) return VT_EUNSUPPORTED;
+  if (C < 1 || C > 1024 || nblocks < 1) return VT_EUNSUPPORTED;
   if ((long)(nblocks - 1) * rows_per_block >= rows_total || (long)nblocks * rows_per_block < rows_total) return VT_EINVAL;
-  hipLaunchKernelGGL(k_bn_stats_finalize, dim3(1), dim3(FIN_T), 0, (hipStream_t)s, part, nblocks, C, rows_per_block,
+  hipLaunchKernelGGL(k_bn_stats_finalize, dim3(C), dim3(FIN_T), 0, (hipStream_t)s, part, nblocks, C, rows_per_block,
                      rows_total, running_mean, running_var, stat);
   VT_CHECK_LAUNCH();
   return 0;
