@@ -63,6 +63,28 @@ def algorithmic_bytes_per_image(d):
     return t, total
 
 
+LAUNCHER_KERNEL = {  # launcher name (vt_model_profile) -> device kernel it launches
+    "conv3x3_fwd": "k_conv_fwd", "tokenizer_fwd": "k_tokenizer_fwd", "transformer_ffn_fwd": "k_tr_ffn_fwd",
+    "projector_tokens_fwd": "k_proj_tokens_fwd", "projector_fwd": "k_proj_fwd", "head_fwd": "k_head_fwd",
+    "head_bwd": "k_head_bwd", "projector_bwd": "k_proj_bwd", "transformer_bwd_b": "k_tr_bwd_b",
+    "tokenizer_bwd": "k_tokenizer_bwd", "conv3x3_wgrad": "k_conv_wgrad", "mha_bwd_rows": "k_mha_rows",
+}
+
+
+def measured_traffic(launcher, batch, classes):
+    """HBM bytes per launch of the launcher's kernel from the committed PMC passes
+    (profiles/r01_hbm_traffic_b1024_k8.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+    runs of this same command, 2*FETCH_SIZE + WRITE_SIZE as the gfx950 notes prescribe).  Only
+    valid for the configuration it was measured on; None otherwise."""
+    if batch != 1024 or classes != 8:
+        return None
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic_b1024_k8.json")))
+        return int(t["kernels"][LAUNCHER_KERNEL[launcher]]["traffic_bytes"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(batch, classes):
     """Reference CPU path timed on this box's host cores (rank 0, N=1 only): the real reference
     compiled from its own headers (oracle/_ref/ref_harness_o3, built in the build container) when
@@ -178,13 +200,15 @@ def main():
             ach = fl / avg_s / 1e12 if k_cnt else None
             roof = {"bound": "mfma", "kernel": dominant, "achieved": None if ach is None else round(ach, 2),
                     "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": None if ach is None else round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                    "frac": None if ach is None else round(ach / MFMA_F32_PEAK_TFLOPS, 4),
+                    "traffic": measured_traffic(dominant, B, a.classes),
                     "algorithmic_flops_per_launch": fl,
                     "avg_launch_us": None if not k_cnt else round(avg_s * 1e6, 2), "launches_timed": k_cnt}
         else:
             roof = {"bound": "hbm", "kernel": dominant, "achieved": None if achieved is None else round(achieved, 1),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 4),
+                    "traffic": measured_traffic(dominant, B, a.classes),
                     "algorithmic_bytes_per_launch": tbl.get(dominant, 0) * B,
                     "avg_launch_us": None if not k_cnt else round(avg_s * 1e6, 2), "launches_timed": k_cnt}
         res = {
