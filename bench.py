@@ -37,7 +37,7 @@ def attention_bwd_flops(d, batch):
     return 5 * 2 * batch * batch * hd * d.heads * d.tokens
 
 
-def algorithmic_bytes_per_image(d):
+def algorithmic_bytes_per_image(d, forward_only=False):
     """Layer-boundary fp32 traffic per image apportioned to the launcher that performs it.
     Each tensor that crosses a top-level reference Layer interface counts once per write and once
     per read; tensors internal to a composite layer and parameters do not count.  The sum over
@@ -60,7 +60,9 @@ def algorithmic_bytes_per_image(d):
     t = {k: 4 * v for k, v in t.items()}
     total = 4 * (2 * Ci * P + 14 * C1 * P + 5 * C2 * P + 4 * Q + 11 * L * D + 5 * K)
     assert sum(t.values()) == total, (sum(t.values()), total)
-    return t, total
+    fwd_total = 4 * (Ci * P + 5 * C1 * P + 2 * C2 * P + 2 * Q + 4 * L * D + 3 * K)
+    assert sum(v for k, v in t.items() if k.endswith("_fwd")) == fwd_total
+    return t, (fwd_total if forward_only else total)
 
 
 LAUNCHER_KERNEL = {  # launcher name (vt_model_profile) -> device kernel it launches
@@ -128,6 +130,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=1024, help="images per mini-batch per GPU")
     ap.add_argument("--classes", type=int, default=8)
+    ap.add_argument("--mode", choices=("train", "predict"), default="train",
+                    help="train: the headline metric; predict: forward-only images/sec (eval mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel", default=None, help="launcher to time with HIP events (default: the slowest)")
     a = ap.parse_args()
@@ -152,8 +156,14 @@ def main():
     from vit_amd.parallel import DataParallel
     dp = DataParallel(m, world=world, rank=rank)  # world 1: plain forward / backward / SGD
 
+    if a.mode == "predict":
+        m.set_training(False)
+
     def step(i):
-        dp.train_step(xs[i % nb], ys[i % nb], B)
+        if a.mode == "predict":
+            m.forward(xs[i % nb])
+        else:
+            dp.train_step(xs[i % nb], ys[i % nb], B)
 
     def sync():
         torch.cuda.synchronize()
@@ -172,7 +182,7 @@ def main():
     sync()
     breakdown = m.profile_read()
     per_launch_ms = {k: v[0] / v[1] for k, v in breakdown.items()}
-    tbl, total_bytes = algorithmic_bytes_per_image(dims)
+    tbl, total_bytes = algorithmic_bytes_per_image(dims, a.mode == "predict")
     candidates = {k: v for k, v in breakdown.items() if k in tbl or k == "mha_bwd_rows"}
     dominant = a.kernel or (max(candidates, key=lambda k: candidates[k][0]) if candidates else "projector_bwd")
     m.profile(dominant)
@@ -212,10 +222,11 @@ def main():
                     "algorithmic_bytes_per_launch": tbl.get(dominant, 0) * B,
                     "avg_launch_us": None if not k_cnt else round(avg_s * 1e6, 2), "launches_timed": k_cnt}
         res = {
-            "metric": "train images/sec (whole node) VTCNN BloodMNIST", "value": round(value, 1), "unit": "images/sec",
+            "metric": ("train" if a.mode == "train" else "predict") + " images/sec (whole node) VTCNN BloodMNIST", "value": round(value, 1), "unit": "images/sec",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "VTCNN train step (forward+backward+SGD), BloodMNIST shape 1x28x28, %d classes, "
+            "config": {"workload": ("VTCNN train step (forward+backward+SGD)" if a.mode == "train" else
+                                    "VTCNN predict step (eval-mode forward)") + ", BloodMNIST shape 1x28x28, %d classes, "
                                    "mini-batch %d per GPU, fp32, seed-42 reference init" % (a.classes, B),
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world,
                        "grad_allreduce_floats": int(m.layout.n_trainable) if world > 1 else 0},
@@ -224,7 +235,7 @@ def main():
             "algorithmic_bytes_per_image": total_bytes,
             "launcher_us": {k: round(1e3 * v, 2) for k, v in sorted(per_launch_ms.items(), key=lambda kv: -kv[1])},
         }
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and a.mode == "train":
             res["cpu_baseline"] = cpu_baseline(B, a.classes)
         print(json.dumps(res), flush=True)
     if dist is not None:
