@@ -116,5 +116,22 @@ class VTCNN : public Model {
     if (rc == VT_EFORMAT) throw std::runtime_error("El checkpoint no coincide con el modelo actual (capas, tipos o formas)");
     check(rc, "VTCNN::load");
   }
+  // v2 = the same v1 bytes plus a trailer with the transformer block, the BatchNorm1D statistics
+  // and the training position (the reference's loader stops before the trailer).
+  void save_v2(const std::string &filename, const vt_train_state &state) const {
+    vt_host::hip_check(hipStreamSynchronize(stream_), "sync");
+    const int rc = vt_model_save_v2(h_, &state, filename.c_str());
+    if (rc == VT_EIO) throw std::runtime_error("No se pudo abrir el archivo para guardar el modelo: " + filename);
+    check(rc, "VTCNN::save_v2");
+  }
+  vt_train_state load_v2(const std::string &filename) {
+    vt_host::hip_check(hipStreamSynchronize(stream_), "sync");
+    vt_train_state st{};
+    const int rc = vt_model_load_v2(h_, &st, filename.c_str());
+    if (rc == VT_EIO) throw std::runtime_error("No se pudo abrir el archivo para cargar el modelo: " + filename);
+    if (rc == VT_EFORMAT) throw std::runtime_error("El checkpoint no coincide con el modelo actual (capas, tipos o formas)");
+    check(rc, "VTCNN::load_v2");
+    return st;
+  }
   vt_model *handle() { return h_; }
 };

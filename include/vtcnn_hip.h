@@ -118,6 +118,26 @@ int vt_host_init_arena(const vt_dims *dims, unsigned seed, float *arena_host);
 int vt_checkpoint_write(const vt_dims *dims, const float *arena_host, const char *path);
 int vt_checkpoint_read(const vt_dims *dims, float *arena_host, const char *path);
 
+/* Checkpoint v2 = the reference's v1 bytes (model/vit_cnn.hpp:276-394) followed by a trailer that
+ * the reference's loader never reaches (VTCNN::load stops after the fc layer, vit_cnn.hpp:396-546,
+ * so a v2 file still loads there): magic "VTCNNv2\0", i32 2, i32 tensor count, then every arena
+ * tensor that v1 omits (attention, FFN, norm1 / norm2 parameters, the BatchNorm1D running
+ * statistics) as  i32 name length, name, v1 tensor record;  then the training position.
+ * v1 loses the transformer block: a reloaded model restarts it from the seed-42 initialisation.
+ * Reading a v1 file through the v2 entry points succeeds with state->version = 1 and the omitted
+ * tensors untouched. */
+typedef struct vt_train_state {
+  int version;            /* out: 1 = file had no trailer, 2 = full state restored */
+  int epoch;              /* epochs completed */
+  long long step;         /* optimizer steps taken */
+  unsigned loader_seed;   /* DataLoader seed (utils/load_dataset.hpp:117) */
+  int loader_resets;      /* reset() calls so far: fixes the shuffle the next epoch starts from */
+} vt_train_state;
+int vt_checkpoint_write_v2(const vt_dims *dims, const float *arena_host, const vt_train_state *state, const char *path);
+int vt_checkpoint_read_v2(const vt_dims *dims, float *arena_host, vt_train_state *state, const char *path);
+int vt_model_save_v2(vt_model *m, const vt_train_state *state, const char *path);
+int vt_model_load_v2(vt_model *m, vt_train_state *state, const char *path);
+
 /* loadImages2D / loadLabels (utils/load_dataset.hpp:20-85): big-endian IDX headers, pixel
  * u8 / 255.0f, label u8 -> int.  Query sizes with out == NULL. */
 int vt_idx_read_images(const char *path, int max_images, float *out, int *n, int *rows, int *cols);

@@ -161,3 +161,41 @@ def test_train_step_vs_oracle_larger_batch(n, k):
             if not e < TOL:
                 bad.append((name, e))
     assert not bad, bad
+
+
+def test_checkpoint_v2_resume_is_bit_exact(tmp_path):
+    """Train 2 steps, save v2, train a 3rd; a fresh model that loads the v2 file and takes the same
+    3rd step ends with a bit-identical arena (weights, transformer block, all running statistics).
+    The same through a v1 file differs: v1 drops the transformer block (model/vit_cnn.hpp:276-394)."""
+    import torch
+    from vit_amd import VTCNN, Dims
+    n, k = 32, 8
+    rng = np.random.default_rng(77)
+    xs = [torch.from_numpy(rng.integers(0, 256, size=(n, 1, 28, 28)).astype(np.float32) / np.float32(255.0)).cuda()
+          for _ in range(3)]
+    ys = [torch.from_numpy(rng.integers(0, k, size=n).astype(np.int32)).cuda() for _ in range(3)]
+
+    def step(m, i):
+        m.forward(xs[i])
+        m.backward(ys[i])
+        m.update_weights(32.0)
+
+    a = VTCNN(Dims(num_classes=k), max_batch=n, seed=42)
+    step(a, 0)
+    step(a, 1)
+    a.save_v2(tmp_path / "s2.bin", epoch=0, step=2, loader_resets=1)
+    a.save(tmp_path / "s2_v1.bin")
+    step(a, 2)
+    want = a.get_arena().copy()
+
+    b = VTCNN(Dims(num_classes=k), max_batch=n, seed=42)
+    st = b.load_v2(tmp_path / "s2.bin")
+    assert st == {"version": 2, "epoch": 0, "step": 2, "loader_seed": 42, "loader_resets": 1}
+    step(b, 2)
+    assert np.array_equal(b.get_arena(), want)
+
+    c = VTCNN(Dims(num_classes=k), max_batch=n, seed=42)
+    assert c.load_v2(tmp_path / "s2_v1.bin")["version"] == 1
+    step(c, 2)
+    nt = c.layout.n_trainable
+    assert not np.array_equal(c.get_arena()[:nt], want[:nt])

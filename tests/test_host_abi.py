@@ -7,6 +7,7 @@ import hashlib
 import json
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -89,6 +90,64 @@ def test_checkpoint_bytes(tmp_path):
     a10 = np.zeros(layout(10).n_total, dtype=np.float32)
     assert lib.vt_checkpoint_read(C.byref(dims(10)), a10.ctypes.data, src.encode()) == -5
     assert lib.vt_checkpoint_read(C.byref(dims(8)), arena.ctypes.data, b"/nonexistent/x.bin") == -4
+
+
+def test_checkpoint_v2_roundtrip_and_v1_compatibility(tmp_path):
+    """v2 = v1 bytes + trailer (transformer block, BatchNorm1D statistics, training position)."""
+    import shutil
+    import subprocess
+    from vit_amd._lib import VtTrainState
+    lo = layout(8)
+    d8 = dims(8)
+    rng = np.random.default_rng(5)
+    arena = rng.standard_normal(lo.n_total).astype(np.float32)
+    st = VtTrainState(2, 3, 4242, 42, 4)
+    v2 = str(tmp_path / "m_v2.bin")
+    v1 = str(tmp_path / "m_v1.bin")
+    assert lib.vt_checkpoint_write_v2(C.byref(d8), arena.ctypes.data, C.byref(st), v2.encode()) == 0
+    assert lib.vt_checkpoint_write(C.byref(d8), arena.ctypes.data, v1.encode()) == 0
+    raw1, raw2 = open(v1, "rb").read(), open(v2, "rb").read()
+    assert raw2[:len(raw1)] == raw1 and raw2[len(raw1):len(raw1) + 8] == b"VTCNNv2\0"
+    # full restore: every tensor of the arena, and the training position
+    back = np.zeros(lo.n_total, dtype=np.float32)
+    got = VtTrainState()
+    assert lib.vt_checkpoint_read_v2(C.byref(d8), back.ctypes.data, C.byref(got), v2.encode()) == 0
+    assert (got.version, got.epoch, got.step, got.loader_seed, got.loader_resets) == (2, 3, 4242, 42, 4)
+    for name, (off, size, shape, kind) in lo.tensors.items():
+        assert np.array_equal(back[off:off + size], arena[off:off + size]), name
+    # the v1 reader takes the same file and restores exactly the v1 subset
+    part = np.zeros(lo.n_total, dtype=np.float32)
+    assert lib.vt_checkpoint_read(C.byref(d8), part.ctypes.data, v2.encode()) == 0
+    assert np.array_equal(lo.view(part, "fc.W"), lo.view(arena, "fc.W"))
+    assert not lo.view(part, "mha.q0.W").any() and not lo.view(part, "norm2.running_var").any()
+    # a v1 file through the v2 reader: version 1, omitted tensors untouched
+    assert lib.vt_checkpoint_read_v2(C.byref(d8), part.ctypes.data, C.byref(got), v1.encode()) == 0
+    assert got.version == 1 and not lo.view(part, "ffn.linear1.W").any()
+    # truncated trailer and wrong class count are format errors
+    open(str(tmp_path / "cut.bin"), "wb").write(raw2[:len(raw1) + 40])
+    assert lib.vt_checkpoint_read_v2(C.byref(d8), back.ctypes.data, C.byref(got), str(tmp_path / "cut.bin").encode()) == -5
+    a10 = np.zeros(layout(10).n_total, dtype=np.float32)
+    assert lib.vt_checkpoint_read_v2(C.byref(dims(10)), a10.ctypes.data, C.byref(got), v2.encode()) == -5
+    # the REAL reference loads a v2 file like the v1 file it starts with (build container only:
+    # oracle/_ref holds the reference compiled from its own headers)
+    harness = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+    if os.access(harness, os.X_OK):
+        ck = np.zeros(lo.n_total, dtype=np.float32)
+        lib.vt_host_init_arena(C.byref(d8), 42, ck.ctypes.data)
+        src = os.path.join(GOLD, "blood_model.bin")
+        assert lib.vt_checkpoint_read(C.byref(d8), ck.ctypes.data, src.encode()) == 0
+        blood_v2 = str(tmp_path / "blood_v2.bin")
+        assert lib.vt_checkpoint_write_v2(C.byref(d8), ck.ctypes.data, None, blood_v2.encode()) == 0
+        out = str(tmp_path / "blood.bundle")
+        env = dict(os.environ, OMP_NUM_THREADS="1")
+        subprocess.run([harness, "blood", out, os.path.join(GOLD, "blood_t10k_256-images-idx3-ubyte"),
+                        os.path.join(GOLD, "blood_t10k_256-labels-idx1-ubyte"), blood_v2, "256"], check=True, env=env,
+                       capture_output=True, timeout=300)
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from bundle import read_bundle
+        got_b = read_bundle(out)
+        g = load_golden("blood_t10k_256.npz")
+        assert np.array_equal(got_b["pred"], g["pred"]) and np.array_equal(got_b["probs"], g["probs"])
 
 
 def test_loader_shuffle_known_answers():

@@ -24,6 +24,11 @@ class VtTensorInfo(C.Structure):
                 ("shape", C.c_int * 4), ("kind", C.c_int)]
 
 
+class VtTrainState(C.Structure):
+    _fields_ = [("version", C.c_int), ("epoch", C.c_int), ("step", C.c_longlong), ("loader_seed", C.c_uint),
+                ("loader_resets", C.c_int)]
+
+
 class VtLayout(C.Structure):
     _fields_ = [("n_tensors", C.c_int), ("n_trainable", C.c_int), ("n_total", C.c_int),
                 ("n_trainable_exact", C.c_int), ("t", VtTensorInfo * VT_MAX_TENSORS)]
@@ -57,6 +62,10 @@ SIGNATURES = {
     "vt_host_init_arena": (i, [C.POINTER(VtDims), u, p]),
     "vt_checkpoint_write": (i, [C.POINTER(VtDims), p, C.c_char_p]),
     "vt_checkpoint_read": (i, [C.POINTER(VtDims), p, C.c_char_p]),
+    "vt_checkpoint_write_v2": (i, [C.POINTER(VtDims), p, C.POINTER(VtTrainState), C.c_char_p]),
+    "vt_checkpoint_read_v2": (i, [C.POINTER(VtDims), p, C.POINTER(VtTrainState), C.c_char_p]),
+    "vt_model_save_v2": (i, [p, C.POINTER(VtTrainState), C.c_char_p]),
+    "vt_model_load_v2": (i, [p, C.POINTER(VtTrainState), C.c_char_p]),
     "vt_idx_read_images": (i, [C.c_char_p, i, p, C.POINTER(i), C.POINTER(i), C.POINTER(i)]),
     "vt_idx_read_labels": (i, [C.c_char_p, i, p, C.POINTER(i)]),
     "vt_loader_indices": (i, [i, u, i, p]),

@@ -297,7 +297,25 @@ extern "C" int vt_host_init_arena(const vt_dims *dims, unsigned seed, float *are
   return 0;
 }
 
-extern "C" int vt_checkpoint_write(const vt_dims *dims, const float *arena_host, const char *path) {
+static const char kV2Magic[8] = {'V', 'T', 'C', 'N', 'N', 'v', '2', 0};
+
+static bool in_v1(const char *name) {
+  for (const CkEntry &e : ck_entries())
+    for (const char *tn : e.tensors)
+      if (std::strcmp(tn, name) == 0) return true;
+  return false;
+}
+
+static void write_tensor_record(FILE *f, const vt_tensor_info &ti, const float *arena_host) {
+  auto wi = [&](int v) { std::fwrite(&v, 4, 1, f); };
+  wi(ti.ndim);
+  for (int k = 0; k < ti.ndim; ++k) wi(ti.shape[k]);
+  wi(ti.size);
+  std::fwrite(arena_host + ti.offset, 4, ti.size, f);
+}
+
+static int checkpoint_write(const vt_dims *dims, const float *arena_host, const vt_train_state *st, bool v2,
+                            const char *path) {
   vt_layout lo;
   if (!dims || !arena_host || !path || vt_make_layout(dims, &lo) != 0) return VT_EINVAL;
   FILE *f = std::fopen(path, "wb");
@@ -309,17 +327,39 @@ extern "C" int vt_checkpoint_write(const vt_dims *dims, const float *arena_host,
     wi(len);
     std::fwrite(e.type, 1, len, f);
     if (e.count_field) wi((int)e.tensors.size());
-    for (const char *tn : e.tensors) {
-      const vt_tensor_info &ti = lo.t[vt_find(&lo, tn)];
-      wi(ti.ndim);
-      for (int k = 0; k < ti.ndim; ++k) wi(ti.shape[k]);
-      wi(ti.size);
-      std::fwrite(arena_host + ti.offset, 4, ti.size, f);
+    for (const char *tn : e.tensors) write_tensor_record(f, lo.t[vt_find(&lo, tn)], arena_host);
+  }
+  if (v2) {
+    std::fwrite(kV2Magic, 1, 8, f);
+    wi(2);
+    int extra = 0;
+    for (int k = 0; k < lo.n_tensors; ++k) extra += in_v1(lo.t[k].name) ? 0 : 1;
+    wi(extra);
+    for (int k = 0; k < lo.n_tensors; ++k) {
+      if (in_v1(lo.t[k].name)) continue;
+      const int len = (int)std::strlen(lo.t[k].name);
+      wi(len);
+      std::fwrite(lo.t[k].name, 1, len, f);
+      write_tensor_record(f, lo.t[k], arena_host);
     }
+    const vt_train_state zero = {2, 0, 0, 42u, 0};
+    const vt_train_state &t = st ? *st : zero;
+    std::fwrite(&t.step, 8, 1, f);
+    wi(t.epoch);
+    std::fwrite(&t.loader_seed, 4, 1, f);
+    wi(t.loader_resets);
   }
   const bool ok = std::ferror(f) == 0;
   std::fclose(f);
   return ok ? 0 : VT_EIO;
+}
+
+extern "C" int vt_checkpoint_write(const vt_dims *dims, const float *arena_host, const char *path) {
+  return checkpoint_write(dims, arena_host, nullptr, false, path);
+}
+extern "C" int vt_checkpoint_write_v2(const vt_dims *dims, const float *arena_host, const vt_train_state *state,
+                                      const char *path) {
+  return checkpoint_write(dims, arena_host, state, true, path);
 }
 
 extern "C" int vt_model_save(vt_model *m, const char *path) {
@@ -329,7 +369,14 @@ extern "C" int vt_model_save(vt_model *m, const char *path) {
   return vt_checkpoint_write(&m->d, h.data(), path);
 }
 
-static int checkpoint_read(const vt_layout &lo, std::vector<float> &h, const char *path);
+static int checkpoint_read(const vt_layout &lo, std::vector<float> &h, const char *path, vt_train_state *st = nullptr);
+
+extern "C" int vt_model_save_v2(vt_model *m, const vt_train_state *state, const char *path) {
+  if (!m || !path) return VT_EINVAL;
+  std::vector<float> h(m->lo.n_total);
+  VTCHK(vt_model_get_arena(m, h.data()));
+  return vt_checkpoint_write_v2(&m->d, h.data(), state, path);
+}
 
 // Tensors absent from the file (transformer block, BatchNorm1D running statistics) keep the
 // values already in arena_host, exactly as a freshly constructed reference model keeps its
@@ -351,7 +398,41 @@ extern "C" int vt_model_load(vt_model *m, const char *path) {
   return vt_model_set_arena(m, h.data());
 }
 
-static int checkpoint_read(const vt_layout &lo, std::vector<float> &h, const char *path) {
+extern "C" int vt_checkpoint_read_v2(const vt_dims *dims, float *arena_host, vt_train_state *state, const char *path) {
+  vt_layout lo;
+  if (!dims || !arena_host || !path || vt_make_layout(dims, &lo) != 0) return VT_EINVAL;
+  std::vector<float> h(arena_host, arena_host + lo.n_total);
+  vt_train_state st = {1, 0, 0, 42u, 0};
+  const int rc = checkpoint_read(lo, h, path, &st);
+  if (rc == 0) {
+    std::memcpy(arena_host, h.data(), sizeof(float) * lo.n_total);
+    if (state) *state = st;
+  }
+  return rc;
+}
+
+extern "C" int vt_model_load_v2(vt_model *m, vt_train_state *state, const char *path) {
+  if (!m || !path) return VT_EINVAL;
+  std::vector<float> h(m->lo.n_total);
+  VTCHK(vt_model_get_arena(m, h.data()));
+  vt_train_state st = {1, 0, 0, 42u, 0};
+  VTCHK(checkpoint_read(m->lo, h, path, &st));
+  if (state) *state = st;
+  return vt_model_set_arena(m, h.data());
+}
+
+// Reads one v1 tensor record into the arena slot of ti; shape and count must match.
+static int read_tensor_record(FILE *f, const vt_tensor_info &ti, float *dst) {
+  auto ri = [&](int *v) { return std::fread(v, 4, 1, f) == 1; };
+  int nd = 0, cnt = 0, dim = 0;
+  if (!ri(&nd) || nd != ti.ndim) return VT_EFORMAT;
+  for (int k = 0; k < nd; ++k)
+    if (!ri(&dim) || dim != ti.shape[k]) return VT_EFORMAT;  // shape mismatch (vit_cnn.hpp:444)
+  if (!ri(&cnt) || cnt != ti.size || std::fread(dst, 4, cnt, f) != (size_t)cnt) return VT_EFORMAT;
+  return 0;
+}
+
+static int checkpoint_read(const vt_layout &lo, std::vector<float> &h, const char *path, vt_train_state *st) {
   FILE *f = std::fopen(path, "rb");
   if (!f) return VT_EIO;  // "No se pudo abrir el archivo para cargar el modelo" (vit_cnn.hpp:400)
   int rc = 0;
@@ -372,12 +453,32 @@ static int checkpoint_read(const vt_layout &lo, std::vector<float> &h, const cha
     }
     for (const char *tn : e.tensors) {
       const vt_tensor_info &ti = lo.t[vt_find(&lo, tn)];
-      int nd = 0, cnt = 0, dim = 0;
-      if (!ri(&nd) || nd != ti.ndim) { rc = VT_EFORMAT; break; }
-      for (int k = 0; k < nd && rc == 0; ++k)
-        if (!ri(&dim) || dim != ti.shape[k]) rc = VT_EFORMAT;  // shape mismatch (vit_cnn.hpp:444)
+      rc = read_tensor_record(f, ti, h.data() + ti.offset);
       if (rc != 0) break;
-      if (!ri(&cnt) || cnt != ti.size || std::fread(h.data() + ti.offset, 4, cnt, f) != (size_t)cnt) { rc = VT_EFORMAT; break; }
+    }
+  }
+  // optional v2 trailer; only looked for when the caller asked for the training state
+  if (rc == 0 && st) {
+    char magic[8];
+    if (std::fread(magic, 1, 8, f) == 8 && std::memcmp(magic, kV2Magic, 8) == 0) {
+      int ver = 0, extra = 0;
+      if (!ri(&ver) || ver != 2 || !ri(&extra) || extra < 0 || extra > VT_MAX_TENSORS) rc = VT_EFORMAT;
+      for (int k = 0; k < extra && rc == 0; ++k) {
+        int len = 0;
+        char name[VT_NAME_LEN] = {0};
+        if (!ri(&len) || len < 1 || len >= VT_NAME_LEN || std::fread(name, 1, len, f) != (size_t)len) { rc = VT_EFORMAT; break; }
+        const int idx = vt_find(&lo, name);
+        if (idx < 0 || in_v1(name)) { rc = VT_EFORMAT; break; }
+        rc = read_tensor_record(f, lo.t[idx], h.data() + lo.t[idx].offset);
+      }
+      if (rc == 0) {
+        st->version = 2;
+        if (std::fread(&st->step, 8, 1, f) != 1 || !ri(&st->epoch) || std::fread(&st->loader_seed, 4, 1, f) != 1 ||
+            !ri(&st->loader_resets))
+          rc = VT_EFORMAT;
+      }
+    } else {
+      st->version = 1;
     }
   }
   std::fclose(f);

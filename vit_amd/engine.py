@@ -146,6 +146,21 @@ class VTCNN:
     def load(self, path):
         check(lib.vt_model_load(self._h, str(path).encode()), "vt_model_load(%s)" % path)
 
+    def save_v2(self, path, epoch=0, step=0, loader_seed=42, loader_resets=0):
+        """Reference v1 bytes + trailer with the transformer block, BatchNorm1D statistics and the
+        training position (still loadable by the reference, which never reads past the fc layer)."""
+        from ._lib import VtTrainState
+        st = VtTrainState(2, int(epoch), int(step), int(loader_seed), int(loader_resets))
+        check(lib.vt_model_save_v2(self._h, C.byref(st), str(path).encode()), "vt_model_save_v2(%s)" % path)
+
+    def load_v2(self, path):
+        """Loads a v1 or v2 file; returns dict(version, epoch, step, loader_seed, loader_resets)."""
+        from ._lib import VtTrainState
+        st = VtTrainState()
+        check(lib.vt_model_load_v2(self._h, C.byref(st), str(path).encode()), "vt_model_load_v2(%s)" % path)
+        return {"version": st.version, "epoch": st.epoch, "step": st.step, "loader_seed": st.loader_seed,
+                "loader_resets": st.loader_resets}
+
     # ---- tooling -------------------------------------------------------------------------
     def profile(self, launcher=None):
         """Time one launcher ("projector_bwd"), every launcher ("*") or none (None) with HIP events."""
