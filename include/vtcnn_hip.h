@@ -200,6 +200,19 @@ int vt_head_fwd(const float *z, const float *pn_stat, const float *pn_gamma, con
                 int H, int K, vt_stream s);
 /* Tensor::argmax_batch + cross-entropy terms (tensor_cpu.hpp:1155-1173, 1294-1307). */
 int vt_metrics(const float *probs, const int *labels, int N, int K, float *loss_sum, int *argmax, vt_stream s);
+/* DataLoader::next_batch on the device (utils/load_dataset.hpp:129-151) with loadImages2D's pixel
+ * conversion (:47-51) fused in: images_u8 = the IDX pixel bytes resident on the device
+ * [S][pixels], labels int [S], indices = n entries of the shuffled order (vt_loader_indices);
+ * x[i] = images_u8[indices[i]] / 255.0f, y[i] = labels[indices[i]] (y may be NULL).
+ * pixels must be a multiple of 4. */
+int vt_loader_gather(const unsigned char *images_u8, const int *labels, const int *indices, int n, int pixels, float *x,
+                     int *y, vt_stream s);
+/* Per-batch bookkeeping of Trainer::evaluate / evaluate_test (utils/trainer.hpp:104-127) kept on
+ * the device: loss_sums[slot] = -sum log(p[label] + 1e-8), correct[slot] = number of arg-max hits,
+ * confusion[truth*K + pred] += 1 (int [K*K], may be NULL; zero it before the first batch),
+ * argmax int [N] (may be NULL).  Read everything back once after the last batch. */
+int vt_eval_accumulate(const float *probs, const int *labels, int N, int K, int slot, float *loss_sums, int *correct,
+                       int *confusion, int *argmax, vt_stream s);
 
 /* SoftmaxLayer::backward with targets (layers/softmax_layer.hpp:29), fc input delta
  * (layers/dense_layer.hpp:98-99), MaxPool2DLayer::backward (pooling_layer.hpp:68-97), ReLU mask

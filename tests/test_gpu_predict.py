@@ -171,3 +171,37 @@ def test_predict_batch_8192_labels_vs_oracle():
     assert decided.mean() > 0.999
     assert np.array_equal(labels[decided], po.argmax(1)[decided])
     assert np.array_equal(labels, p.argmax(1))  # first maximum wins, as Tensor::argmax_batch
+
+
+def test_device_loader_gather_bit_exact_and_eval_bookkeeping():
+    """Device-resident input pipeline: the dataset stays on the GPU as the IDX bytes, a batch is one
+    gather launch with /255.0f fused in.  Bit-exact against the host decode (vt_idx_read_images) in
+    the reference loader's order, ragged last batch included; then the same sweep through
+    Trainer.evaluate_test (device-side loss / hit / confusion bookkeeping) must reproduce the real
+    reference's predictions, loss and accuracy."""
+    from vit_amd import VTCNN, Dims
+    from vit_amd.engine import DataLoader, Trainer, load_dataset
+    g = load_golden("blood_t10k_256.npz")
+    img, lbl, ckpt = _paths()
+    ds = load_dataset(img, lbl, 10000)
+    assert ds.images_u8.dtype == np.uint8 and ds.images_u8.shape == (256, 784)
+    dl = DataLoader(ds.images_u8, ds.labels, 48)  # 256 = 5 * 48 + 16: ragged tail
+    seen = 0
+    while dl.has_next():
+        x, y = dl.next_batch()
+        idx = dl.indices[seen:seen + x.shape[0]]
+        assert np.array_equal(x.cpu().numpy().reshape(x.shape[0], -1), ds.images[idx])
+        assert np.array_equal(y.cpu().numpy(), ds.labels[idx])
+        seen += x.shape[0]
+    assert seen == 256
+    m = VTCNN(Dims(num_classes=8), max_batch=32, seed=42)
+    m.load(ckpt)
+    test_loader = DataLoader(ds.images_u8, ds.labels, 32)
+    tr = Trainer(m, test_loader, test_loader, 8, 32, test_loader=test_loader, out=lambda s: None)
+    loss, acc, pred, truth, cm = tr.evaluate_test()
+    assert np.array_equal(pred, g["pred"]) and np.array_equal(truth, g["truth"])
+    assert abs(loss - float(g["loss"][0])) < 1e-4 * max(1.0, abs(float(g["loss"][0])))
+    assert abs(acc - float(g["acc"][0])) < 1e-5
+    want = np.zeros((8, 8), dtype=np.int64)
+    np.add.at(want, (g["truth"], g["pred"]), 1)
+    assert np.array_equal(cm, want)

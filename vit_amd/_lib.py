@@ -78,6 +78,8 @@ SIGNATURES = {
     "vt_projector_fwd": (i, [p] * 11 + [i, i, p]),
     "vt_head_fwd": (i, [p] * 10 + [i, i, i, p]),
     "vt_metrics": (i, [p, p, i, i, p, p, p]),
+    "vt_loader_gather": (i, [p, p, p, i, i, p, p, p]),
+    "vt_eval_accumulate": (i, [p, p, i, i, i, p, p, p, p, p]),
     "vt_head_bwd": (i, [p] * 11 + [i, i, i, p]),
     "vt_fc_wgrad": (i, [p] * 5 + [i, i, i, p]),
     "vt_bn_bwd_finalize": (i, [p, i, i, l, p, p, p, p, p, p, p]),

@@ -193,6 +193,71 @@ __global__ __launch_bounds__(TPB) void k_metrics(const float *__restrict__ probs
   if (threadIdx.x == 0 && loss_sum) loss_sum[0] = part[0];
 }
 
+// DataLoader::next_batch on the device (reference utils/load_dataset.hpp:129-151 with the pixel
+// conversion of loadImages2D, :47-51, fused in): the dataset stays resident as the IDX file's
+// bytes, a batch is the rows named by a slice of the shuffled index vector, pixel = u8 / 255.0f
+// (IEEE division, as on the host).  One thread per 4 pixels.
+__global__ __launch_bounds__(TPB) void k_loader_gather(const unsigned char *__restrict__ images,
+                                                       const int *__restrict__ labels, const int *__restrict__ indices,
+                                                       int n, int pixels, float *__restrict__ x, int *__restrict__ y) {
+  const int quads = pixels >> 2;  // pixels % 4 == 0 (checked by the launcher)
+  const long t = (long)blockIdx.x * TPB + threadIdx.x;
+  if (t >= (long)n * quads) return;
+  const int i = (int)(t / quads), q = (int)(t % quads);
+  const int src = indices[i];
+  const uchar4 b = *reinterpret_cast<const uchar4 *>(images + (size_t)src * pixels + 4 * q);
+  float4 o;
+  o.x = __fdiv_rn((float)b.x, 255.0f);
+  o.y = __fdiv_rn((float)b.y, 255.0f);
+  o.z = __fdiv_rn((float)b.z, 255.0f);
+  o.w = __fdiv_rn((float)b.w, 255.0f);
+  *reinterpret_cast<float4 *>(x + (size_t)i * pixels + 4 * q) = o;
+  if (q == 0 && y != nullptr) y[i] = labels[src];
+}
+
+// Trainer::evaluate / evaluate_test bookkeeping for one batch without leaving the device
+// (reference utils/trainer.hpp:104-127, tensor_cpu.hpp:1137-1173, 1294-1357): arg-max (first
+// maximum), the batch's cross-entropy sum and number of correct predictions into slot `slot` of
+// two per-batch arrays, and the confusion matrix cm[truth][pred] += 1.  One workgroup; launches
+// of one evaluation run are ordered on their stream, so plain integer adds suffice.
+__global__ __launch_bounds__(TPB) void k_eval_accumulate(const float *__restrict__ probs, const int *__restrict__ labels,
+                                                         int N, int K, int slot, float *__restrict__ loss_sums,
+                                                         int *__restrict__ correct, int *__restrict__ cm,
+                                                         int *__restrict__ argmax) {
+  __shared__ float red[NW];
+  __shared__ int scm[KMAX * KMAX];
+  __shared__ int sok;
+  for (int i = threadIdx.x; i < K * K; i += TPB) scm[i] = 0;
+  if (threadIdx.x == 0) sok = 0;
+  __syncthreads();
+  float part[1] = {0.f};
+  int ok = 0;
+  for (int n = threadIdx.x; n < N; n += TPB) {
+    int best = 0;
+    float bv = probs[(size_t)n * K];
+    for (int k = 1; k < K; ++k) {
+      const float v = probs[(size_t)n * K + k];
+      if (v > bv) {
+        bv = v;
+        best = k;
+      }
+    }
+    const int truth = labels[n];
+    if (argmax) argmax[n] = best;
+    part[0] += -logf(probs[(size_t)n * K + truth] + 1e-8f);
+    ok += best == truth ? 1 : 0;
+    if (truth >= 0 && truth < K) atomicAdd(&scm[truth * K + best], 1);  // LDS integer add: order-independent
+  }
+  atomicAdd(&sok, ok);
+  block_sum<1>(part, red);
+  if (threadIdx.x == 0) {
+    loss_sums[slot] = part[0];
+    correct[slot] = sok;
+  }
+  if (cm != nullptr)
+    for (int i = threadIdx.x; i < K * K; i += TPB) cm[i] += scm[i];
+}
+
 }  // namespace vt
 
 // ---------------------------------------------------------------------------------------------
@@ -223,6 +288,25 @@ extern "C" int vt_bn_stats_finalize(const float *part, int nblocks, int C, long 
 extern "C" int vt_bn_stats_eval(const float *running_mean, const float *running_var, int C, float *stat, vt_stream s) {
   if (C < 1 || C > 64) return VT_EUNSUPPORTED;
   hipLaunchKernelGGL(k_bn_stats_eval, dim3(1), dim3(64), 0, (hipStream_t)s, running_mean, running_var, C, stat);
+  VT_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int vt_loader_gather(const unsigned char *images_u8, const int *labels, const int *indices, int n, int pixels,
+                                float *x, int *y, vt_stream s) {
+  if (n < 1 || pixels < 4 || pixels % 4 != 0 || !images_u8 || !indices || !x || (y && !labels)) return VT_EINVAL;
+  const long threads = (long)n * (pixels / 4);
+  hipLaunchKernelGGL(k_loader_gather, dim3((unsigned)((threads + TPB - 1) / TPB)), dim3(TPB), 0, (hipStream_t)s, images_u8,
+                     labels, indices, n, pixels, x, y);
+  VT_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int vt_eval_accumulate(const float *probs, const int *labels, int N, int K, int slot, float *loss_sums,
+                                  int *correct, int *confusion, int *argmax, vt_stream s) {
+  if (N < 1 || K < 1 || K > KMAX || slot < 0 || !probs || !labels || !loss_sums || !correct) return VT_EINVAL;
+  hipLaunchKernelGGL(k_eval_accumulate, dim3(1), dim3(TPB), 0, (hipStream_t)s, probs, labels, N, K, slot, loss_sums,
+                     correct, confusion, argmax);
   VT_CHECK_LAUNCH();
   return 0;
 }

@@ -204,9 +204,10 @@ class VTCNN:
 # Data path (reference utils/load_dataset.hpp)
 # ---------------------------------------------------------------------------------------------
 class Dataset:
-    def __init__(self, images, labels):
-        self.images = images  # float32 [S, rows*cols]
+    def __init__(self, images, labels, images_u8=None):
+        self.images = images  # float32 [S, rows*cols] = u8 / 255.0f
         self.labels = labels  # int32 [S]
+        self.images_u8 = images_u8  # the IDX pixel bytes [S, rows*cols], when loaded from a file
 
 
 def load_dataset(image_path, label_path, max_samples=9999999):
@@ -224,7 +225,10 @@ def load_dataset(image_path, label_path, max_samples=9999999):
     check(lib.vt_idx_read_labels(str(label_path).encode(), max_samples, C.c_void_p(lbl.ctypes.data), C.byref(m)))
     if imgs.shape[0] != lbl.shape[0]:
         raise RuntimeError("El número de imágenes y etiquetas no coincide")
-    return Dataset(imgs, lbl)
+    raw = np.fromfile(str(image_path), dtype=np.uint8, offset=16, count=imgs.size)
+    u8 = np.zeros(imgs.size, dtype=np.uint8)  # a short file leaves the missing pixels at 0, as the float path does
+    u8[:raw.size] = raw
+    return Dataset(imgs, lbl, u8.reshape(imgs.shape))
 
 
 def loader_indices(n, seed=42, resets=0):
@@ -250,15 +254,21 @@ class DataLoader:
         self.index = 0
         self.indices = loader_indices(self.n, seed, 0)
         dev = device or torch.device("cuda", torch.cuda.current_device())
-        self._images = torch.from_numpy(np.ascontiguousarray(images, dtype=np.float32)).to(dev)
+        # uint8 input (Dataset.images_u8): the dataset stays resident as bytes and a batch is one
+        # gather launch with the /255.0f fused in; float input: resident floats, same gather in torch
+        self._u8 = np.asarray(images).dtype == np.uint8
+        if self._u8:
+            self._images = torch.from_numpy(np.ascontiguousarray(images, dtype=np.uint8)).to(dev)
+        else:
+            self._images = torch.from_numpy(np.ascontiguousarray(images, dtype=np.float32)).to(dev)
         self._labels = torch.from_numpy(np.ascontiguousarray(labels, dtype=np.int32)).to(dev)
-        self._idx_dev = torch.from_numpy(self.indices.astype(np.int64)).to(dev)
+        self._idx_dev = torch.from_numpy(self.indices.astype(np.int32 if self._u8 else np.int64)).to(dev)
 
     def reset(self):
         self.index = 0
         self._resets += 1
         self.indices = loader_indices(self.n, self.seed, self._resets)
-        self._idx_dev = torch.from_numpy(self.indices.astype(np.int64)).to(self._images.device)
+        self._idx_dev = torch.from_numpy(self.indices.astype(np.int32 if self._u8 else np.int64)).to(self._images.device)
 
     def has_next(self):
         return self.index < self.n
@@ -269,7 +279,16 @@ class DataLoader:
     def next_batch(self):
         end = min(self.index + self.batch_size, self.n)
         sel = self._idx_dev[self.index:end]
+        nb = end - self.index
         self.index = end
+        if self._u8:
+            pixels = self._images.shape[1]
+            x = torch.empty((nb,) + self.shape, dtype=torch.float32, device=self._images.device)
+            y = torch.empty(nb, dtype=torch.int32, device=self._images.device)
+            check(lib.vt_loader_gather(C.c_void_p(self._images.data_ptr()), C.c_void_p(self._labels.data_ptr()),
+                                       C.c_void_p(sel.data_ptr()), nb, pixels, C.c_void_p(x.data_ptr()),
+                                       C.c_void_p(y.data_ptr()), _stream_handle()), "vt_loader_gather")
+            return x, y
         x = self._images.index_select(0, sel).reshape(-1, *self.shape).contiguous()
         y = self._labels.index_select(0, sel).contiguous()
         return x, y
@@ -283,21 +302,35 @@ class Trainer:
         self.num_classes, self.batch_size, self.out = num_classes, batch_size, out
 
     def _epoch_eval(self, loader):
-        loss_sum, acc_sum, batches = 0.0, 0.0, 0
-        preds, truth = [], []
+        """Forward-only sweep in eval mode; per-batch loss sums, hit counts and the confusion matrix
+        stay on the device (vt_eval_accumulate) and are read back once at the end."""
+        dev = self.model.device
+        nb = loader.total_batches()
+        k = self.num_classes
+        loss_sums = torch.zeros(nb, dtype=torch.float32, device=dev)
+        correct = torch.zeros(nb, dtype=torch.int32, device=dev)
+        cm = torch.zeros(k * k, dtype=torch.int32, device=dev)
+        preds, truth, sizes = [], [], []
         self.model.set_training(False)
+        b = 0
         while loader.has_next():
             x, y = loader.next_batch()
-            self.model.forward(x)
-            ls, am = self.model.metrics(y)
-            n = y.numel()
-            loss_sum += float(ls.item()) / n
-            acc_sum += float((am == y).sum().item()) / n
-            batches += 1
-            preds.append(am.cpu().numpy())
-            truth.append(y.cpu().numpy())
+            p = self.model.forward(x)
+            am = torch.empty(y.numel(), dtype=torch.int32, device=dev)
+            check(lib.vt_eval_accumulate(C.c_void_p(p.data_ptr()), C.c_void_p(y.data_ptr()), y.numel(), k, b,
+                                         C.c_void_p(loss_sums.data_ptr()), C.c_void_p(correct.data_ptr()),
+                                         C.c_void_p(cm.data_ptr()), C.c_void_p(am.data_ptr()), _stream_handle()),
+                  "vt_eval_accumulate")
+            preds.append(am)
+            truth.append(y)
+            sizes.append(y.numel())
+            b += 1
         self.model.set_training(True)
-        return loss_sum / batches, acc_sum / batches, np.concatenate(preds), np.concatenate(truth)
+        sizes = np.asarray(sizes, dtype=np.float64)
+        ls = loss_sums[:b].cpu().numpy().astype(np.float64) / sizes  # per-batch means, then their mean
+        ac = correct[:b].cpu().numpy().astype(np.float64) / sizes    # (utils/trainer.hpp:112-127)
+        self._last_cm = cm.cpu().numpy().reshape(k, k).astype(np.int64)
+        return float(ls.mean()), float(ac.mean()), torch.cat(preds).cpu().numpy(), torch.cat(truth).cpu().numpy()
 
     def train(self, epochs, log_every=100, device="hip"):
         for epoch in range(epochs):
@@ -336,8 +369,7 @@ class Trainer:
         loss, acc, pred, truth = self._epoch_eval(self.test_loader)
         self.out("[TEST] Final Evaluation — Loss: %.4f | Accuracy: %.4f%%" % (loss, acc * 100.0))
         k = self.num_classes
-        cm = np.zeros((k, k), dtype=np.int64)
-        np.add.at(cm, (truth, pred), 1)
+        cm = self._last_cm  # accumulated on the device, confusion[truth][pred]
         self.out("\n🧩 Matriz de Confusión:\n    " + "".join("%4d" % j for j in range(k)))
         for i_ in range(k):
             self.out("%2d: " % i_ + "".join("%4d" % cm[i_, j] for j in range(k)))
