@@ -132,6 +132,8 @@ def main():
     ap.add_argument("--classes", type=int, default=8)
     ap.add_argument("--mode", choices=("train", "predict"), default="train",
                     help="train: the headline metric; predict: forward-only images/sec (eval mode)")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the step as one HIP graph (single GPU, train mode; for small batches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel", default=None, help="launcher to time with HIP events (default: the slowest)")
     a = ap.parse_args()
@@ -159,8 +161,17 @@ def main():
     if a.mode == "predict":
         m.set_training(False)
 
+    use_graph = a.graph and world == 1 and a.mode == "train"
+    if use_graph:
+        xbuf, ybuf = torch.empty_like(xs[0]), torch.empty_like(ys[0])
+        m.capture_step(xbuf, ybuf, float(B))
+
     def step(i):
-        if a.mode == "predict":
+        if use_graph:
+            xbuf.copy_(xs[i % nb], non_blocking=True)
+            ybuf.copy_(ys[i % nb], non_blocking=True)
+            m.step_graph()
+        elif a.mode == "predict":
             m.forward(xs[i % nb])
         else:
             dp.train_step(xs[i % nb], ys[i % nb], B)
@@ -228,7 +239,7 @@ def main():
             "config": {"workload": ("VTCNN train step (forward+backward+SGD)" if a.mode == "train" else
                                     "VTCNN predict step (eval-mode forward)") + ", BloodMNIST shape 1x28x28, %d classes, "
                                    "mini-batch %d per GPU, fp32, seed-42 reference init" % (a.classes, B),
-                       "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world,
+                       "hip_graph": bool(use_graph), "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world,
                        "grad_allreduce_floats": int(m.layout.n_trainable) if world > 1 else 0},
             "roofline": roof,
             "whole_step_hbm_frac": round(value / world * total_bytes / (HBM_PEAK_GBS * 1e9), 4),

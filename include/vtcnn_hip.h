@@ -88,6 +88,16 @@ int vt_model_backward(vt_model *m, const int *d_labels, vt_stream s);
  * utils/optimizer.hpp:22-28):  g <- g * (1/divisor);  w <- w - g * lr  over the trainable region.
  * The reference always passes divisor = Trainer::batch_size = 32 (utils/trainer.hpp:53). */
 int vt_model_sgd_step(vt_model *m, float lr, float divisor, vt_stream s);
+/* One training step (forward, backward, SGD update) captured once as a HIP graph and replayed:
+ * at the reference's own batch size of 32 the step is ~30 launches of a few microseconds each and
+ * launch overhead, not arithmetic, sets the step time.  x_dev / y_dev / n / lr / divisor are baked
+ * into the graph: the caller refills the same two device buffers before every launch (for
+ * instance with vt_loader_gather).  Capture runs on a stream owned by the model; launch enqueues
+ * the whole step on stream s.  Re-capturing replaces the previous graph.  No counterpart in the
+ * reference. */
+int vt_model_graph_capture(vt_model *m, const float *x_dev, const int *y_dev, int n, float lr, float divisor);
+int vt_model_graph_launch(vt_model *m, vt_stream s);
+
 /* Tensor::compute_loss + argmax of the last forward (tensor_cpu.hpp:1137-1173, 1294-1307):
  * d_loss_sum device float[1] = sum over samples of -log(p[label] + 1e-8); d_argmax device int32[n].
  * Either may be NULL. */

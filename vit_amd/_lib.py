@@ -56,6 +56,8 @@ SIGNATURES = {
     "vt_model_backward": (i, [p, p, p]),
     "vt_model_sgd_step": (i, [p, f, f, p]),
     "vt_model_metrics": (i, [p, p, p, p, p]),
+    "vt_model_graph_capture": (i, [p, p, p, i, f, f]),
+    "vt_model_graph_launch": (i, [p, p]),
     "vt_model_read": (l, [p, C.c_char_p, p, l]),
     "vt_model_profile": (i, [p, C.c_char_p]),
     "vt_model_profile_read": (i, [p, i, C.c_char_p, i, C.POINTER(f), C.POINTER(i)]),

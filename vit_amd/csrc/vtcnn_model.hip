@@ -32,6 +32,9 @@ struct vt_model {
   vt_layout lo;
   int maxN = 0, device = 0, lastN = 0, training = 1;
   int P = 0, Q = 0, K = 0;
+  hipStream_t gstream = nullptr;  // capture stream of the step graph
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t graph_exec = nullptr;
   bool keep_internals = false;  // also store the two attention maps (test aid)
   bool own_arena = false, own_grads = false;
   float *arena = nullptr, *grads = nullptr;
@@ -163,6 +166,9 @@ extern "C" int vt_model_destroy(vt_model *m) {
   if (!m) return 0;
   (void)hipSetDevice(m->device);
   (void)hipDeviceSynchronize();
+  if (m->graph_exec) (void)hipGraphExecDestroy(m->graph_exec);
+  if (m->graph) (void)hipGraphDestroy(m->graph);
+  if (m->gstream) (void)hipStreamDestroy(m->gstream);
   for (void *p : m->allocs) (void)hipFree(p);
   for (hipEvent_t e : m->prof_ev) (void)hipEventDestroy(e);
   delete m;
@@ -716,7 +722,9 @@ extern "C" int vt_model_backward(vt_model *m, const int *d_labels, vt_stream s) 
   STEP("mha_bwd_rows", vt_mha_bwd_rows(m->qkv, m->dc, m->tok, m->sc_mha, n, L, s));
   STEP("mha_bwd_wgrad", vt_mha_bwd_wgrad(m->qkv, m->dc, m->tok, m->P_("mha.q0.W"), m->G_("mha.q0.W"), m->sc_mha, n, L, s));
   // the output projection's cached input is the zero concat: its gradient is exactly zero
-  HIPCHK(hipMemsetAsync(m->G_("mha.o.W"), 0, sizeof(float) * D * D, hs));
+  // (a reduction over zero slab rows writes the zeros: it rides in the fused reduction launch and keeps
+  // memset nodes, which did not replay reliably, out of the captured step graph)
+  VTCHK(reduce_rows(m->gslab, 0, D * D, D * D, m->G_("mha.o.W"), hs));
   // tokenizer.backward2(projector token delta, projector input delta) + BatchNorm2D + conv
   STEP("tokenizer_bwd", vt_tokenizer_bwd(m->conv, m->stat_bn, m->P_("bn.gamma"), m->P_("bn.beta"), m->tokstat, m->dT0,
                          m->P_("tok.linear1.W"), m->P_("tok.linear1.b"), m->pdx, m->dy, m->part, n, P, s));
@@ -731,6 +739,33 @@ extern "C" int vt_model_backward(vt_model *m, const int *d_labels, vt_stream s) 
 extern "C" int vt_model_sgd_step(vt_model *m, float lr, float divisor, vt_stream s) {
   if (!m) return VT_EINVAL;
   STEP("sgd_update", vt_sgd_update(m->arena, m->grads, m->lo.n_trainable, lr, divisor, 1, s));
+  return 0;
+}
+
+extern "C" int vt_model_graph_capture(vt_model *m, const float *x_dev, const int *y_dev, int n, float lr, float divisor) {
+  if (!m || !x_dev || !y_dev || n < 1 || n > m->maxN || divisor == 0.f) return VT_EINVAL;
+  HIPCHK(hipSetDevice(m->device));
+  if (!m->gstream) HIPCHK(hipStreamCreateWithFlags(&m->gstream, hipStreamNonBlocking));
+  if (m->graph_exec) { (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
+  if (m->graph) { (void)hipGraphDestroy(m->graph); m->graph = nullptr; }
+  const std::string saved = m->prof_filter;
+  m->prof_filter.clear();  // no timing events inside the captured region
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipStreamBeginCapture(m->gstream, hipStreamCaptureModeThreadLocal));
+  int rc = vt_model_forward(m, x_dev, n, nullptr, (vt_stream)m->gstream);
+  if (rc == 0) rc = vt_model_backward(m, y_dev, (vt_stream)m->gstream);
+  if (rc == 0) rc = vt_model_sgd_step(m, lr, divisor, (vt_stream)m->gstream);
+  const hipError_t e = hipStreamEndCapture(m->gstream, &m->graph);
+  m->prof_filter = saved;
+  if (rc != 0) return rc;
+  if (e != hipSuccess) return (int)e;
+  HIPCHK(hipGraphInstantiate(&m->graph_exec, m->graph, nullptr, nullptr, 0));
+  return 0;
+}
+
+extern "C" int vt_model_graph_launch(vt_model *m, vt_stream s) {
+  if (!m || !m->graph_exec) return VT_EINVAL;
+  HIPCHK(hipGraphLaunch(m->graph_exec, (hipStream_t)s));
   return 0;
 }
 

@@ -131,6 +131,19 @@ class VTCNN:
     def zero_grad(self):
         self.grads.zero_()
 
+    def capture_step(self, x, labels, batch_size=32.0):
+        """Captures forward + backward + SGD on the fixed device buffers x / labels as one HIP
+        graph; replay with step_graph() after refilling the same buffers."""
+        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+        assert labels.is_cuda and labels.dtype == torch.int32 and labels.numel() == x.shape[0]
+        self._n = x.shape[0]
+        self._x, self._y = x, labels  # keep alive: the graph holds their addresses
+        check(lib.vt_model_graph_capture(self._h, C.c_void_p(x.data_ptr()), C.c_void_p(labels.data_ptr()), self._n,
+                                         self.lr, float(batch_size)), "vt_model_graph_capture")
+
+    def step_graph(self):
+        check(lib.vt_model_graph_launch(self._h, _stream_handle()), "vt_model_graph_launch")
+
     def metrics(self, labels=None):
         """(sum of cross-entropy terms, argmax labels) of the last forward, computed on the device."""
         loss = torch.zeros(1, dtype=torch.float32, device=self.device)
