@@ -132,6 +132,9 @@ def main():
     ap.add_argument("--classes", type=int, default=8)
     ap.add_argument("--mode", choices=("train", "predict"), default="train",
                     help="train: the headline metric; predict: forward-only images/sec (eval mode)")
+    ap.add_argument("--group", type=int, default=0,
+                    help="predict mode: the batch is consecutive reference mini-batches of this many images, "
+                         "each with its own BatchNorm1D statistics (what run.sh predict evaluates)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step as one HIP graph (single GPU, train mode; for small batches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -171,6 +174,8 @@ def main():
             xbuf.copy_(xs[i % nb], non_blocking=True)
             ybuf.copy_(ys[i % nb], non_blocking=True)
             m.step_graph()
+        elif a.mode == "predict" and a.group > 0:
+            m.forward_grouped(xs[i % nb], a.group)
         elif a.mode == "predict":
             m.forward(xs[i % nb])
         else:
@@ -239,7 +244,7 @@ def main():
             "config": {"workload": ("VTCNN train step (forward+backward+SGD)" if a.mode == "train" else
                                     "VTCNN predict step (eval-mode forward)") + ", BloodMNIST shape 1x28x28, %d classes, "
                                    "mini-batch %d per GPU, fp32, seed-42 reference init" % (a.classes, B),
-                       "hip_graph": bool(use_graph), "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world,
+                       "hip_graph": bool(use_graph), "statistics_group": a.group if a.mode == "predict" else 0, "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world,
                        "grad_allreduce_floats": int(m.layout.n_trainable) if world > 1 else 0},
             "roofline": roof,
             "whole_step_hbm_frac": round(value / world * total_bytes / (HBM_PEAK_GBS * 1e9), 4),

@@ -84,6 +84,13 @@ int vt_model_forward(vt_model *m, const float *d_images, int n, float *d_probs, 
 /* VTCNN::backward (model/vit_cnn.hpp:215-242) for the mini-batch of the last forward; d_labels:
  * device int32 [n].  Leaves the summed gradients in the gradient arena (overwrites it). */
 int vt_model_backward(vt_model *m, const int *d_labels, vt_stream s);
+/* Evaluation sweep in one launch set (eval mode only): the n images are consecutive mini-batches
+ * of `group` images (a multiple of 4; the last batch may be short), each normalised with its own
+ * BatchNorm1D statistics exactly as Trainer::evaluate / evaluate_test see them batch after batch
+ * (utils/trainer.hpp:104-127, 172-197); the running statistics end as after that loop.  The
+ * probabilities equal those of calling vt_model_forward on each batch up to the rounding of the
+ * statistics (1e-6 relative).  No backward. */
+int vt_model_forward_grouped(vt_model *m, const float *d_images, int n, int group, float *d_probs, vt_stream s);
 /* VTCNN::update_weights + SGD::update + zero_grad (model/vit_cnn.hpp:244-260,
  * utils/optimizer.hpp:22-28):  g <- g * (1/divisor);  w <- w - g * lr  over the trainable region.
  * The reference always passes divisor = Trainer::batch_size = 32 (utils/trainer.hpp:53). */
@@ -171,6 +178,12 @@ int vt_conv3x3_fwd(const float *x, const float *w, const float *b, float *conv_o
  * stat[2][C] = (mean, 1/sqrt(var+eps)) and updates the running statistics. */
 int vt_bn_stats_finalize(const float *part, int nblocks, int C, long rows_per_block, long rows_total,
                          float *running_mean, float *running_var, float *stat, vt_stream s);
+/* The same for consecutive groups of blocks_per_group partial blocks (the last group may be
+ * short): stat[g][2][C] per group; batch_mv[groups][2][C] is scratch; the running statistics
+ * receive the groups' updates one after another, in order. */
+int vt_bn_stats_finalize_grouped(const float *part, int nblocks, int blocks_per_group, int C, long rows_per_block,
+                                 long rows_total, float *running_mean, float *running_var, float *stat, float *batch_mv,
+                                 vt_stream s);
 /* Eval-mode statistics (batch_normalization_layer.hpp:287-291): stat from the running buffers. */
 int vt_bn_stats_eval(const float *running_mean, const float *running_var, int C, float *stat, vt_stream s);
 /* BatchNorm2D apply + flatten/transpose (model/vit_cnn.hpp:127-134) + FilterTokenizer::forward
@@ -208,6 +221,17 @@ int vt_projector_fwd(const float *conv_out, const float *bn_stat, const float *b
 int vt_head_fwd(const float *z, const float *pn_stat, const float *pn_gamma, const float *pn_beta, const float *wfc,
                 const float *bfc, float *pooled, unsigned char *pool_idx, float *logits, float *probs, int N,
                 int H, int K, vt_stream s);
+/* Grouped forms of three launchers above: statistics records are per group (n1_stat / n2_stat /
+ * pn_stat = [groups][2][C]); group_rows must be a multiple of 64, group counts images; 0 = one group. */
+int vt_transformer_ffn_fwd_grouped(const float *tokens, const float *n1_stat, const float *n1_gamma, const float *n1_beta,
+                                   const float *w1, const float *b1, const float *w2, const float *b2, float *a,
+                                   float *hdn, float *s2, float *part_n2, long rows, long group_rows, vt_stream s);
+int vt_projector_tokens_fwd_grouped(const float *s2, const float *n2_stat, const float *n2_gamma, const float *n2_beta,
+                                    const float *wq, const float *wk, const float *wv, const float *bv, float *o,
+                                    float *pk, int N, int group, vt_stream s);
+int vt_head_fwd_grouped(const float *z, const float *pn_stat, const float *pn_gamma, const float *pn_beta,
+                        const float *wfc, const float *bfc, float *pooled, unsigned char *pool_idx, float *logits,
+                        float *probs, int N, int H, int K, int group, vt_stream s);
 /* Tensor::argmax_batch + cross-entropy terms (tensor_cpu.hpp:1155-1173, 1294-1307). */
 int vt_metrics(const float *probs, const int *labels, int N, int K, float *loss_sum, int *argmax, vt_stream s);
 /* DataLoader::next_batch on the device (utils/load_dataset.hpp:129-151) with loadImages2D's pixel
@@ -223,6 +247,10 @@ int vt_loader_gather(const unsigned char *images_u8, const int *labels, const in
  * argmax int [N] (may be NULL).  Read everything back once after the last batch. */
 int vt_eval_accumulate(const float *probs, const int *labels, int N, int K, int slot, float *loss_sums, int *correct,
                        int *confusion, int *argmax, vt_stream s);
+/* The same for N images that are consecutive mini-batches of `group` images (the last may be
+ * short): batch g of the call fills slot slot0 + g. */
+int vt_eval_accumulate_grouped(const float *probs, const int *labels, int N, int K, int group, int slot0,
+                               float *loss_sums, int *correct, int *confusion, int *argmax, vt_stream s);
 
 /* SoftmaxLayer::backward with targets (layers/softmax_layer.hpp:29), fc input delta
  * (layers/dense_layer.hpp:98-99), MaxPool2DLayer::backward (pooling_layer.hpp:68-97), ReLU mask

@@ -205,3 +205,51 @@ def test_device_loader_gather_bit_exact_and_eval_bookkeeping():
     want = np.zeros((8, 8), dtype=np.int64)
     np.add.at(want, (g["truth"], g["pred"]), 1)
     assert np.array_equal(cm, want)
+    # the same sweep with room for several loader batches per launch set (grouped forward: every
+    # batch of 32 keeps its own BatchNorm1D statistics): same predictions, loss, accuracy
+    m4 = VTCNN(Dims(num_classes=8), max_batch=96, seed=42)  # 3 batches per call: 256 = 2*96 + 64
+    m4.load(ckpt)
+    loader4 = DataLoader(ds.images_u8, ds.labels, 32)
+    tr4 = Trainer(m4, loader4, loader4, 8, 32, test_loader=loader4, out=lambda s: None)
+    loss4, acc4, pred4, truth4, cm4 = tr4.evaluate_test()
+    assert np.array_equal(pred4, g["pred"]) and np.array_equal(truth4, g["truth"]) and np.array_equal(cm4, want)
+    assert abs(loss4 - float(g["loss"][0])) < 1e-4 * max(1.0, abs(float(g["loss"][0])))
+    assert abs(acc4 - float(g["acc"][0])) < 1e-5
+
+
+@pytest.mark.parametrize("n", [256, 250])
+def test_grouped_forward_matches_batch_by_batch(n):
+    """vt_model_forward_grouped: an evaluation sweep (consecutive loader batches of 32, last one
+    short when n = 250) in one launch set.  Probabilities and the final running statistics must
+    equal those of forwarding the batches one after another up to rounding of the statistics (the
+    projector's variance is accumulated around its running mean, which moves between batches in the
+    sequential run: 1e-6 relative), labels exactly; for the full 256-image slice they must match
+    the real reference's probabilities and labels."""
+    from vit_amd import VTCNN, Dims
+    from vit_amd.engine import load_dataset
+    g = load_golden("blood_t10k_256.npz")
+    img, lbl, ckpt = _paths()
+    ds = load_dataset(img, lbl, 10000)
+    order = torch.from_numpy(g["order"][:n].astype(np.int64))
+    x = torch.from_numpy(ds.images.reshape(256, 1, 28, 28))[order].contiguous().cuda()
+    a = VTCNN(Dims(num_classes=8), max_batch=256, seed=42)
+    a.load(ckpt)
+    a.set_training(False)
+    seq = torch.cat([a.forward(x[s:s + 32]).clone() for s in range(0, n, 32)]).cpu().numpy()
+    b = VTCNN(Dims(num_classes=8), max_batch=256, seed=42)
+    b.load(ckpt)
+    b.set_training(False)
+    grp = b.forward_grouped(x, 32).cpu().numpy()
+    assert rel_err(grp, seq) < 1e-6
+    assert np.array_equal(grp.argmax(1), seq.argmax(1))
+    nt = a.layout.n_trainable
+    assert np.array_equal(a.get_arena()[:nt], b.get_arena()[:nt])
+    assert np.allclose(a.get_arena()[nt:], b.get_arena()[nt:], rtol=1e-5, atol=1e-7)  # running statistics, batch order
+    if n == 256:
+        assert rel_err(grp, g["probs"]) < 1e-4
+        assert np.array_equal(grp.argmax(1), g["pred"])
+    with pytest.raises(Exception):
+        b.backward(torch.zeros(n, dtype=torch.int32, device="cuda"))  # no backward after a grouped forward
+    b.set_training(True)
+    with pytest.raises(Exception):
+        b.forward_grouped(x, 32)  # training mode: BatchNorm2D would couple the groups

@@ -53,6 +53,7 @@ SIGNATURES = {
     "vt_model_set_training": (i, [p, i]),
     "vt_model_keep_internals": (i, [p, i]),
     "vt_model_forward": (i, [p, p, i, p, p]),
+    "vt_model_forward_grouped": (i, [p, p, i, i, p, p]),
     "vt_model_backward": (i, [p, p, p]),
     "vt_model_sgd_step": (i, [p, f, f, p]),
     "vt_model_metrics": (i, [p, p, p, p, p]),
@@ -73,7 +74,11 @@ SIGNATURES = {
     "vt_loader_indices": (i, [i, u, i, p]),
     "vt_conv3x3_fwd": (i, [p, p, p, p, p, i, i, i, i, p]),
     "vt_bn_stats_finalize": (i, [p, i, i, l, l, p, p, p, p]),
+    "vt_bn_stats_finalize_grouped": (i, [p, i, i, i, l, l, p, p, p, p, p]),
     "vt_bn_stats_eval": (i, [p, p, i, p, p]),
+    "vt_transformer_ffn_fwd_grouped": (i, [p] * 12 + [l, l, p]),
+    "vt_projector_tokens_fwd_grouped": (i, [p] * 10 + [i, i, p]),
+    "vt_head_fwd_grouped": (i, [p] * 10 + [i, i, i, i, p]),
     "vt_tokenizer_fwd": (i, [p] * 12 + [i, i, p]),
     "vt_transformer_ffn_fwd": (i, [p] * 12 + [l, p]),
     "vt_projector_tokens_fwd": (i, [p] * 10 + [i, p]),
@@ -82,6 +87,7 @@ SIGNATURES = {
     "vt_metrics": (i, [p, p, i, i, p, p, p]),
     "vt_loader_gather": (i, [p, p, p, i, i, p, p, p]),
     "vt_eval_accumulate": (i, [p, p, i, i, i, p, p, p, p, p]),
+    "vt_eval_accumulate_grouped": (i, [p, p, i, i, i, i, p, p, p, p, p]),
     "vt_head_bwd": (i, [p] * 11 + [i, i, i, p]),
     "vt_fc_wgrad": (i, [p] * 5 + [i, i, i, p]),
     "vt_bn_bwd_finalize": (i, [p, i, i, l, p, p, p, p, p, p, p]),

@@ -102,13 +102,20 @@ __device__ __forceinline__ double wave_sum_d(double x) {
   for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
   return x;
 }
-__global__ __launch_bounds__(FIN_T) void k_bn_stats_finalize(const float *__restrict__ part, int nb, int C,
-                                                             long rows_per_block, long rows_total,
+// Grouped form (blockIdx.y = statistics group): group g owns blocks [g*nbpg, (g+1)*nbpg) and
+// rows [g*rows_group, ...); its statistics go to stat[g][2C] and, instead of touching the running
+// buffers, its (mean, biased var) to batch_mv[g][2C] for k_bn_running_seq.  With one group the
+// running buffers are updated here.
+__global__ __launch_bounds__(FIN_T) void k_bn_stats_finalize(const float *__restrict__ part, int nb_total, int nbpg, int C,
+                                                             long rows_per_block, long rows_group, long rows_total,
                                                              float *__restrict__ run_mean, float *__restrict__ run_var,
-                                                             float *__restrict__ stat) {
+                                                             float *__restrict__ stat, float *__restrict__ batch_mv) {
   __shared__ double sh[3][FIN_T / 64];
-  const int tid = threadIdx.x, c = blockIdx.x;
-  const long last_cnt = rows_total - (long)(nb - 1) * rows_per_block;
+  const int tid = threadIdx.x, c = blockIdx.x, grp = blockIdx.y;
+  const int bfirst = grp * nbpg, nb = min(nbpg, nb_total - bfirst);
+  const long rows_here = min(rows_group, rows_total - (long)grp * rows_group);
+  part += (size_t)bfirst * 2 * C;
+  const long last_cnt = rows_here - (long)(nb - 1) * rows_per_block;
   const double rc = 1.0 / (double)rows_per_block, rc_last = 1.0 / (double)last_cnt;
   double S = 0.0, Q = 0.0, U = 0.0;
   for (int b0 = tid; b0 < nb; b0 += 8 * FIN_T) {
@@ -147,17 +154,48 @@ __global__ __launch_bounds__(FIN_T) void k_bn_stats_finalize(const float *__rest
       q += sh[1][k];
       u += sh[2][k];
     }
-    const double R = (double)rows_total;
+    const double R = (double)rows_here;
     const double mu = s / R;
     double m2 = q + u - s * s / R;
     if (m2 < 0.0) m2 = 0.0;
     const float mean = (float)mu;
     const float var = (float)(m2 / R);
-    stat[c] = mean;
-    stat[C + c] = 1.0f / sqrtf(var + BN_EPS);
-    run_mean[c] = mean * BN_MOM + run_mean[c] * (1 - BN_MOM);
-    run_var[c] = var * BN_MOM + run_var[c] * (1 - BN_MOM);
+    stat[(size_t)grp * 2 * C + c] = mean;
+    stat[(size_t)grp * 2 * C + C + c] = 1.0f / sqrtf(var + BN_EPS);
+    if (batch_mv != nullptr) {
+      batch_mv[(size_t)grp * 2 * C + c] = mean;
+      batch_mv[(size_t)grp * 2 * C + C + c] = var;
+    } else {
+      run_mean[c] = mean * BN_MOM + run_mean[c] * (1 - BN_MOM);
+      run_var[c] = var * BN_MOM + run_var[c] * (1 - BN_MOM);
+    }
   }
+}
+
+// running = 0.1*batch + 0.9*running applied once per group, in group order: what the reference's
+// loop over mini-batches leaves in the running buffers (batch_normalization_layer.hpp:156-159).
+__global__ void k_bn_running_seq(const float *__restrict__ batch_mv, int groups, int C, float *__restrict__ run_mean,
+                                 float *__restrict__ run_var) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float rm = run_mean[c], rv = run_var[c];
+  for (int g0 = 0; g0 < groups; g0 += 16) {  // 32 independent loads, then the ordered recurrence
+    float bm[16], bv[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int g = min(g0 + k, groups - 1);
+      bm[k] = batch_mv[(size_t)g * 2 * C + c];
+      bv[k] = batch_mv[(size_t)g * 2 * C + C + c];
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+      if (g0 + k < groups) {
+        rm = bm[k] * BN_MOM + rm * (1 - BN_MOM);
+        rv = bv[k] * BN_MOM + rv * (1 - BN_MOM);
+      }
+  }
+  run_mean[c] = rm;
+  run_var[c] = rv;
 }
 
 // Eval-mode statistics from the running buffers (batch_normalization_layer.hpp:287-291).
@@ -218,21 +256,24 @@ __global__ __launch_bounds__(TPB) void k_loader_gather(const unsigned char *__re
 // Trainer::evaluate / evaluate_test bookkeeping for one batch without leaving the device
 // (reference utils/trainer.hpp:104-127, tensor_cpu.hpp:1137-1173, 1294-1357): arg-max (first
 // maximum), the batch's cross-entropy sum and number of correct predictions into slot `slot` of
-// two per-batch arrays, and the confusion matrix cm[truth][pred] += 1.  One workgroup; launches
-// of one evaluation run are ordered on their stream, so plain integer adds suffice.
+// two per-batch arrays, and the confusion matrix cm[truth][pred] += 1 (integer atomics: the result
+// does not depend on their order).  One workgroup per mini-batch of the sweep.
 __global__ __launch_bounds__(TPB) void k_eval_accumulate(const float *__restrict__ probs, const int *__restrict__ labels,
-                                                         int N, int K, int slot, float *__restrict__ loss_sums,
+                                                         int N, int K, int group, int slot0, float *__restrict__ loss_sums,
                                                          int *__restrict__ correct, int *__restrict__ cm,
                                                          int *__restrict__ argmax) {
   __shared__ float red[NW];
   __shared__ int scm[KMAX * KMAX];
   __shared__ int sok;
+  // workgroup = one mini-batch of the sweep: images [first, first + cnt)
+  const int first = blockIdx.x * group, cnt = min(group, N - first);
   for (int i = threadIdx.x; i < K * K; i += TPB) scm[i] = 0;
   if (threadIdx.x == 0) sok = 0;
   __syncthreads();
   float part[1] = {0.f};
   int ok = 0;
-  for (int n = threadIdx.x; n < N; n += TPB) {
+  for (int i = threadIdx.x; i < cnt; i += TPB) {
+    const int n = first + i;
     int best = 0;
     float bv = probs[(size_t)n * K];
     for (int k = 1; k < K; ++k) {
@@ -246,16 +287,17 @@ __global__ __launch_bounds__(TPB) void k_eval_accumulate(const float *__restrict
     if (argmax) argmax[n] = best;
     part[0] += -logf(probs[(size_t)n * K + truth] + 1e-8f);
     ok += best == truth ? 1 : 0;
-    if (truth >= 0 && truth < K) atomicAdd(&scm[truth * K + best], 1);  // LDS integer add: order-independent
+    if (truth >= 0 && truth < K) atomicAdd(&scm[truth * K + best], 1);  // integer add: order-independent
   }
   atomicAdd(&sok, ok);
   block_sum<1>(part, red);
   if (threadIdx.x == 0) {
-    loss_sums[slot] = part[0];
-    correct[slot] = sok;
+    loss_sums[slot0 + blockIdx.x] = part[0];
+    correct[slot0 + blockIdx.x] = sok;
   }
   if (cm != nullptr)
-    for (int i = threadIdx.x; i < K * K; i += TPB) cm[i] += scm[i];
+    for (int i = threadIdx.x; i < K * K; i += TPB)
+      if (scm[i] != 0) atomicAdd(&cm[i], scm[i]);
 }
 
 }  // namespace vt
@@ -279,8 +321,24 @@ extern "C" int vt_bn_stats_finalize(const float *part, int nblocks, int C, long 
                                     float *running_mean, float *running_var, float *stat, vt_stream s) {
   if (C < 1 || C > 1024 || nblocks < 1) return VT_EUNSUPPORTED;
   if ((long)(nblocks - 1) * rows_per_block >= rows_total || (long)nblocks * rows_per_block < rows_total) return VT_EINVAL;
-  hipLaunchKernelGGL(k_bn_stats_finalize, dim3(C), dim3(FIN_T), 0, (hipStream_t)s, part, nblocks, C, rows_per_block,
-                     rows_total, running_mean, running_var, stat);
+  hipLaunchKernelGGL(k_bn_stats_finalize, dim3(C, 1), dim3(FIN_T), 0, (hipStream_t)s, part, nblocks, nblocks, C,
+                     rows_per_block, rows_total, rows_total, running_mean, running_var, stat, (float *)nullptr);
+  VT_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int vt_bn_stats_finalize_grouped(const float *part, int nblocks, int blocks_per_group, int C,
+                                            long rows_per_block, long rows_total, float *running_mean,
+                                            float *running_var, float *stat, float *batch_mv, vt_stream s) {
+  if (C < 1 || C > 1024 || nblocks < 1 || blocks_per_group < 1 || !batch_mv) return VT_EUNSUPPORTED;
+  if ((long)(nblocks - 1) * rows_per_block >= rows_total || (long)nblocks * rows_per_block < rows_total) return VT_EINVAL;
+  const int groups = (nblocks + blocks_per_group - 1) / blocks_per_group;
+  hipLaunchKernelGGL(k_bn_stats_finalize, dim3(C, groups), dim3(FIN_T), 0, (hipStream_t)s, part, nblocks, blocks_per_group,
+                     C, rows_per_block, (long)blocks_per_group * rows_per_block, rows_total, running_mean, running_var,
+                     stat, batch_mv);
+  VT_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_bn_running_seq, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)s, batch_mv, groups, C, running_mean,
+                     running_var);
   VT_CHECK_LAUNCH();
   return 0;
 }
@@ -302,13 +360,17 @@ extern "C" int vt_loader_gather(const unsigned char *images_u8, const int *label
   return 0;
 }
 
-extern "C" int vt_eval_accumulate(const float *probs, const int *labels, int N, int K, int slot, float *loss_sums,
-                                  int *correct, int *confusion, int *argmax, vt_stream s) {
-  if (N < 1 || K < 1 || K > KMAX || slot < 0 || !probs || !labels || !loss_sums || !correct) return VT_EINVAL;
-  hipLaunchKernelGGL(k_eval_accumulate, dim3(1), dim3(TPB), 0, (hipStream_t)s, probs, labels, N, K, slot, loss_sums,
-                     correct, confusion, argmax);
+extern "C" int vt_eval_accumulate_grouped(const float *probs, const int *labels, int N, int K, int group, int slot0,
+                                          float *loss_sums, int *correct, int *confusion, int *argmax, vt_stream s) {
+  if (N < 1 || K < 1 || K > KMAX || group < 1 || slot0 < 0 || !probs || !labels || !loss_sums || !correct) return VT_EINVAL;
+  hipLaunchKernelGGL(k_eval_accumulate, dim3((N + group - 1) / group), dim3(TPB), 0, (hipStream_t)s, probs, labels, N, K,
+                     group, slot0, loss_sums, correct, confusion, argmax);
   VT_CHECK_LAUNCH();
   return 0;
+}
+extern "C" int vt_eval_accumulate(const float *probs, const int *labels, int N, int K, int slot, float *loss_sums,
+                                  int *correct, int *confusion, int *argmax, vt_stream s) {
+  return vt_eval_accumulate_grouped(probs, labels, N, K, N, slot, loss_sums, correct, confusion, argmax, s);
 }
 
 extern "C" int vt_metrics(const float *probs, const int *labels, int N, int K, float *loss_sum, int *argmax,

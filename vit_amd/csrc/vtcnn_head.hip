@@ -54,11 +54,13 @@ __global__ __launch_bounds__(TPB) void k_head_fwd(const float *__restrict__ z, c
                                                   const float *__restrict__ g, const float *__restrict__ b,
                                                   const float *__restrict__ Wfc, const float *__restrict__ bfc,
                                                   float *__restrict__ pooled, unsigned char *__restrict__ pool_idx,
-                                                  float *__restrict__ logits, float *__restrict__ probs, int H) {
+                                                  float *__restrict__ logits, float *__restrict__ probs, int H,
+                                                  int group) {
   __shared__ float sbn[4 * C2];
   __shared__ float red[NW * K];
   const int W = H, P = H * W, pk = H / 14, Q = C2 * 196;
   const int n = blockIdx.x, tid = threadIdx.x;
+  if (group > 0) st += (size_t)(n / group) * 2 * C2;  // statistics group of this image
   if (tid < C2) {
     sbn[tid] = st[tid];
     sbn[C2 + tid] = st[C2 + tid];
@@ -276,9 +278,9 @@ using namespace vt;
 template <int K>
 static void launch_head_fwd(const float *z, const float *pn_stat, const float *pn_gamma, const float *pn_beta,
                             const float *wfc, const float *bfc, float *pooled, unsigned char *pool_idx, float *logits,
-                            float *probs, int N, int H, hipStream_t s) {
+                            float *probs, int N, int H, int group, hipStream_t s) {
   hipLaunchKernelGGL(k_head_fwd<K>, dim3(N), dim3(TPB), 0, s, z, pn_stat, pn_gamma, pn_beta, wfc, bfc, pooled, pool_idx,
-                     logits, probs, H);
+                     logits, probs, H, group);
 }
 template <int K>
 static void launch_head_bwd(const float *probs, const int *labels, const float *wfc, const unsigned char *pool_idx,
@@ -302,15 +304,20 @@ static void launch_head_bwd(const float *probs, const int *labels, const float *
     default: return VT_EUNSUPPORTED;                                                                        \
   }
 
-extern "C" int vt_head_fwd(const float *z, const float *pn_stat, const float *pn_gamma, const float *pn_beta,
-                           const float *wfc, const float *bfc, float *pooled, unsigned char *pool_idx, float *logits,
-                           float *probs, int N, int H, int K, vt_stream s) {
-  if (N < 1 || H < 14 || H % 14 != 0 || K < 1 || K > KMAX) return VT_EUNSUPPORTED;
-#define CALL(KK) launch_head_fwd<KK>(z, pn_stat, pn_gamma, pn_beta, wfc, bfc, pooled, pool_idx, logits, probs, N, H, (hipStream_t)s)
+extern "C" int vt_head_fwd_grouped(const float *z, const float *pn_stat, const float *pn_gamma, const float *pn_beta,
+                                   const float *wfc, const float *bfc, float *pooled, unsigned char *pool_idx,
+                                   float *logits, float *probs, int N, int H, int K, int group, vt_stream s) {
+  if (N < 1 || H < 14 || H % 14 != 0 || K < 1 || K > KMAX || group < 0) return VT_EUNSUPPORTED;
+#define CALL(KK) launch_head_fwd<KK>(z, pn_stat, pn_gamma, pn_beta, wfc, bfc, pooled, pool_idx, logits, probs, N, H, group, (hipStream_t)s)
   VT_FOR_K(CALL)
 #undef CALL
   VT_CHECK_LAUNCH();
   return 0;
+}
+extern "C" int vt_head_fwd(const float *z, const float *pn_stat, const float *pn_gamma, const float *pn_beta,
+                           const float *wfc, const float *bfc, float *pooled, unsigned char *pool_idx, float *logits,
+                           float *probs, int N, int H, int K, vt_stream s) {
+  return vt_head_fwd_grouped(z, pn_stat, pn_gamma, pn_beta, wfc, bfc, pooled, pool_idx, logits, probs, N, H, K, 0, s);
 }
 
 extern "C" int vt_head_bwd(const float *probs, const int *labels, const float *wfc, const unsigned char *pool_idx,

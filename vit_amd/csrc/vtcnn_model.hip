@@ -43,7 +43,8 @@ struct vt_model {
   // forward workspace
   float *conv, *tokA = nullptr, *tokstat, *tok, *a, *hdn, *s2, *o, *pk, *projA = nullptr, *z, *pooled, *logits, *probs;
   unsigned char *pool_idx;
-  float *part, *stat_bn, *stat_n1, *stat_n2, *stat_pn;
+  float *part, *stat_bn, *stat_n1, *stat_n2, *stat_pn, *batch_mv;
+  bool last_grouped = false;  // the last forward was a grouped one: no backward for it
   const float *last_images = nullptr;
   // backward workspace
   float *dlogits, *du, *pdx, *pdt, *dv, *dk, *d0, *ds2, *dh, *da, *dr, *dc, *dT0, *dy, *qkv, *gslab, *gslab_conv;
@@ -122,9 +123,12 @@ extern "C" int vt_model_create(const vt_dims *dims, int max_batch, int device, f
   const size_t nrb = (NL + RB - 1) / RB;
   rc |= dalloc(m, &m->part, std::max(N, nrb) * 64);
   rc |= dalloc(m, &m->stat_bn, 2 * C1, "stat.bn");
-  rc |= dalloc(m, &m->stat_n1, 2 * D, "stat.norm1");
-  rc |= dalloc(m, &m->stat_n2, 2 * D, "stat.norm2");
-  rc |= dalloc(m, &m->stat_pn, 2 * C2, "stat.proj.norm");
+  // one (mean, inv) record per statistics group: grouped forward runs up to maxN/4 groups
+  const size_t max_groups = N / 4 + 1;
+  rc |= dalloc(m, &m->stat_n1, max_groups * 2 * D, "stat.norm1");
+  rc |= dalloc(m, &m->stat_n2, max_groups * 2 * D, "stat.norm2");
+  rc |= dalloc(m, &m->stat_pn, max_groups * 2 * C2, "stat.proj.norm");
+  rc |= dalloc(m, &m->batch_mv, max_groups * 2 * D);
   rc |= dalloc(m, &m->dlogits, N * K, "bwd.d_logits");
   rc |= dalloc(m, &m->du, N * P * C2, "bwd.du");
   rc |= dalloc(m, &m->pdx, N * P * C1, "bwd.proj_dx");
@@ -645,13 +649,20 @@ extern "C" int vt_model_set_training(vt_model *m, int training) {
   return 0;
 }
 
-extern "C" int vt_model_forward(vt_model *m, const float *d_images, int n, float *d_probs, vt_stream s) {
+// group = 0: the n images are one mini-batch.  group > 0 (eval mode only): the n images are
+// consecutive mini-batches of `group` images (the last may be short), each with its own
+// BatchNorm1D statistics, processed by the same launches: what Trainer::evaluate_test computes
+// batch after batch (utils/trainer.hpp:104-127), at one launch set per sweep instead of one per batch.
+static int forward_impl(vt_model *m, const float *d_images, int n, int group, float *d_probs, vt_stream s) {
   if (!m || !d_images || n < 1 || n > m->maxN) return VT_EINVAL;
+  if (group > 0 && (m->training || group % 4 != 0)) return VT_EUNSUPPORTED;
+  if (group >= n) group = 0;
   const int H = m->d.input_dim, P = m->P, Ci = m->d.image_channels, K = m->K;
   const long NL = (long)n * L;
   const int nrb = (int)((NL + RB - 1) / RB);
   m->lastN = n;
   m->last_images = d_images;
+  m->last_grouped = group > 0;
   // conv + BatchNorm2D statistics (training: batch stats; eval: running stats)
   STEP("conv3x3_fwd", vt_conv3x3_fwd(d_images, m->P_("conv.W"), m->P_("conv.b"), m->conv, m->training ? m->part : nullptr, n, Ci, H, H, s));
   if (m->training)
@@ -663,30 +674,48 @@ extern "C" int vt_model_forward(vt_model *m, const float *d_images, int n, float
                          m->P_("tok.linear1.b"), m->P_("tok.linear2.W"), m->P_("tok.linear2.b"), m->keep_internals ? m->tokA : nullptr, m->tokstat,
                          m->tok, m->part,
                          n, P, s));
-  STEP("bn_stats_finalize", vt_bn_stats_finalize(m->part, n, D, L, NL, m->P_("norm1.running_mean"), m->P_("norm1.running_var"), m->stat_n1, s));
-  STEP("transformer_ffn_fwd", vt_transformer_ffn_fwd(m->tok, m->stat_n1, m->P_("norm1.gamma"), m->P_("norm1.beta"), m->P_("ffn.linear1.W"),
+  if (group > 0)
+    STEP("bn_stats_finalize", vt_bn_stats_finalize_grouped(m->part, n, group, D, L, NL, m->P_("norm1.running_mean"), m->P_("norm1.running_var"), m->stat_n1, m->batch_mv, s));
+  else
+    STEP("bn_stats_finalize", vt_bn_stats_finalize(m->part, n, D, L, NL, m->P_("norm1.running_mean"), m->P_("norm1.running_var"), m->stat_n1, s));
+  STEP("transformer_ffn_fwd", vt_transformer_ffn_fwd_grouped(m->tok, m->stat_n1, m->P_("norm1.gamma"), m->P_("norm1.beta"), m->P_("ffn.linear1.W"),
                                m->P_("ffn.linear1.b"), m->P_("ffn.linear2.W"), m->P_("ffn.linear2.b"), m->a, m->hdn, m->s2,
-                               m->part, NL, s));
-  STEP("bn_stats_finalize", vt_bn_stats_finalize(m->part, nrb, D, RB, NL, m->P_("norm2.running_mean"), m->P_("norm2.running_var"), m->stat_n2, s));
-  STEP("projector_tokens_fwd", vt_projector_tokens_fwd(m->s2, m->stat_n2, m->P_("norm2.gamma"), m->P_("norm2.beta"), m->P_("proj.linear1.W"),
-                                m->P_("proj.linear2.W"), m->P_("proj.linear3.W"), m->P_("proj.linear3.b"), m->o, m->pk, n, s));
+                               m->part, NL, (long)group * L, s));
+  if (group > 0)
+    STEP("bn_stats_finalize", vt_bn_stats_finalize_grouped(m->part, nrb, group * L / RB, D, RB, NL, m->P_("norm2.running_mean"), m->P_("norm2.running_var"), m->stat_n2, m->batch_mv, s));
+  else
+    STEP("bn_stats_finalize", vt_bn_stats_finalize(m->part, nrb, D, RB, NL, m->P_("norm2.running_mean"), m->P_("norm2.running_var"), m->stat_n2, s));
+  STEP("projector_tokens_fwd", vt_projector_tokens_fwd_grouped(m->s2, m->stat_n2, m->P_("norm2.gamma"), m->P_("norm2.beta"), m->P_("proj.linear1.W"),
+                                m->P_("proj.linear2.W"), m->P_("proj.linear3.W"), m->P_("proj.linear3.b"), m->o, m->pk, n, group, s));
   STEP("projector_fwd", vt_projector_fwd(m->conv, m->stat_bn, m->P_("bn.gamma"), m->P_("bn.beta"), m->pk, m->P_("proj.downsample.W"),
                          m->P_("proj.downsample.b"), m->P_("proj.norm.running_mean"),
                          m->keep_internals ? m->projA : nullptr, m->z, m->part, n, P, s));
-  STEP("bn_stats_finalize", vt_bn_stats_finalize(m->part, n, C2, P, (long)n * P, m->P_("proj.norm.running_mean"), m->P_("proj.norm.running_var"),
-                             m->stat_pn, s));
-  STEP("head_fwd", vt_head_fwd(m->z, m->stat_pn, m->P_("proj.norm.gamma"), m->P_("proj.norm.beta"), m->P_("fc.W"), m->P_("fc.b"),
-                    m->pooled, m->pool_idx, m->logits, m->probs, n, H, K, s));
+  if (group > 0)
+    STEP("bn_stats_finalize", vt_bn_stats_finalize_grouped(m->part, n, group, C2, P, (long)n * P, m->P_("proj.norm.running_mean"), m->P_("proj.norm.running_var"),
+                               m->stat_pn, m->batch_mv, s));
+  else
+    STEP("bn_stats_finalize", vt_bn_stats_finalize(m->part, n, C2, P, (long)n * P, m->P_("proj.norm.running_mean"), m->P_("proj.norm.running_var"),
+                               m->stat_pn, s));
+  STEP("head_fwd", vt_head_fwd_grouped(m->z, m->stat_pn, m->P_("proj.norm.gamma"), m->P_("proj.norm.beta"), m->P_("fc.W"), m->P_("fc.b"),
+                    m->pooled, m->pool_idx, m->logits, m->probs, n, H, K, group, s));
   if (d_probs && d_probs != m->probs)
     HIPCHK(hipMemcpyAsync(d_probs, m->probs, (size_t)n * K * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)s));
   return 0;
+}
+
+extern "C" int vt_model_forward(vt_model *m, const float *d_images, int n, float *d_probs, vt_stream s) {
+  return forward_impl(m, d_images, n, 0, d_probs, s);
+}
+extern "C" int vt_model_forward_grouped(vt_model *m, const float *d_images, int n, int group, float *d_probs, vt_stream s) {
+  if (group < 1) return VT_EINVAL;
+  return forward_impl(m, d_images, n, group, d_probs, s);
 }
 
 // VTCNN::backward (reference model/vit_cnn.hpp:215-242): softmax -> fc -> flatten -> maxpool ->
 // VisualTransformer::backward (projector -> transformer -> tokenizer.backward2,
 // layers/visual_transformer.hpp:127-199) -> BatchNorm2D -> conv.
 extern "C" int vt_model_backward(vt_model *m, const int *d_labels, vt_stream s) {
-  if (!m || !d_labels || m->lastN < 1 || !m->last_images) return VT_EINVAL;
+  if (!m || !d_labels || m->lastN < 1 || !m->last_images || m->last_grouped) return VT_EINVAL;
   const int n = m->lastN, H = m->d.input_dim, P = m->P, Ci = m->d.image_channels, K = m->K, Q = m->Q;
   const long NL = (long)n * L;
   const int nrb = (int)((NL + RB - 1) / RB);

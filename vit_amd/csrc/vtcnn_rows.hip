@@ -139,12 +139,14 @@ __global__ __launch_bounds__(TPB) void k_tr_ffn_fwd(const float *__restrict__ to
                                                     const float *__restrict__ W2, const float *__restrict__ b2,
                                                     float *__restrict__ a_out, float *__restrict__ hdn_out,
                                                     float *__restrict__ s2_out, float *__restrict__ part_n2,
-                                                    long rows) {
+                                                    long rows, long group_rows) {
   __shared__ float sred[NW][D];
   const Lane ln;
   const int wave = threadIdx.x >> 6;
   const long row0 = ((long)blockIdx.x * NW + wave) * 16;
   const int nv = (int)max(0L, min(16L, rows - row0));
+  // statistics group of this workgroup's rows (group_rows is a multiple of RB; 0 = one group)
+  if (group_rows > 0) st += ((long)blockIdx.x * RB / group_rows) * 2 * D;
   f4 mean[2], inv[2], gam[2], bet[2], bb1[2], bb2[2];
   load_fvec<2>(st, mean, ln);
   load_fvec<2>(st + D, inv, ln);
@@ -181,6 +183,8 @@ __global__ __launch_bounds__(TPB) void k_tr_ffn_fwd(const float *__restrict__ to
   s2.store(s2_out, row0, nv, D, 0, ln);
   if (part_n2 == nullptr) return;
   // per-workgroup (sum, centred M2) of s2 per feature over the workgroup's valid rows
+  // (a group boundary never falls inside a workgroup, so "rows left" is also right for the last
+  // workgroup of a short last group: the short group is the last one)
   const long left = rows - (long)blockIdx.x * RB;
   const float cnt = (float)(left < RB ? left : RB);
   const bool ok = ln.j < nv;
@@ -245,11 +249,13 @@ __global__ __launch_bounds__(TPB) void k_proj_tokens_fwd(const float *__restrict
                                                          const float *__restrict__ g, const float *__restrict__ b,
                                                          const float *__restrict__ Wq, const float *__restrict__ Wk,
                                                          const float *__restrict__ Wv, const float *__restrict__ bv,
-                                                         float *__restrict__ o_out, float *__restrict__ pk, int N) {
+                                                         float *__restrict__ o_out, float *__restrict__ pk, int N,
+                                                         int group) {
   static_assert(L == 16, "one 16-row tile per image");
   const Lane ln;
   const int n = blockIdx.x * NW + (threadIdx.x >> 6);
   if (n >= N) return;
+  if (group > 0) st += (size_t)(n / group) * 2 * D;  // statistics group of this image
   const long row0 = (long)n * L;
   f4 mean[2], inv[2], gam[2], bet[2];
   load_fvec<2>(st, mean, ln);
@@ -573,26 +579,37 @@ __global__ __launch_bounds__(TPB) void k_tr_bwd_c(const float *__restrict__ da, 
 // ---------------------------------------------------------------------------------------------
 using namespace vt;
 
+extern "C" int vt_transformer_ffn_fwd_grouped(const float *tokens, const float *n1_stat, const float *n1_gamma,
+                                              const float *n1_beta, const float *w1, const float *b1, const float *w2,
+                                              const float *b2, float *a, float *hdn, float *s2, float *part_n2,
+                                              long rows, long group_rows, vt_stream s) {
+  if (rows < 1 || group_rows < 0 || group_rows % RB != 0) return VT_EINVAL;
+  const int nb = (int)((rows + RB - 1) / RB);
+  hipLaunchKernelGGL(k_tr_ffn_fwd, dim3(nb), dim3(TPB), 0, (hipStream_t)s, tokens, n1_stat, n1_gamma, n1_beta, w1, b1,
+                     w2, b2, a, hdn, s2, part_n2, rows, group_rows);
+  VT_CHECK_LAUNCH();
+  return 0;
+}
 extern "C" int vt_transformer_ffn_fwd(const float *tokens, const float *n1_stat, const float *n1_gamma,
                                       const float *n1_beta, const float *w1, const float *b1, const float *w2,
                                       const float *b2, float *a, float *hdn, float *s2, float *part_n2, long rows,
                                       vt_stream s) {
-  if (rows < 1) return VT_EINVAL;
-  const int nb = (int)((rows + RB - 1) / RB);
-  hipLaunchKernelGGL(k_tr_ffn_fwd, dim3(nb), dim3(TPB), 0, (hipStream_t)s, tokens, n1_stat, n1_gamma, n1_beta, w1, b1,
-                     w2, b2, a, hdn, s2, part_n2, rows);
+  return vt_transformer_ffn_fwd_grouped(tokens, n1_stat, n1_gamma, n1_beta, w1, b1, w2, b2, a, hdn, s2, part_n2, rows, 0, s);
+}
+
+extern "C" int vt_projector_tokens_fwd_grouped(const float *s2, const float *n2_stat, const float *n2_gamma,
+                                               const float *n2_beta, const float *wq, const float *wk, const float *wv,
+                                               const float *bv, float *o, float *pk, int N, int group, vt_stream s) {
+  if (N < 1 || group < 0) return VT_EINVAL;
+  hipLaunchKernelGGL(k_proj_tokens_fwd, dim3((N + NW - 1) / NW), dim3(TPB), 0, (hipStream_t)s, s2, n2_stat, n2_gamma,
+                     n2_beta, wq, wk, wv, bv, o, pk, N, group);
   VT_CHECK_LAUNCH();
   return 0;
 }
-
 extern "C" int vt_projector_tokens_fwd(const float *s2, const float *n2_stat, const float *n2_gamma,
                                        const float *n2_beta, const float *wq, const float *wk, const float *wv,
                                        const float *bv, float *o, float *pk, int N, vt_stream s) {
-  if (N < 1) return VT_EINVAL;
-  hipLaunchKernelGGL(k_proj_tokens_fwd, dim3((N + NW - 1) / NW), dim3(TPB), 0, (hipStream_t)s, s2, n2_stat, n2_gamma,
-                     n2_beta, wq, wk, wv, bv, o, pk, N);
-  VT_CHECK_LAUNCH();
-  return 0;
+  return vt_projector_tokens_fwd_grouped(s2, n2_stat, n2_gamma, n2_beta, wq, wk, wv, bv, o, pk, N, 0, s);
 }
 
 // Token side of the projector backward; scratch >= ceil(rows/64) * 1552 floats.

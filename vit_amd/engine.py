@@ -118,6 +118,19 @@ class VTCNN:
                                    _stream_handle()), "vt_model_forward")
         return self._probs[:n]
 
+    def forward_grouped(self, x, group):
+        """Eval-mode forward of consecutive mini-batches of `group` images in one launch set;
+        equal to forward() on each batch up to rounding of the statistics (vt_model_forward_grouped)."""
+        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+        n = x.shape[0]
+        if n < 1 or n > self.max_batch:
+            raise ValueError("batch %d outside [1, max_batch=%d]" % (n, self.max_batch))
+        self._n = n
+        self._x = x
+        check(lib.vt_model_forward_grouped(self._h, C.c_void_p(x.data_ptr()), n, int(group),
+                                           C.c_void_p(self._probs.data_ptr()), _stream_handle()), "vt_model_forward_grouped")
+        return self._probs[:n]
+
     def backward(self, labels):
         """VTCNN::backward for the last forward; labels int32 CUDA tensor [N] (class indices; the
         reference passes the one-hot matrix, utils/trainer.hpp:47-52)."""
@@ -289,6 +302,15 @@ class DataLoader:
     def total_batches(self):
         return (self.n + self.batch_size - 1) // self.batch_size
 
+    def next_batches(self, count):
+        """`count` consecutive batches as one tensor pair (for grouped evaluation sweeps)."""
+        saved = self.batch_size
+        self.batch_size = saved * int(count)
+        try:
+            return self.next_batch()
+        finally:
+            self.batch_size = saved
+
     def next_batch(self):
         end = min(self.index + self.batch_size, self.n)
         sel = self._idx_dev[self.index:end]
@@ -326,6 +348,26 @@ class Trainer:
         preds, truth, sizes = [], [], []
         self.model.set_training(False)
         b = 0
+        bs = loader.batch_size
+        per_call = (self.model.max_batch // bs) if (bs % 4 == 0 and hasattr(loader, "next_batches")) else 0
+        if per_call >= 2:
+            # whole chunks of loader batches per launch set (vt_model_forward_grouped): each batch
+            # keeps its own BatchNorm1D statistics, as in the reference's batch-by-batch loop
+            while loader.has_next():
+                x, y = loader.next_batches(per_call)
+                p = self.model.forward_grouped(x, bs)
+                am = torch.empty(y.numel(), dtype=torch.int32, device=dev)
+                check(lib.vt_eval_accumulate_grouped(C.c_void_p(p.data_ptr()), C.c_void_p(y.data_ptr()), y.numel(), k, bs, b,
+                                                     C.c_void_p(loss_sums.data_ptr()), C.c_void_p(correct.data_ptr()),
+                                                     C.c_void_p(cm.data_ptr()), C.c_void_p(am.data_ptr()),
+                                                     _stream_handle()), "vt_eval_accumulate_grouped")
+                preds.append(am)
+                truth.append(y)
+                left = y.numel()
+                while left > 0:
+                    sizes.append(min(bs, left))
+                    left -= bs
+                    b += 1
         while loader.has_next():
             x, y = loader.next_batch()
             p = self.model.forward(x)
