@@ -137,6 +137,10 @@ def main():
                          "each with its own BatchNorm1D statistics (what run.sh predict evaluates)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step as one HIP graph (single GPU, train mode; for small batches)")
+    ap.add_argument("--overlap", type=int, default=0,
+                    help="1: data-parallel gradient exchange hidden behind compute (vit_amd/parallel.py)")
+    ap.add_argument("--exchange-alone", action="store_true",
+                    help="rehearsal on one GPU: a one-rank RCCL group whose all-reduces are really launched")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel", default=None, help="launcher to time with HIP events (default: the slowest)")
     a = ap.parse_args()
@@ -149,6 +153,11 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    elif a.exchange_alone:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local))
 
     from vit_amd import VTCNN, Dims
     dims = Dims(num_classes=a.classes)
@@ -159,7 +168,10 @@ def main():
     xs = torch.from_numpy(rng.integers(0, 256, size=(nb, B, 1, 28, 28)).astype(np.float32) / np.float32(255.0)).cuda()
     ys = torch.from_numpy(rng.integers(0, a.classes, size=(nb, B)).astype(np.int32)).cuda()
     from vit_amd.parallel import DataParallel
-    dp = DataParallel(m, world=world, rank=rank)  # world 1: plain forward / backward / SGD
+    # world 1: plain forward / backward / SGD; world > 1: one blocking all-reduce of the gradient arena
+    # (--overlap 1: exchange hidden behind the attention backward and the next step's forward)
+    dp = DataParallel(m, world=world, rank=rank, overlap=bool(a.overlap))
+    dp.always_exchange = a.exchange_alone
 
     if a.mode == "predict":
         m.set_training(False)
@@ -195,6 +207,7 @@ def main():
             sync()
             m.profile("*")
         step(i)
+    dp.finish()
     sync()
     breakdown = m.profile_read()
     per_launch_ms = {k: v[0] / v[1] for k, v in breakdown.items()}
@@ -207,6 +220,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(a.steps):
         step(a.warmup + i)
+    dp.finish()  # the last step's trailing attention update belongs to the timed work
     sync()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -245,6 +259,7 @@ def main():
                                     "VTCNN predict step (eval-mode forward)") + ", BloodMNIST shape 1x28x28, %d classes, "
                                    "mini-batch %d per GPU, fp32, seed-42 reference init" % (a.classes, B),
                        "hip_graph": bool(use_graph), "statistics_group": a.group if a.mode == "predict" else 0, "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world,
+                       "exchange_overlapped": bool(dp.overlap and a.mode == "train" and not use_graph),
                        "grad_allreduce_floats": int(m.layout.n_trainable) if world > 1 else 0},
             "roofline": roof,
             "whole_step_hbm_frac": round(value / world * total_bytes / (HBM_PEAK_GBS * 1e9), 4),

@@ -84,6 +84,19 @@ int vt_model_forward(vt_model *m, const float *d_images, int n, float *d_probs, 
 /* VTCNN::backward (model/vit_cnn.hpp:215-242) for the mini-batch of the last forward; d_labels:
  * device int32 [n].  Leaves the summed gradients in the gradient arena (overwrites it). */
 int vt_model_backward(vt_model *m, const int *d_labels, vt_stream s);
+/* The same backward in two calls, for data-parallel callers that overlap their gradient exchange
+ * with compute.  vt_model_backward_main leaves every gradient final except those of the attention
+ * weights (mha.q*, mha.k*, mha.v*: MultiHeadAttention::backward, layers/multi_head_attention.hpp:
+ * 109-181), which vt_model_backward_attention then writes; nothing else reads or writes that block,
+ * and the forward pass never reads the attention weights (its output is discarded by the zero
+ * concat, layers/multi_head_attention.hpp:100), so their exchange and update may trail into the next step's
+ * forward.  Both calls together produce exactly the bytes of vt_model_backward.  d_grads_out: where
+ * the block's gradients go (device, vt_model_attention_range's count floats), NULL = their place in
+ * the gradient arena; a buffer of the caller's own keeps the arena free for an exchange in flight.
+ * vt_model_attention_range returns the block's first float and length inside the arenas. */
+int vt_model_backward_main(vt_model *m, const int *d_labels, vt_stream s);
+int vt_model_backward_attention(vt_model *m, float *d_grads_out, vt_stream s);
+int vt_model_attention_range(const vt_model *m, int *first, int *count);
 /* Evaluation sweep in one launch set (eval mode only): the n images are consecutive mini-batches
  * of `group` images (a multiple of 4; the last batch may be short), each normalised with its own
  * BatchNorm1D statistics exactly as Trainer::evaluate / evaluate_test see them batch after batch
@@ -95,6 +108,8 @@ int vt_model_forward_grouped(vt_model *m, const float *d_images, int n, int grou
  * utils/optimizer.hpp:22-28):  g <- g * (1/divisor);  w <- w - g * lr  over the trainable region.
  * The reference always passes divisor = Trainer::batch_size = 32 (utils/trainer.hpp:53). */
 int vt_model_sgd_step(vt_model *m, float lr, float divisor, vt_stream s);
+/* The same update over floats [first, first + count) of the trainable region (first a multiple of 4). */
+int vt_model_sgd_step_range(vt_model *m, float lr, float divisor, int first, int count, vt_stream s);
 /* One training step (forward, backward, SGD update) captured once as a HIP graph and replayed:
  * at the reference's own batch size of 32 the step is ~30 launches of a few microseconds each and
  * launch overhead, not arithmetic, sets the step time.  x_dev / y_dev / n / lr / divisor are baked

@@ -39,6 +39,35 @@ class OracleModel:
         self.grads.zero_()
 
 
+class PhasedOracleModel(OracleModel):
+    """Adds the two-call backward of the device model.  The oracle has one backward only, so each
+    call runs it whole and keeps its own part: the first everything outside the attention block,
+    the second (with the attention weights as they are THEN) the block itself."""
+
+    def attention_range(self):
+        a = self.layout.tensors["mha.q0.W"][0]
+        b = self.layout.tensors["mha.o.W"][0]
+        return a, b - a
+
+    def backward_main(self, y):
+        self._y = y
+        a, c = self.attention_range()
+        g = torch.from_numpy(self.o.backward(self.arena_np, y.numpy()))
+        self.grads[:a].copy_(g[:a])
+        self.grads[a + c:].copy_(g[a + c:])
+
+    def backward_attention(self):
+        a, c = self.attention_range()
+        g = torch.from_numpy(self.o.backward(self.arena_np, self._y.numpy()))
+        self.grads[a:a + c].copy_(g[a:a + c])
+
+    def update_weights_range(self, divisor, first, count):
+        g = self.grads.numpy()[first:first + count]
+        w = self.arena_np[first:first + count]
+        w -= (g * np.float32(1.0 / divisor)) * np.float32(self.lr)  # two roundings, as SGD::update
+        g[:] = 0
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -76,6 +105,23 @@ def _worker(rank, world, port, out_dir):
     y2 = torch.from_numpy(g["in%d.labels" % (1 - rank)].astype(np.int32))
     dp.train_step(x2, y2, 32)
     assert dp.weights_in_sync()
+    # overlapped exchange (attention block trailing into the next step) against the plain one,
+    # three steps from the same start: bit-identical weights on every rank
+    plain, over = OracleModel(8, 4, arena0), PhasedOracleModel(8, 4, arena0)
+    dp_plain, dp_over = DataParallel(plain), DataParallel(over, overlap=True)
+    assert dp_over.overlap and not dp_plain.overlap
+    a, c = over.attention_range()
+    for t in range(3):
+        xt, yt = (x, y) if t % 2 == 0 else (x2, y2)
+        dp_plain.train_step(xt, yt, 32)
+        dp_over.train_step(xt, yt, 32)
+        nt = lo.n_trainable
+        lag = np.flatnonzero(plain.arena_np[:nt] != over.arena_np[:nt])
+        assert lag.size > 0 and lag.min() >= a and lag.max() < a + c  # only the attention block trails
+    dp_over.finish()
+    assert np.array_equal(plain.arena_np[:lo.n_trainable], over.arena_np[:lo.n_trainable])
+    assert not over.grads.numpy().any()
+    assert dp_over.weights_in_sync()
     dist.barrier()
     dist.destroy_process_group()
 

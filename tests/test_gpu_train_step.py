@@ -229,3 +229,60 @@ def test_graph_step_is_bit_identical_to_eager(n):
         b.step_graph()
     torch.cuda.synchronize()
     assert np.array_equal(b.get_arena(), want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [32, 200])
+def test_two_call_backward_and_overlapped_update_are_bit_identical(n):
+    """vt_model_backward_main + vt_model_backward_attention write exactly the bytes of
+    vt_model_backward, and the data-parallel step that lets the attention block's update trail into
+    the next step (vit_amd/parallel.py, here with a world of one: same order of device work, no
+    collective) ends on exactly the weights of plain steps."""
+    import torch
+    from vit_amd import VTCNN, Dims
+    from vit_amd.parallel import DataParallel
+    rng = np.random.default_rng(7 * n)
+    xs = [torch.from_numpy(rng.integers(0, 256, size=(n, 1, 28, 28)).astype(np.float32) / np.float32(255.0)).cuda()
+          for _ in range(3)]
+    ys = [torch.from_numpy(rng.integers(0, 8, size=n).astype(np.int32)).cuda() for _ in range(3)]
+    a, b = (VTCNN(Dims(num_classes=8), max_batch=n, seed=42) for _ in range(2))
+    a.forward(xs[0]); a.backward(ys[0])
+    b.forward(xs[0]); b.backward_main(ys[0])
+    first, count = b.attention_range()
+    assert count == 6 * 32 * 16 and first % 4 == 0
+    gb = b.get_grads()
+    assert not gb[first:first + count].any()           # untouched by the first call
+    b.backward_attention()
+    assert np.array_equal(a.get_grads(), b.get_grads())
+    with pytest.raises(RuntimeError):
+        b.backward_attention()                          # nothing pending any more
+    a.update_weights(float(n)); b.update_weights(float(n))
+    dp = DataParallel(b, world=1, rank=0, overlap=True)
+    if n == 200:
+        # the same through RCCL: a one-rank group still launches its all-reduce kernels on the
+        # collective stream, so the stream ordering between exchange and update is the real one
+        import os
+        import socket
+        import torch.distributed as dist
+        sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        dp = DataParallel(b, overlap=True)
+        dp.always_exchange = True
+    try:
+        _overlapped_steps(a, b, dp, xs, ys, n, first, count)
+    finally:
+        if n == 200:
+            dist.destroy_process_group()
+
+
+def _overlapped_steps(a, b, dp, xs, ys, n, first, count):
+    for t in range(3):
+        a.forward(xs[t]); a.backward(ys[t]); a.update_weights(float(n))
+        dp.train_step(xs[t], ys[t], n)
+        wa, wb = a.get_arena(), b.get_arena()
+        lag = np.flatnonzero(wa != wb)
+        assert lag.size > 0 and lag.min() >= first and lag.max() < first + count
+    dp.finish()
+    assert np.array_equal(a.get_arena(), b.get_arena())
+    assert not b.get_grads().any()

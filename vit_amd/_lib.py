@@ -55,7 +55,11 @@ SIGNATURES = {
     "vt_model_forward": (i, [p, p, i, p, p]),
     "vt_model_forward_grouped": (i, [p, p, i, i, p, p]),
     "vt_model_backward": (i, [p, p, p]),
+    "vt_model_backward_main": (i, [p, p, p]),
+    "vt_model_backward_attention": (i, [p, p, p]),
+    "vt_model_attention_range": (i, [p, p, p]),
     "vt_model_sgd_step": (i, [p, f, f, p]),
+    "vt_model_sgd_step_range": (i, [p, f, f, i, i, p]),
     "vt_model_metrics": (i, [p, p, p, p, p]),
     "vt_model_graph_capture": (i, [p, p, p, i, f, f]),
     "vt_model_graph_launch": (i, [p, p]),

@@ -45,6 +45,7 @@ struct vt_model {
   unsigned char *pool_idx;
   float *part, *stat_bn, *stat_n1, *stat_n2, *stat_pn, *batch_mv;
   bool last_grouped = false;  // the last forward was a grouped one: no backward for it
+  bool attention_pending = false;  // vt_model_backward_main ran, vt_model_backward_attention has not yet
   const float *last_images = nullptr;
   // backward workspace
   float *dlogits, *du, *pdx, *pdt, *dv, *dk, *d0, *ds2, *dh, *da, *dr, *dc, *dT0, *dy, *qkv, *gslab, *gslab_conv;
@@ -714,18 +715,22 @@ extern "C" int vt_model_forward_grouped(vt_model *m, const float *d_images, int 
 // VTCNN::backward (reference model/vit_cnn.hpp:215-242): softmax -> fc -> flatten -> maxpool ->
 // VisualTransformer::backward (projector -> transformer -> tokenizer.backward2,
 // layers/visual_transformer.hpp:127-199) -> BatchNorm2D -> conv.
-extern "C" int vt_model_backward(vt_model *m, const int *d_labels, vt_stream s) {
-  if (!m || !d_labels || m->lastN < 1 || !m->last_images || m->last_grouped) return VT_EINVAL;
+// every weight-gradient slab reduction requested inside a scope is queued and runs as one launch at flush
+struct BatchScope {
+  ReduceBatch b;
+  BatchScope() { reduce_batch_begin(&b); }
+  ~BatchScope() { reduce_batch_abandon(); }
+};
+
+// Backward of everything except the attention block: head, projector, feed-forward half of the
+// transformer layer, tokenizer, BatchNorm2D and the convolution.  The tokenizer only needs the
+// transformer's input delta (transformer_bwd_a) and the projector's input delta, so it runs here
+// and the attention block, which nothing else waits for, closes the step.
+static int backward_main(vt_model *m, const int *d_labels, vt_stream s) {
   const int n = m->lastN, H = m->d.input_dim, P = m->P, Ci = m->d.image_channels, K = m->K, Q = m->Q;
   const long NL = (long)n * L;
   const int nrb = (int)((NL + RB - 1) / RB);
   hipStream_t hs = (hipStream_t)s;
-  // every weight-gradient slab reduction requested below is queued and runs as one launch at the end
-  struct BatchScope {
-    ReduceBatch b;
-    BatchScope() { reduce_batch_begin(&b); }
-    ~BatchScope() { reduce_batch_abandon(); }
-  } batch;
   // head: softmax/fc/pool/relu backward + projector BatchNorm1D backward sums
   STEP("head_bwd", vt_head_bwd(m->probs, d_labels, m->P_("fc.W"), m->pool_idx, m->z, m->stat_pn, m->P_("proj.norm.gamma"),
                     m->P_("proj.norm.beta"), m->dlogits, m->du, m->part, n, H, K, s));
@@ -747,9 +752,6 @@ extern "C" int vt_model_backward(vt_model *m, const int *d_labels, vt_stream s) 
                              m->P_("ffn.linear2.W"), m->ds2, m->da, m->G_("ffn.linear1.W"), m->sc_ffn, m->part, NL, s));
   STEP("bn_bwd_finalize", vt_bn_bwd_finalize(m->part, nrb, D, NL, m->P_("norm1.gamma"), m->stat_n1, m->tok, m->G_("norm1.gamma"),
                            m->G_("norm1.beta"), m->coef_n1, s));
-  STEP("transformer_bwd_c", vt_transformer_bwd_c(m->da, m->coef_n1, m->P_("mha.o.W"), m->tok, m->P_("mha.q0.W"), m->dr, m->dc, m->qkv, NL, s));
-  STEP("mha_bwd_rows", vt_mha_bwd_rows(m->qkv, m->dc, m->tok, m->sc_mha, n, L, s));
-  STEP("mha_bwd_wgrad", vt_mha_bwd_wgrad(m->qkv, m->dc, m->tok, m->P_("mha.q0.W"), m->G_("mha.q0.W"), m->sc_mha, n, L, s));
   // the output projection's cached input is the zero concat: its gradient is exactly zero
   // (a reduction over zero slab rows writes the zeros: it rides in the fused reduction launch and keeps
   // memset nodes, which did not replay reliably, out of the captured step graph)
@@ -761,13 +763,68 @@ extern "C" int vt_model_backward(vt_model *m, const int *d_labels, vt_stream s) 
                            m->G_("bn.beta"), m->coef_bn, s));
   STEP("conv3x3_wgrad", vt_conv3x3_wgrad(m->last_images, m->dy, m->coef_bn, m->gslab_conv, n, Ci, H, H, s));
   VTCHK(vt_reduce_rows(m->gslab_conv, n, C1 * Ci * 9 + C1, C1 * Ci * 9 + C1, m->G_("conv.W"), s));
-  STEP("reduce_rows", reduce_batch_flush(hs));
+  return 0;
+}
+
+// Backward of the attention block (MultiHeadAttention::backward's q/k/v weight gradients): reads the
+// delta of the first residual (transformer_bwd_b) and writes only the mha.q*/k*/v* gradients.
+static int backward_attention(vt_model *m, float *g_out, vt_stream s) {
+  const int n = m->lastN;
+  const long NL = (long)n * L;
+  STEP("transformer_bwd_c", vt_transformer_bwd_c(m->da, m->coef_n1, m->P_("mha.o.W"), m->tok, m->P_("mha.q0.W"), m->dr, m->dc, m->qkv, NL, s));
+  STEP("mha_bwd_rows", vt_mha_bwd_rows(m->qkv, m->dc, m->tok, m->sc_mha, n, L, s));
+  STEP("mha_bwd_wgrad", vt_mha_bwd_wgrad(m->qkv, m->dc, m->tok, m->P_("mha.q0.W"), g_out ? g_out : m->G_("mha.q0.W"), m->sc_mha, n, L, s));
+  return 0;
+}
+
+static bool backward_ready(const vt_model *m) { return m && m->lastN >= 1 && m->last_images && !m->last_grouped; }
+
+extern "C" int vt_model_backward(vt_model *m, const int *d_labels, vt_stream s) {
+  if (!backward_ready(m) || !d_labels) return VT_EINVAL;
+  BatchScope batch;
+  VTCHK(backward_main(m, d_labels, s));
+  VTCHK(backward_attention(m, nullptr, s));
+  STEP("reduce_rows", reduce_batch_flush((hipStream_t)s));
+  m->attention_pending = false;
+  return 0;
+}
+
+extern "C" int vt_model_backward_main(vt_model *m, const int *d_labels, vt_stream s) {
+  if (!backward_ready(m) || !d_labels) return VT_EINVAL;
+  BatchScope batch;
+  VTCHK(backward_main(m, d_labels, s));
+  STEP("reduce_rows", reduce_batch_flush((hipStream_t)s));
+  m->attention_pending = true;
+  return 0;
+}
+
+extern "C" int vt_model_backward_attention(vt_model *m, float *d_grads_out, vt_stream s) {
+  if (!backward_ready(m) || !m->attention_pending) return VT_EINVAL;
+  BatchScope batch;
+  VTCHK(backward_attention(m, d_grads_out, s));
+  STEP("reduce_rows", reduce_batch_flush((hipStream_t)s));
+  m->attention_pending = false;
+  return 0;
+}
+
+extern "C" int vt_model_attention_range(const vt_model *m, int *first, int *count) {
+  if (!m || !first || !count) return VT_EINVAL;
+  const int a = m->lo.t[vt_find(&m->lo, "mha.q0.W")].offset, b = m->lo.t[vt_find(&m->lo, "mha.o.W")].offset;
+  *first = a;
+  *count = b - a;
   return 0;
 }
 
 extern "C" int vt_model_sgd_step(vt_model *m, float lr, float divisor, vt_stream s) {
   if (!m) return VT_EINVAL;
   STEP("sgd_update", vt_sgd_update(m->arena, m->grads, m->lo.n_trainable, lr, divisor, 1, s));
+  return 0;
+}
+
+extern "C" int vt_model_sgd_step_range(vt_model *m, float lr, float divisor, int first, int count, vt_stream s) {
+  if (!m || first < 0 || count < 0 || (first & 3) || (long)first + count > m->lo.n_trainable) return VT_EINVAL;
+  if (count == 0) return 0;
+  STEP("sgd_update", vt_sgd_update(m->arena + first, m->grads + first, count, lr, divisor, 1, s));
   return 0;
 }
 

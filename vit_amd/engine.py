@@ -137,9 +137,40 @@ class VTCNN:
         assert labels.is_cuda and labels.dtype == torch.int32 and labels.numel() == self._n
         check(lib.vt_model_backward(self._h, C.c_void_p(labels.data_ptr()), _stream_handle()), "vt_model_backward")
 
+    def backward_main(self, labels):
+        """Backward of everything but the attention block: afterwards every gradient outside
+        attention_range() is final (vt_model_backward_main)."""
+        assert labels.is_cuda and labels.dtype == torch.int32 and labels.numel() == self._n
+        check(lib.vt_model_backward_main(self._h, C.c_void_p(labels.data_ptr()), _stream_handle()), "vt_model_backward_main")
+
+    def backward_attention(self, out=None):
+        """The attention block's backward: writes the gradients inside attention_range(), or into
+        `out` (float32 CUDA tensor of that many elements) instead of the gradient arena."""
+        if out is not None:
+            assert out.is_cuda and out.dtype == torch.float32 and out.is_contiguous() and out.numel() == self.attention_range()[1]
+        check(lib.vt_model_backward_attention(self._h, C.c_void_p(out.data_ptr() if out is not None else None), _stream_handle()),
+              "vt_model_backward_attention")
+
+    def update_block(self, batch_size, first, grads):
+        """SGD on arena[first : first + len(grads)] with the gradients in `grads` (cleared afterwards)."""
+        assert grads.is_cuda and grads.dtype == torch.float32 and grads.is_contiguous()
+        check(lib.vt_sgd_update(C.c_void_p(self.arena.data_ptr() + 4 * int(first)), C.c_void_p(grads.data_ptr()), grads.numel(),
+                                self.lr, float(batch_size), 1, _stream_handle()), "vt_sgd_update")
+
+    def attention_range(self):
+        """(first, count): the floats of the arenas that hold mha.q*/k*/v*."""
+        first, count = C.c_int(0), C.c_int(0)
+        check(lib.vt_model_attention_range(self._h, C.byref(first), C.byref(count)), "vt_model_attention_range")
+        return first.value, count.value
+
     def update_weights(self, batch_size=32.0):
         """VTCNN::update_weights + zero_grad with the reference's constant divisor (trainer.hpp:53)."""
         check(lib.vt_model_sgd_step(self._h, self.lr, float(batch_size), _stream_handle()), "vt_model_sgd_step")
+
+    def update_weights_range(self, batch_size, first, count):
+        """The same update over floats [first, first + count) of the trainable region."""
+        check(lib.vt_model_sgd_step_range(self._h, self.lr, float(batch_size), int(first), int(count), _stream_handle()),
+              "vt_model_sgd_step_range")
 
     def zero_grad(self):
         self.grads.zero_()
