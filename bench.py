@@ -176,15 +176,19 @@ def main():
     if a.mode == "predict":
         m.set_training(False)
 
-    use_graph = a.graph and world == 1 and a.mode == "train"
+    use_graph = a.graph and world == 1 and (a.mode == "train" or a.group == 0)
     if use_graph:
         xbuf, ybuf = torch.empty_like(xs[0]), torch.empty_like(ys[0])
-        m.capture_step(xbuf, ybuf, float(B))
+        if a.mode == "train":
+            m.capture_step(xbuf, ybuf, float(B))
+        else:
+            m.capture_forward(xbuf)
 
     def step(i):
         if use_graph:
             xbuf.copy_(xs[i % nb], non_blocking=True)
-            ybuf.copy_(ys[i % nb], non_blocking=True)
+            if a.mode == "train":
+                ybuf.copy_(ys[i % nb], non_blocking=True)
             m.step_graph()
         elif a.mode == "predict" and a.group > 0:
             m.forward_grouped(xs[i % nb], a.group)

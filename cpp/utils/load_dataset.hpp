@@ -3,13 +3,17 @@
 // the constructor and again at every reset() from one mt19937(seed), short last batch.
 // The bit-exact pieces (IDX decode, shuffle) are the C ABI's host entry points.
 #pragma once
+#include <algorithm>
+#include <cstdio>
 #include <filesystem>
+#include <iostream>
 #include <stdexcept>
 #include <string>
 #include <utility>
 #include <vector>
 
 #include "../../include/vtcnn_hip.h"
+#include "load_image_stb.hpp"
 #include "tensor.hpp"
 
 struct Dataset {
@@ -86,35 +90,45 @@ class DataLoader {
   const std::vector<int> &order() const { return indices; }
 };
 
-// Custom images for `predict`: binary PGM (P5, 28x28, maxval 255) files in alphabetical order,
-// pixel/255.0f.  (The reference decodes PNG/JPG through a vendored third-party header,
-// utils/load_image_stb.hpp; that decoder is outside this engine.)
+// Custom images for `predict` (utils/load_dataset.hpp:167-209): the .png / .jpg / .jpeg files of the
+// folder in alphabetical order of their names, each through load_image_as_vector; a file that does
+// not load is reported on stderr and skipped.  Binary PGM (P5, 28x28, maxval 255) is accepted as
+// well (an addition: handy for raw dataset pixels).
+inline std::vector<float> load_pgm_as_vector(const std::string &path) {
+  FILE *f = std::fopen(path.c_str(), "rb");
+  if (!f) throw std::runtime_error("No se pudo cargar la imagen: " + path);
+  int w = 0, h = 0, mx = 0;
+  std::vector<float> img;
+  if (std::fscanf(f, "P5 %d %d %d", &w, &h, &mx) == 3 && w == 28 && h == 28 && mx == 255) {
+    std::fgetc(f);
+    std::vector<unsigned char> raw(784);
+    if (std::fread(raw.data(), 1, 784, f) == 784) {
+      img.resize(784);
+      for (int i = 0; i < 784; ++i) img[i] = static_cast<float>(raw[i]) / 255.0f;
+    }
+  }
+  std::fclose(f);
+  if (img.empty()) throw std::runtime_error("La imagen debe ser de tamaño 28x28");
+  return img;
+}
+
 inline Dataset load_custom_images_from_folder(const std::string &folder_path) {
   namespace fs = std::filesystem;
   Dataset ds;
   std::vector<fs::path> files;
-  for (const auto &e : fs::directory_iterator(folder_path))  // throws if the folder is missing, like the reference
-    if (e.is_regular_file() && e.path().extension() == ".pgm") files.push_back(e.path());
-  std::sort(files.begin(), files.end(), [](const fs::path &a, const fs::path &b) { return a.filename() < b.filename(); });
+  for (const auto &e : fs::directory_iterator(folder_path)) {  // throws if the folder is missing, like the reference
+    if (!e.is_regular_file()) continue;
+    const std::string ext = e.path().extension().string();
+    if (ext == ".png" || ext == ".jpg" || ext == ".jpeg" || ext == ".pgm") files.push_back(e.path());
+  }
+  std::sort(files.begin(), files.end(),
+            [](const fs::path &a, const fs::path &b) { return a.filename().string() < b.filename().string(); });
   for (const fs::path &p : files) {
-    FILE *f = std::fopen(p.c_str(), "rb");
-    if (!f) continue;
-    int w = 0, h = 0, mx = 0;
-    std::vector<float> img;
-    if (std::fscanf(f, "P5 %d %d %d", &w, &h, &mx) == 3 && w == 28 && h == 28 && mx == 255) {
-      std::fgetc(f);
-      std::vector<unsigned char> raw(784);
-      if (std::fread(raw.data(), 1, 784, f) == 784) {
-        img.resize(784);
-        for (int i = 0; i < 784; ++i) img[i] = static_cast<float>(raw[i]) / 255.0f;
-      }
-    }
-    std::fclose(f);
-    if (!img.empty()) {
-      ds.images.push_back(std::move(img));
-      ds.labels.push_back(0);
-    } else {
-      std::fprintf(stderr, "Error al cargar %s\n", p.c_str());
+    try {
+      ds.images.push_back(p.extension() == ".pgm" ? load_pgm_as_vector(p.string()) : load_image_as_vector(p.string()));
+      ds.labels.push_back(0);  // dummy label
+    } catch (const std::exception &e) {
+      std::cerr << "Error al cargar " << p.string() << ": " << e.what() << "\n";
     }
   }
   return ds;

@@ -118,6 +118,10 @@ int vt_model_sgd_step_range(vt_model *m, float lr, float divisor, int first, int
  * the whole step on stream s.  Re-capturing replaces the previous graph.  No counterpart in the
  * reference. */
 int vt_model_graph_capture(vt_model *m, const float *x_dev, const int *y_dev, int n, float lr, float divisor);
+/* The forward pass alone as the model's graph, in the mode set by vt_model_set_training: the
+ * single-image latency path of Trainer::predict (utils/trainer.hpp:199-243) and of the prediction
+ * service in front of it; d_probs as in vt_model_forward.  Replaces a captured training step. */
+int vt_model_graph_capture_forward(vt_model *m, const float *x_dev, int n, float *d_probs);
 int vt_model_graph_launch(vt_model *m, vt_stream s);
 
 /* Tensor::compute_loss + argmax of the last forward (tensor_cpu.hpp:1137-1173, 1294-1307):
@@ -174,6 +178,13 @@ int vt_model_load_v2(vt_model *m, vt_train_state *state, const char *path);
  * u8 / 255.0f, label u8 -> int.  Query sizes with out == NULL. */
 int vt_idx_read_images(const char *path, int max_images, float *out, int *n, int *rows, int *cols);
 int vt_idx_read_labels(const char *path, int max_labels, int *out, int *n);
+/* load_image_as_vector's decode step (utils/load_image_stb.hpp:9-26: stbi_load(path, &w, &h, &n, 1)):
+ * one grey byte per pixel of a PNG file, mapped from every PNG colour type and depth exactly as
+ * that decoder maps them ((77 r + 150 g + 29 b) >> 8 for colour, alpha dropped, 16-bit samples cut
+ * to their high byte).  Host only.  out == NULL queries the size; capacity = bytes available at out.
+ * VT_EIO: cannot open; VT_EFORMAT: not a decodable PNG; VT_EUNSUPPORTED: a JPEG file (the reference
+ * accepts .jpg through the same decoder; JPEG is not decoded here). */
+int vt_image_read_gray(const char *path, unsigned char *out, int capacity, int *width, int *height);
 /* DataLoader shuffling (utils/load_dataset.hpp:112-127, 155-159): indices = iota(n), shuffled
  * once by the constructor and once more by every reset(), all from one mt19937(seed) with
  * libstdc++'s std::shuffle.  Writes the permutation after `resets` resets (0 = constructor only). */

@@ -392,11 +392,24 @@ static int cmd_bench(int argc, char **argv)
   return 0;
 }
 
+// The reference's custom-image loader (utils/load_image_stb.hpp:9-26) on each file of a folder, in
+// the order load_custom_images_from_folder visits them (utils/load_dataset.hpp:167-209).
+static int cmd_images(int argc, char **argv)
+{
+  // images <folder> <out.bin>: per accepted file 784 floats, in order; prints "<n> <name>..." to stdout
+  Dataset ds = load_custom_images_from_folder(argv[2]);
+  std::ofstream f(argv[3], std::ios::binary);
+  for (auto &img : ds.images)
+    f.write(reinterpret_cast<const char *>(img.data()), (std::streamsize)(img.size() * sizeof(float)));
+  std::printf("images: %zu\n", ds.images.size());
+  return 0;
+}
+
 int main(int argc, char **argv)
 {
   if (argc < 2)
   {
-    std::fprintf(stderr, "usage: ref_harness step|dp|kat|blood|bench ...\n");
+    std::fprintf(stderr, "usage: ref_harness step|dp|kat|blood|bench|images ...\n");
     return 2;
   }
   std::string c = argv[1];
@@ -412,6 +425,8 @@ int main(int argc, char **argv)
       return cmd_blood(argc, argv);
     if (c == "bench" && argc == 6)
       return cmd_bench(argc, argv);
+    if (c == "images" && argc == 4)
+      return cmd_images(argc, argv);
   }
   catch (const std::exception &e)
   {

@@ -8,6 +8,7 @@ import os
 import re
 import shutil
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -86,13 +87,19 @@ def test_cpp_cli_predict_matches_reference(tmp_path):
         shutil.copy(img, data / ("%s-images-idx3-ubyte" % stem))
         shutil.copy(lbl, data / ("%s-labels-idx1-ubyte" % stem))
     shutil.copy(ckpt, tmp_path / "model_bloodmnist.bin")
-    # custom images (the reference decodes PNG/JPG through stb_image; this build reads binary PGM):
-    # the first three test images, predicted one at a time by Trainer::predict
+    # custom images: the first three test images as PNG files (grey, RGB with equal channels, and a
+    # binary PGM, which this build accepts in addition), predicted one at a time by Trainer::predict
     raw = np.fromfile(img, dtype=np.uint8)[16:].reshape(256, 784)
     (tmp_path / "custom_images").mkdir()
-    for k in range(3):
-        with open(tmp_path / "custom_images" / ("img_%d.pgm" % k), "wb") as f:
-            f.write(b"P5\n28 28\n255\n" + raw[k].tobytes())
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from make_png_golden import encode
+    (tmp_path / "custom_images" / "img_0.png").write_bytes(encode(raw[0].reshape(28, 28).astype(np.int64), 0, 8, lambda y: y % 5))
+    # (77 v + 150 v + 29 v) >> 8 == v: an RGB file with equal channels decodes to the same grey bytes
+    (tmp_path / "custom_images" / "img_1.png").write_bytes(
+        encode(np.repeat(raw[1].reshape(28, 28, 1), 3, axis=2).reshape(28, 84).astype(np.int64), 2, 8, lambda y: 4))
+    with open(tmp_path / "custom_images" / "img_2.pgm", "wb") as f:
+        f.write(b"P5\n28 28\n255\n" + raw[2].tobytes())
+    (tmp_path / "custom_images" / "broken.png").write_bytes(b"junk")  # reported on stderr and skipped
     from oracle.pyoracle import Oracle, make_dims
     from tests_util import arena_from_checkpoint
     o = Oracle(make_dims(num_classes=8), 1)
@@ -109,6 +116,7 @@ def test_cpp_cli_predict_matches_reference(tmp_path):
     assert np.array_equal(pred, g["pred"])
     shown = [int(s.split(":")[1]) for s in r.stdout.splitlines() if s.startswith("Imagen predicción:")]
     assert shown == single, (shown, single)
+    assert "Error al cargar" in r.stderr and "broken.png" in r.stderr
     line = [s for s in r.stdout.splitlines() if s.startswith("[TEST]")][0]
     # default stream formatting (6 significant digits), as in the reference's predict mode
     mt = re.search(r"Loss: ([0-9.eE+-]+) \| Accuracy: ([0-9.eE+-]+)%", line)
@@ -253,3 +261,26 @@ def test_grouped_forward_matches_batch_by_batch(n):
     b.set_training(True)
     with pytest.raises(Exception):
         b.forward_grouped(x, 32)  # training mode: BatchNorm2D would couple the groups
+
+
+def test_single_image_graph_replay_matches_eager():
+    """Trainer::predict's single image (utils/trainer.hpp:199-243) as a captured forward graph:
+    replaying it on refilled input gives exactly the eager forward's probabilities."""
+    from vit_amd import VTCNN, Dims
+    from vit_amd.engine import load_dataset
+    img, lbl, ckpt = _paths()
+    ds = load_dataset(img, lbl, 16)
+    a, b = (VTCNN(Dims(num_classes=8), max_batch=1, seed=42) for _ in range(2))
+    for m in (a, b):
+        m.load(ckpt)
+        m.set_training(False)
+    xbuf = torch.zeros(1, 1, 28, 28, device="cuda")
+    out = b.capture_forward(xbuf)
+    for k in range(6):
+        x = torch.from_numpy(np.ascontiguousarray(ds.images[k].reshape(1, 1, 28, 28))).cuda()
+        pa = a.forward(x).cpu().numpy().copy()
+        xbuf.copy_(x)
+        b.step_graph()
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), pa), k
+    assert np.array_equal(a.get_arena(), b.get_arena())  # running statistics moved the same way

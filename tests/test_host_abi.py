@@ -197,3 +197,62 @@ def test_layout_matches_python_mirror():
         class Fake:
             dims = dims(k)
         assert E.VTCNN._layout_sizes(Fake) == (lo.n_total, lo.n_trainable)
+
+
+def test_png_decode_matches_reference_loader(tmp_path):
+    """vt_image_read_gray against the real reference's load_image_as_vector
+    (utils/load_image_stb.hpp:9-26) on 25 PNG files covering every colour type, bit depth, scanline
+    filter, Adam7, tRNS and split IDAT (tests/golden/png, expectations from
+    tools/make_png_golden.py through the reference harness): every pixel bit-exact.  When the
+    harness is present (build container) it is run again here on the same folder."""
+    import shutil
+    import subprocess
+    from vit_amd._lib import lib
+    from vit_amd.engine import load_custom_images_from_folder, load_image_as_vector
+    g = np.load(os.path.join(GOLD, "png_expected.npz"))
+    folder = os.path.join(GOLD, "png")
+    names = [str(n) for n in g["names"]]
+    assert sorted(os.listdir(folder)) == names
+    for nm, exp in zip(names, g["images"]):
+        got = load_image_as_vector(os.path.join(folder, nm))
+        assert got.dtype == np.float32 and np.array_equal(got, exp), nm
+    ds = load_custom_images_from_folder(folder)
+    assert np.array_equal(ds.images, g["images"])
+    harness = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+    if os.access(harness, os.X_OK) and os.path.isdir("/root/reference"):
+        out = tmp_path / "ref.bin"
+        subprocess.run([harness, "images", folder + "/", str(out)], check=True, capture_output=True, timeout=60)
+        assert np.array_equal(np.fromfile(str(out), dtype=np.float32).reshape(-1, 784), ds.images)
+    # error behaviour: wrong size, not a PNG, JPEG magic, truncated stream, missing file
+    w, h = C.c_int(0), C.c_int(0)
+    big = tmp_path / "big.png"
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from make_png_golden import encode
+    big.write_bytes(encode(np.zeros((30, 30), dtype=np.int64), 0, 8, lambda y: 0))
+    assert lib.vt_image_read_gray(str(big).encode(), None, 0, C.byref(w), C.byref(h)) == 0 and (w.value, h.value) == (30, 30)
+    with pytest.raises(RuntimeError, match="28x28"):
+        load_image_as_vector(str(big))
+    junk = tmp_path / "junk.png"
+    junk.write_bytes(b"not a png at all")
+    assert lib.vt_image_read_gray(str(junk).encode(), None, 0, C.byref(w), C.byref(h)) == -5
+    jpg = tmp_path / "a.jpg"
+    jpg.write_bytes(b"\xff\xd8\xff\xe0" + b"\0" * 64)
+    assert lib.vt_image_read_gray(str(jpg).encode(), None, 0, C.byref(w), C.byref(h)) == -2
+    cut = tmp_path / "cut.png"
+    data = open(os.path.join(folder, "rgb16.png"), "rb").read()
+    cut.write_bytes(data[:len(data) // 2])
+    buf = np.zeros(784, dtype=np.uint8)
+    assert lib.vt_image_read_gray(str(cut).encode(), C.c_void_p(buf.ctypes.data), 784, C.byref(w), C.byref(h)) != 0
+    assert lib.vt_image_read_gray(str(tmp_path / "none.png").encode(), None, 0, C.byref(w), C.byref(h)) == -4
+    with pytest.raises(RuntimeError, match="No se pudo cargar la imagen"):
+        load_image_as_vector(str(junk))
+    # a folder with a bad file: reported and skipped, the good ones kept in name order
+    mix = tmp_path / "mix"
+    mix.mkdir()
+    shutil.copy(os.path.join(folder, "gray08.png"), mix / "b.png")
+    shutil.copy(str(junk), mix / "a.png")
+    shutil.copy(os.path.join(folder, "rgb16.png"), mix / "c.png")
+    ds = load_custom_images_from_folder(str(mix))
+    assert ds.images.shape == (2, 784)
+    assert np.array_equal(ds.images[0], g["images"][names.index("gray08.png")])
+    assert np.array_equal(ds.images[1], g["images"][names.index("rgb16.png")])

@@ -62,6 +62,7 @@ SIGNATURES = {
     "vt_model_sgd_step_range": (i, [p, f, f, i, i, p]),
     "vt_model_metrics": (i, [p, p, p, p, p]),
     "vt_model_graph_capture": (i, [p, p, p, i, f, f]),
+    "vt_model_graph_capture_forward": (i, [p, p, i, p]),
     "vt_model_graph_launch": (i, [p, p]),
     "vt_model_read": (l, [p, C.c_char_p, p, l]),
     "vt_model_profile": (i, [p, C.c_char_p]),
@@ -74,6 +75,7 @@ SIGNATURES = {
     "vt_model_save_v2": (i, [p, C.POINTER(VtTrainState), C.c_char_p]),
     "vt_model_load_v2": (i, [p, C.POINTER(VtTrainState), C.c_char_p]),
     "vt_idx_read_images": (i, [C.c_char_p, i, p, C.POINTER(i), C.POINTER(i), C.POINTER(i)]),
+    "vt_image_read_gray": (i, [C.c_char_p, p, i, p, p]),
     "vt_idx_read_labels": (i, [C.c_char_p, i, p, C.POINTER(i)]),
     "vt_loader_indices": (i, [i, u, i, p]),
     "vt_conv3x3_fwd": (i, [p, p, p, p, p, i, i, i, i, p]),

@@ -828,8 +828,9 @@ extern "C" int vt_model_sgd_step_range(vt_model *m, float lr, float divisor, int
   return 0;
 }
 
-extern "C" int vt_model_graph_capture(vt_model *m, const float *x_dev, const int *y_dev, int n, float lr, float divisor) {
-  if (!m || !x_dev || !y_dev || n < 1 || n > m->maxN || divisor == 0.f) return VT_EINVAL;
+// Captures `body` (launches on m->gstream) as the model's step graph.
+template <typename Body>
+static int capture_graph(vt_model *m, Body body) {
   HIPCHK(hipSetDevice(m->device));
   if (!m->gstream) HIPCHK(hipStreamCreateWithFlags(&m->gstream, hipStreamNonBlocking));
   if (m->graph_exec) { (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
@@ -838,15 +839,28 @@ extern "C" int vt_model_graph_capture(vt_model *m, const float *x_dev, const int
   m->prof_filter.clear();  // no timing events inside the captured region
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipStreamBeginCapture(m->gstream, hipStreamCaptureModeThreadLocal));
-  int rc = vt_model_forward(m, x_dev, n, nullptr, (vt_stream)m->gstream);
-  if (rc == 0) rc = vt_model_backward(m, y_dev, (vt_stream)m->gstream);
-  if (rc == 0) rc = vt_model_sgd_step(m, lr, divisor, (vt_stream)m->gstream);
+  const int rc = body((vt_stream)m->gstream);
   const hipError_t e = hipStreamEndCapture(m->gstream, &m->graph);
   m->prof_filter = saved;
   if (rc != 0) return rc;
   if (e != hipSuccess) return (int)e;
   HIPCHK(hipGraphInstantiate(&m->graph_exec, m->graph, nullptr, nullptr, 0));
   return 0;
+}
+
+extern "C" int vt_model_graph_capture(vt_model *m, const float *x_dev, const int *y_dev, int n, float lr, float divisor) {
+  if (!m || !x_dev || !y_dev || n < 1 || n > m->maxN || divisor == 0.f) return VT_EINVAL;
+  return capture_graph(m, [&](vt_stream gs) {
+    int rc = vt_model_forward(m, x_dev, n, nullptr, gs);
+    if (rc == 0) rc = vt_model_backward(m, y_dev, gs);
+    if (rc == 0) rc = vt_model_sgd_step(m, lr, divisor, gs);
+    return rc;
+  });
+}
+
+extern "C" int vt_model_graph_capture_forward(vt_model *m, const float *x_dev, int n, float *probs_dev) {
+  if (!m || !x_dev || n < 1 || n > m->maxN) return VT_EINVAL;
+  return capture_graph(m, [&](vt_stream gs) { return vt_model_forward(m, x_dev, n, probs_dev, gs); });
 }
 
 extern "C" int vt_model_graph_launch(vt_model *m, vt_stream s) {

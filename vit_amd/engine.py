@@ -6,6 +6,7 @@ streams and (optionally) torch.distributed; every computation is a HIP kernel in
 """
 import ctypes as C
 import math
+import os
 import time
 
 import numpy as np
@@ -185,6 +186,16 @@ class VTCNN:
         check(lib.vt_model_graph_capture(self._h, C.c_void_p(x.data_ptr()), C.c_void_p(labels.data_ptr()), self._n,
                                          self.lr, float(batch_size)), "vt_model_graph_capture")
 
+    def capture_forward(self, x):
+        """Captures the forward pass on the fixed device buffer x as a HIP graph (current
+        training / eval mode); replay with step_graph(), results in self.probs_view(n)."""
+        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+        self._n = x.shape[0]
+        self._x = x
+        check(lib.vt_model_graph_capture_forward(self._h, C.c_void_p(x.data_ptr()), self._n, C.c_void_p(self._probs.data_ptr())),
+              "vt_model_graph_capture_forward")
+        return self._probs[:self._n]
+
     def step_graph(self):
         check(lib.vt_model_graph_launch(self._h, _stream_handle()), "vt_model_graph_launch")
 
@@ -286,6 +297,36 @@ def load_dataset(image_path, label_path, max_samples=9999999):
     u8 = np.zeros(imgs.size, dtype=np.uint8)  # a short file leaves the missing pixels at 0, as the float path does
     u8[:raw.size] = raw
     return Dataset(imgs, lbl, u8.reshape(imgs.shape))
+
+
+def load_image_as_vector(path, target_w=28, target_h=28):
+    """load_image_as_vector (utils/load_image_stb.hpp:9-26): one grey float per pixel of a PNG,
+    pixel / 255.0f, the grey byte exactly as the reference's decoder forms it."""
+    w, h = C.c_int(0), C.c_int(0)
+    if lib.vt_image_read_gray(str(path).encode(), None, 0, C.byref(w), C.byref(h)) != 0:
+        raise RuntimeError("No se pudo cargar la imagen: %s" % path)
+    if w.value != target_w or h.value != target_h:
+        raise RuntimeError("La imagen debe ser de tamaño 28x28")
+    raw = np.zeros(w.value * h.value, dtype=np.uint8)
+    if lib.vt_image_read_gray(str(path).encode(), C.c_void_p(raw.ctypes.data), raw.size, C.byref(w), C.byref(h)) != 0:
+        raise RuntimeError("No se pudo cargar la imagen: %s" % path)
+    return raw.astype(np.float32) / np.float32(255.0)
+
+
+def load_custom_images_from_folder(folder_path):
+    """load_custom_images_from_folder (utils/load_dataset.hpp:167-209): .png/.jpg/.jpeg files in
+    alphabetical order of their names; files that do not load are reported and skipped."""
+    import sys
+    names = sorted(f for f in os.listdir(folder_path)
+                   if os.path.isfile(os.path.join(folder_path, f)) and os.path.splitext(f)[1] in (".png", ".jpg", ".jpeg"))
+    images = []
+    for f in names:
+        try:
+            images.append(load_image_as_vector(os.path.join(folder_path, f)))
+        except RuntimeError as e:
+            print("Error al cargar %s: %s" % (os.path.join(folder_path, f), e), file=sys.stderr)
+    arr = np.stack(images) if images else np.zeros((0, 784), dtype=np.float32)
+    return Dataset(arr, np.zeros(len(images), dtype=np.int32), None)
 
 
 def loader_indices(n, seed=42, resets=0):
