@@ -346,6 +346,15 @@ int vt_conv3x3_wgrad(const float *x, const float *dy, const float *bn_coef, floa
                      vt_stream s);
 /* Column sums of a [rows][cols] slab into out[cols] (deterministic order). */
 int vt_reduce_rows(const float *slab, long rows, int cols, int ld, float *out, vt_stream s);
+/* Tensor::matmul and its batched form (tensor_cpu.hpp:754-814, 816-893) behind every DenseLayer
+ * (layers/dense_layer.hpp:67-100) when the contraction is a real matrix product (the scaled and wide
+ * shapes):  C[b] = alpha * op(A[b]) . op(B[b]) (+ bias[n]) (+ C[b] if accumulate), b < batch.
+ * Row-major, leading dimensions lda/ldb/ldc, element strides between batch members; transX != 0
+ * reads the operand transposed.  Exact fp32 on the matrix cores.  workspace (may be NULL) lets a
+ * long contraction with a small result be cut along K; its partial sums are added in a fixed order. */
+int vt_gemm_f32(int transA, int transB, int M, int N, int K, float alpha, const float *A, int lda, long strideA,
+                const float *B, int ldb, long strideB, int accumulate, float *C, int ldc, long strideC,
+                const float *bias, int batch, float *workspace, long workspace_floats, vt_stream s);
 /* update_weights + SGD::update (utils/optimizer.hpp:22-28) over n floats. */
 int vt_sgd_update(float *w, float *g, int n, float lr, float divisor, int zero_grad, vt_stream s);
 /* Textbook Adam over the arena.  NOT in the reference (utils/optimizer.hpp has SGD only):

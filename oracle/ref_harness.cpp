@@ -84,6 +84,19 @@ struct Hyper
   int vt_channels = 16, enc_layers = 2, heads = 2, fc_dim = 64, num_classes = 10;
 };
 
+// Hyper-parameters other than the class count come from the environment when set (the scaled and
+// wide shapes): VT_REF_CI, VT_REF_H, VT_REF_TOKENS, VT_REF_D, VT_REF_C2, VT_REF_HEADS.
+static void hyper_from_env(Hyper &h)
+{
+  auto geti = [](const char *k, int &v) { if (const char *e = std::getenv(k)) v = std::atoi(e); };
+  geti("VT_REF_CI", h.image_channels);
+  geti("VT_REF_H", h.input_dim);
+  geti("VT_REF_TOKENS", h.tokens);
+  geti("VT_REF_D", h.token_channels);
+  geti("VT_REF_C2", h.vt_channels);
+  geti("VT_REF_HEADS", h.heads);
+}
+
 static VTCNN *make_model(const Hyper &h)
 {
   Tensor::set_seed(42);
@@ -172,6 +185,7 @@ static int cmd_step(int argc, char **argv)
   std::string path = argv[2];
   int N = std::atoi(argv[3]);
   Hyper h;
+  hyper_from_env(h);
   h.num_classes = std::atoi(argv[4]);
   unsigned seed = (unsigned)std::atoi(argv[5]);
   bool full = std::atoi(argv[6]) != 0;

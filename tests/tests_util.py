@@ -48,3 +48,38 @@ def arena_from_checkpoint(path, layout, arena):
     for nm, v in parse_checkpoint(path).items():
         layout.view(arena, nm)[...] = v.reshape(layout.tensors[nm][2])
     return arena
+
+
+STRIDE, BIG = 7, 4096  # tools/make_golden_shapes.py: tensors above BIG elements are stored strided plus their sum
+
+
+def shape_case(g):
+    """(dims kwargs, n, k, seed, x [n,ci,h,h], labels) of a tests/golden/shape_*.npz fixture; the
+    inputs are regenerated exactly as the reference harness draws them."""
+    ci, h, tokens, d, c2, heads, k, n, seed = (int(v) for v in g["meta.dims"])
+    raw = np.random.RandomState(seed)._bit_generator.random_raw(n * ci * h * h + n).astype(np.uint64)
+    x = ((raw[:n * ci * h * h] & 0xFF).astype(np.float32) / np.float32(255.0)).reshape(n, ci, h, h)
+    y = (raw[n * ci * h * h:] % k).astype(np.int32)
+    dims = dict(num_classes=k, image_channels=ci, input_dim=h, tokens=tokens, token_channels=d, vt_channels=c2, heads=heads)
+    return dims, n, k, seed, x, y
+
+
+def compare_compact(g, key, full, tol, exact=False):
+    """Compares a full tensor with its fixture entry (strided + sum when the tensor is big).
+    Returns the relative error max|a-b| / max|b| over the stored elements."""
+    want = g[key]
+    full = np.asarray(full).ravel()
+    if key + ".sum" in g:
+        got = full[::STRIDE]
+        scale = max(float(np.abs(full).sum()), 1e-30)
+        assert abs(float(full.astype(np.float64).sum()) - float(g[key + ".sum"][0])) <= 10 * tol * scale, key
+    else:
+        got = full
+        want = want.ravel()
+    assert got.shape == want.shape, (key, got.shape, want.shape)
+    if exact:
+        assert np.array_equal(got, want), key
+        return 0.0
+    err = float(np.abs(got.astype(np.float64) - want).max() / max(float(np.abs(want).max()), 1e-30))
+    assert err < tol, (key, err)
+    return err

@@ -201,7 +201,7 @@ __global__ void k_bn_running_seq(const float *__restrict__ batch_mv, int groups,
 // Eval-mode statistics from the running buffers (batch_normalization_layer.hpp:287-291).
 __global__ void k_bn_stats_eval(const float *__restrict__ run_mean, const float *__restrict__ run_var, int C,
                                 float *__restrict__ stat) {
-  const int c = threadIdx.x;
+  const int c = blockIdx.x * 64 + threadIdx.x;
   if (c < C) {
     stat[c] = run_mean[c];
     stat[C + c] = 1.0f / sqrtf(run_var[c] + BN_EPS);
@@ -344,8 +344,8 @@ extern "C" int vt_bn_stats_finalize_grouped(const float *part, int nblocks, int 
 }
 
 extern "C" int vt_bn_stats_eval(const float *running_mean, const float *running_var, int C, float *stat, vt_stream s) {
-  if (C < 1 || C > 64) return VT_EUNSUPPORTED;
-  hipLaunchKernelGGL(k_bn_stats_eval, dim3(1), dim3(64), 0, (hipStream_t)s, running_mean, running_var, C, stat);
+  if (C < 1) return VT_EUNSUPPORTED;
+  hipLaunchKernelGGL(k_bn_stats_eval, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)s, running_mean, running_var, C, stat);
   VT_CHECK_LAUNCH();
   return 0;
 }

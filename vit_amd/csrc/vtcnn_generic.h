@@ -1,0 +1,35 @@
+// State of the general-shape VTCNN step (vtcnn_generic.hip): activation and delta buffers sized for
+// max_batch samples.  Owned by the model handle, which also owns the arenas and the layout.
+#pragma once
+#include "vtcnn_common.h"
+
+namespace vt {
+
+#define HIPCHK_G(x)                         \
+  do {                                      \
+    hipError_t e__ = (x);                   \
+    if (e__ != hipSuccess) return (int)e__; \
+  } while (0)
+
+struct GenModel {
+  int Ci, H, P, C1, C2, L, D, heads, hd, K, Q, pk, maxN;
+  // forward
+  float *col, *conv, *x, *tokA, *T0, *tok, *a, *hdn, *rl, *s2, *o, *q, *k, *v, *pa, *z, *pooled, *logits, *probs;
+  int *pool_idx;
+  float *stat_bn, *stat_n1, *stat_n2, *stat_pn, *coef, *part, *ws;
+  long part_floats, ws_floats;
+  // backward
+  float *dlogits, *dpool, *du, *dz, *pdx, *dsa, *dq, *dv, *dk, *pdt, *d0, *ds2, *dh, *da, *dr, *dc;
+  float *Qm, *Km, *Vm, *dQ, *dK, *dV, *attn, *dat, *dT0, *tdx;
+};
+
+// alloc(ctx, &ptr, floats, name or NULL) allocates device memory that the caller tracks
+int gen_create(GenModel *g, const vt_dims *d, int maxN, int (*alloc)(void *, float **, size_t, const char *), void *ctx);
+// arena: weights (read); arena_rw: the same arena, for the running statistics the forward updates
+int gen_forward(GenModel *g, const float *arena, const vt_layout *lo, float *arena_rw, const float *X, int n, int training,
+                float *probs_out, hipStream_t s);
+// phase bit 0: everything but the attention block; bit 1: the attention block (mha.q*/k*/v* gradients)
+int gen_backward(GenModel *g, const float *arena, const vt_layout *lo, float *grads, const float *X, const int *labels, int n,
+                 int phase, hipStream_t s);
+
+}  // namespace vt

@@ -1,0 +1,609 @@
+// The VTCNN step for shapes outside the compiled headline kernels (any conv width, token count,
+// token width, head count and image size: the scaled 224x224 and the wide 196-token shapes).
+// Here the contractions are real matrix products, so the step is laid out the way the reference's
+// layers are (model/vit_cnn.hpp:103-242): every DenseLayer and every batched matmul is one
+// vt_gemm_f32 launch on the matrix cores; what lies between them (BatchNorm statistics and apply,
+// the two softmax flavours, pooling, masks, residual adds) is a set of small row-matrix kernels.
+// All activations are row matrices [rows, channels]; the conv output is kept pixel-major [N*P, C1]
+// (the reference's flatten + transpose, vit_cnn.hpp:127-134, is then the identity).
+#include "vtcnn_generic.h"
+
+#include <algorithm>
+#include <string>
+
+namespace vt {
+
+#define VTG(x)              \
+  do {                      \
+    int r__ = (x);          \
+    if (r__ != 0) return r__; \
+  } while (0)
+
+constexpr int GT = 256;  // threads per workgroup of the row-matrix kernels
+
+// column-tile geometry shared by the column-wise kernels: `cw` columns (16, 32 or 64) side by
+// side, GT / cw row lanes; a block covers rows [blockIdx.x * rpb, ...) and loops over column tiles
+static int col_width(int C) { return C <= 16 ? 16 : (C <= 32 ? 32 : 64); }
+
+// ---- im2col for the 3x3, stride 1, pad 1 convolution (layers/conv2d_layer.hpp:35-87) ----------
+// col[(n*P + p)][ci*9 + kh*3 + kw] = X[n][ci][h+kh-1][w+kw-1] (0 outside the image)
+__global__ __launch_bounds__(GT) void k_im2col(const float *__restrict__ X, float *__restrict__ col, long total, int Ci,
+                                               int H, int W) {
+  const int CK = Ci * 9;
+  for (long i = (long)blockIdx.x * GT + threadIdx.x; i < total; i += (long)gridDim.x * GT) {
+    const int j = (int)(i % CK);
+    const long row = i / CK;
+    const int p = (int)(row % ((long)H * W));
+    const long n = row / ((long)H * W);
+    const int ci = j / 9, kh = (j % 9) / 3, kw = j % 3;
+    const int hi = p / W + kh - 1, wi = p % W + kw - 1;
+    col[i] = (hi >= 0 && hi < H && wi >= 0 && wi < W) ? X[((n * Ci + ci) * H + hi) * W + wi] : 0.f;
+  }
+}
+
+// ---- per-column partial statistics of a row matrix: part[b][0][c] = sum, part[b][1][c] = sum of
+// squared distances from the block's own mean (merged by vt_bn_stats_finalize) ---------------------
+__global__ __launch_bounds__(GT) void k_colstats(const float *__restrict__ in, long R, int C, int rpb, int cw,
+                                                 float *__restrict__ part) {
+  __shared__ float sh[GT];
+  __shared__ float mean_s[64];
+  const int cl = threadIdx.x % cw, rl = threadIdx.x / cw, nrl = GT / cw;
+  const long r0 = (long)blockIdx.x * rpb, r1 = r0 + rpb < R ? r0 + rpb : R;
+  for (int c0 = 0; c0 < C; c0 += cw) {
+    const int c = c0 + cl;
+    float s = 0.f;
+    if (c < C)
+      for (long r = r0 + rl; r < r1; r += nrl) s += in[r * C + c];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    if (rl == 0) {
+      float t = 0.f;
+      for (int k = 0; k < nrl; ++k) t += sh[k * cw + cl];
+      if (c < C) part[(size_t)blockIdx.x * 2 * C + c] = t;
+      mean_s[cl] = t / (float)(r1 - r0);
+    }
+    __syncthreads();
+    const float mu = mean_s[cl];
+    float q = 0.f;
+    if (c < C)
+      for (long r = r0 + rl; r < r1; r += nrl) {
+        const float d = in[r * C + c] - mu;
+        q += d * d;
+      }
+    sh[threadIdx.x] = q;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+      float t = 0.f;
+      for (int k = 0; k < nrl; ++k) t += sh[k * cw + cl];
+      part[(size_t)blockIdx.x * 2 * C + C + c] = t;
+    }
+    __syncthreads();
+  }
+}
+
+// ---- BatchNorm apply: out = (in - mean) * inv * gamma + beta (optionally ReLU) -------------------
+__global__ __launch_bounds__(GT) void k_bn_apply(const float *__restrict__ in, const float *__restrict__ stat,
+                                                 const float *__restrict__ g, const float *__restrict__ b,
+                                                 float *__restrict__ out, long total, int C, int relu) {
+  for (long i = (long)blockIdx.x * GT + threadIdx.x; i < total; i += (long)gridDim.x * GT) {
+    const int c = (int)(i % C);
+    float y = (in[i] - stat[c]) * stat[C + c] * g[c] + b[c];
+    if (relu) y = fmaxf(y, 0.f);
+    out[i] = y;
+  }
+}
+
+// ---- BatchNorm backward partial sums: part[b][0][c] = sum delta, part[b][1][c] = sum delta*xhat --
+// (batch_normalization_layer.hpp:187-188, 316-317); also used, with stat == NULL, for plain column
+// sums (bias gradients), where only part[b][0][c] is meaningful
+__global__ __launch_bounds__(GT) void k_bnbwd_partial(const float *__restrict__ delta, const float *__restrict__ in,
+                                                      const float *__restrict__ stat, long R, int C, int rpb, int cw,
+                                                      float *__restrict__ part) {
+  __shared__ float sh[2][GT];
+  const int cl = threadIdx.x % cw, rl = threadIdx.x / cw, nrl = GT / cw;
+  const long r0 = (long)blockIdx.x * rpb, r1 = r0 + rpb < R ? r0 + rpb : R;
+  for (int c0 = 0; c0 < C; c0 += cw) {
+    const int c = c0 + cl;
+    float s1 = 0.f, s2 = 0.f;
+    if (c < C) {
+      const float mu = stat ? stat[c] : 0.f, iv = stat ? stat[C + c] : 0.f;
+      for (long r = r0 + rl; r < r1; r += nrl) {
+        const float d = delta[r * C + c];
+        s1 += d;
+        if (stat) s2 += d * ((in[r * C + c] - mu) * iv);
+      }
+    }
+    sh[0][threadIdx.x] = s1;
+    sh[1][threadIdx.x] = s2;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+      float t1 = 0.f, t2 = 0.f;
+      for (int k = 0; k < nrl; ++k) {
+        t1 += sh[0][k * cw + cl];
+        t2 += sh[1][k * cw + cl];
+      }
+      part[(size_t)blockIdx.x * 2 * C + c] = t1;
+      part[(size_t)blockIdx.x * 2 * C + C + c] = t2;
+    }
+    __syncthreads();
+  }
+}
+
+// delta_in = delta * scale[c] + shift[c] (coef from vt_bn_bwd_finalize)
+__global__ __launch_bounds__(GT) void k_scale_shift(const float *__restrict__ d, const float *__restrict__ coef,
+                                                    float *__restrict__ out, long total, int C) {
+  for (long i = (long)blockIdx.x * GT + threadIdx.x; i < total; i += (long)gridDim.x * GT) {
+    const int c = (int)(i % C);
+    out[i] = d[i] * coef[c] + coef[C + c];
+  }
+}
+
+// ---- elementwise: out = a + b (op 0), a - b (1), max(a, 0) (2), fill with b-less constant 0 (3) --
+__global__ __launch_bounds__(GT) void k_ewise(const float *__restrict__ a, const float *__restrict__ b,
+                                              float *__restrict__ out, long total, int op) {
+  for (long i = (long)blockIdx.x * GT + threadIdx.x; i < total; i += (long)gridDim.x * GT) {
+    float r;
+    switch (op) {
+      case 0: r = a[i] + b[i]; break;
+      case 1: r = a[i] - b[i]; break;
+      case 2: r = fmaxf(a[i], 0.f); break;
+      default: r = 0.f; break;
+    }
+    out[i] = r;
+  }
+}
+
+// ---- softmax over the pixel axis of S[n][p][l], per (n, l) (tokenizer.hpp:36, Tensor::softmax over
+// dim 1, tensor_cpu.hpp:894-944); in place ------------------------------------------------------------
+__global__ __launch_bounds__(GT) void k_softmax_pixels(float *__restrict__ S, int P, int Lt, int cw) {
+  __shared__ float sh[GT];
+  __shared__ float bc[64];
+  const int cl = threadIdx.x % cw, rl = threadIdx.x / cw, nrl = GT / cw;
+  const int l = blockIdx.x * cw + cl;
+  float *__restrict__ base = S + (size_t)blockIdx.y * P * Lt;
+  const bool on = l < Lt;
+  float mx = -INFINITY;
+  if (on)
+    for (int p = rl; p < P; p += nrl) mx = fmaxf(mx, base[(size_t)p * Lt + l]);
+  sh[threadIdx.x] = mx;
+  __syncthreads();
+  if (rl == 0) {
+    float t = -INFINITY;
+    for (int k = 0; k < nrl; ++k) t = fmaxf(t, sh[k * cw + cl]);
+    bc[cl] = t;
+  }
+  __syncthreads();
+  mx = bc[cl];
+  float s = 0.f;
+  if (on)
+    for (int p = rl; p < P; p += nrl) {
+      const float e = expf(base[(size_t)p * Lt + l] - mx);
+      base[(size_t)p * Lt + l] = e;
+      s += e;
+    }
+  __syncthreads();
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  if (rl == 0) {
+    float t = 0.f;
+    for (int k = 0; k < nrl; ++k) t += sh[k * cw + cl];
+    bc[cl] = t;
+  }
+  __syncthreads();
+  const float sum = bc[cl];
+  if (on)
+    for (int p = rl; p < P; p += nrl) base[(size_t)p * Lt + l] /= sum;
+}
+
+// ---- softmax over the last axis, one wave per row (projector_layer.hpp:84, attention scores
+// multi_head_attention.hpp:157); in place ---------------------------------------------------------------
+__global__ __launch_bounds__(GT) void k_softmax_rows(float *__restrict__ S, long rows, int Wd) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * (GT / 64) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float *__restrict__ r = S + row * Wd;
+  float mx = -INFINITY;
+  for (int j = lane; j < Wd; j += 64) mx = fmaxf(mx, r[j]);
+  mx = wave_max(mx);
+  float s = 0.f;
+  for (int j = lane; j < Wd; j += 64) {
+    const float e = expf(r[j] - mx);
+    r[j] = e;
+    s += e;
+  }
+  s = wave_sum(s);
+  for (int j = lane; j < Wd; j += 64) r[j] /= s;
+}
+
+// Tensor::softmax_backward over the last axis (tensor_cpu.hpp:946-950): ds = a * (da - sum a*da); in
+// place on da
+__global__ __launch_bounds__(GT) void k_softmax_bwd_rows(const float *__restrict__ a, float *__restrict__ da, long rows,
+                                                         int Wd) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * (GT / 64) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float *__restrict__ ar = a + row * Wd;
+  float *__restrict__ dr = da + row * Wd;
+  float dot = 0.f;
+  for (int j = lane; j < Wd; j += 64) dot += ar[j] * dr[j];
+  dot = wave_sum(dot);
+  for (int j = lane; j < Wd; j += 64) dr[j] = ar[j] * (dr[j] - dot);
+}
+
+// ---- reshape [N,P,C2] -> [N,C2,H,W] without moving data (vit_cnn.hpp:179) + MaxPool2DLayer::forward
+// (layers/pooling_layer.hpp:18-66) over the ReLU of the normalised projector output; the first
+// maximum of a window wins ---------------------------------------------------------------------------
+__global__ __launch_bounds__(GT) void k_pool_fwd(const float *__restrict__ z, const float *__restrict__ stat,
+                                                 const float *__restrict__ g, const float *__restrict__ b,
+                                                 float *__restrict__ pooled, int *__restrict__ pool_idx, long total, int C2,
+                                                 int H, int pk) {
+  const int W = H, P = H * W;
+  for (long i = (long)blockIdx.x * GT + threadIdx.x; i < total; i += (long)gridDim.x * GT) {
+    const int j = (int)(i % 14), ii = (int)((i / 14) % 14);
+    const long nc = i / 196;  // n * C2 + ch
+    const float *__restrict__ plane = z + nc * P;
+    const long f0 = (nc % C2) * (long)P;  // flat offset of the plane inside its sample
+    float mv = -INFINITY;
+    int mi = -1;
+    for (int ki = 0; ki < pk; ++ki)
+      for (int kj = 0; kj < pk; ++kj) {
+        const int rem = (ii * pk + ki) * W + j * pk + kj;
+        const int c = (int)((f0 + rem) % C2);
+        const float y = fmaxf((plane[rem] - stat[c]) * stat[C2 + c] * g[c] + b[c], 0.f);
+        if (y > mv) {
+          mv = y;
+          mi = rem;
+        }
+      }
+    pooled[i] = mv;
+    pool_idx[i] = mi;
+  }
+}
+
+// MaxPool2DLayer::backward (pooling_layer.hpp:68-97) as a gather + the ReLU mask on the flat
+// reinterpretation (relu_layer.hpp:20-33): du[F] = dpool[window(F)] if F is the window's arg-max and
+// the activation was positive
+__global__ __launch_bounds__(GT) void k_pool_bwd(const float *__restrict__ z, const float *__restrict__ stat,
+                                                 const float *__restrict__ g, const float *__restrict__ b,
+                                                 const float *__restrict__ dpool, const int *__restrict__ pool_idx,
+                                                 float *__restrict__ du, long total, int C2, int H, int pk) {
+  const int W = H, P = H * W;
+  const long per = (long)P * C2;
+  for (long i = (long)blockIdx.x * GT + threadIdx.x; i < total; i += (long)gridDim.x * GT) {
+    const long n = i / per, F = i - n * per;
+    const int ch = (int)(F / P), rem = (int)(F - (long)ch * P);
+    const int h = rem / W, w = rem - h * W;
+    const long win = (n * C2 + ch) * 196 + (h / pk) * 14 + (w / pk);
+    const int c = (int)(F % C2);
+    const float y = (z[i] - stat[c]) * stat[C2 + c] * g[c] + b[c];
+    du[i] = (y > 0.f && pool_idx[win] == rem) ? dpool[win] : 0.f;
+  }
+}
+
+// SoftmaxLayer::backward with targets (layers/softmax_layer.hpp:29): probs - onehot
+__global__ __launch_bounds__(GT) void k_dlogits(const float *__restrict__ probs, const int *__restrict__ labels,
+                                                float *__restrict__ dl, int total, int K) {
+  const int i = blockIdx.x * GT + threadIdx.x;
+  if (i < total) dl[i] = probs[i] - ((i % K) == labels[i / K] ? 1.0f : 0.0f);
+}
+
+static unsigned nblk(long total) { return (unsigned)std::min<long>((total + GT - 1) / GT, 1 << 20); }
+
+}  // namespace vt
+
+using namespace vt;
+
+// ---------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------
+namespace {
+
+struct Gemm {
+  vt::GenModel *g;
+  hipStream_t s;
+  // C = alpha * op(A).op(B) (+bias) (+C)
+  int operator()(bool ta, bool tb, int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *C, int ldc,
+                 const float *bias = nullptr, bool acc = false, float alpha = 1.f, int batch = 1, long sA = 0, long sB = 0,
+                 long sC = 0) const {
+    return vt_gemm_f32(ta, tb, M, N, K, alpha, A, lda, sA, B, ldb, sB, acc, C, ldc, sC, bias, batch, g->ws, g->ws_floats,
+                       (vt_stream)s);
+  }
+};
+
+int rows_per_block(long R) {
+  // enough blocks to fill the chip, few enough that the finalize kernels stay short
+  long rpb = (R + 4095) / 4096;
+  if (rpb < 64) rpb = 64;
+  return (int)std::min<long>(rpb, 1 << 20);
+}
+
+// BatchNorm forward statistics of in [R, C] (training: batch statistics + running update; eval with
+// eval_ok: the running buffers)
+int bn_stats(vt::GenModel *g, const float *in, long R, int C, float *run_mean, float *run_var, float *stat, bool use_running,
+             hipStream_t s) {
+  if (use_running) return vt_bn_stats_eval(run_mean, run_var, C, stat, (vt_stream)s);
+  const int rpb = rows_per_block(R), nb = (int)((R + rpb - 1) / rpb);
+  if ((long)nb * 2 * C > g->part_floats) return VT_EUNSUPPORTED;
+  hipLaunchKernelGGL(k_colstats, dim3(nb), dim3(GT), 0, s, in, R, C, rpb, col_width(C), g->part);
+  VT_CHECK_LAUNCH();
+  return vt_bn_stats_finalize(g->part, nb, C, rpb, R, run_mean, run_var, stat, (vt_stream)s);
+}
+
+// BatchNormLayer1D / BatchNorm2DLayer::backward (batch_normalization_layer.hpp:172-200, 300-327):
+// gradients of gamma / beta and din = delta * scale + shift with the row-0 variance term
+int bn_backward(vt::GenModel *g, const float *delta, const float *in, const float *stat, const float *gamma, long R, int C,
+                float *ggamma, float *gbeta, float *coef, float *din, hipStream_t s) {
+  const int rpb = rows_per_block(R), nb = (int)((R + rpb - 1) / rpb);
+  if ((long)nb * 2 * C > g->part_floats) return VT_EUNSUPPORTED;
+  hipLaunchKernelGGL(k_bnbwd_partial, dim3(nb), dim3(GT), 0, s, delta, in, stat, R, C, rpb, col_width(C), g->part);
+  VT_CHECK_LAUNCH();
+  VTG(vt_bn_bwd_finalize(g->part, nb, C, R, gamma, stat, in, ggamma, gbeta, coef, (vt_stream)s));
+  hipLaunchKernelGGL(k_scale_shift, dim3(nblk(R * C)), dim3(GT), 0, s, delta, coef, din, R * C, C);
+  VT_CHECK_LAUNCH();
+  return 0;
+}
+
+// bias gradient of a DenseLayer: column sums of dY [R, C] (dense_layer.hpp:95-96)
+int col_sums(vt::GenModel *g, const float *dY, long R, int C, float *out, hipStream_t s) {
+  const int rpb = rows_per_block(R), nb = (int)((R + rpb - 1) / rpb);
+  if ((long)nb * 2 * C > g->part_floats) return VT_EUNSUPPORTED;
+  hipLaunchKernelGGL(k_bnbwd_partial, dim3(nb), dim3(GT), 0, s, dY, (const float *)nullptr, (const float *)nullptr, R, C, rpb,
+                     col_width(C), g->part);
+  VT_CHECK_LAUNCH();
+  return vt_reduce_rows(g->part, nb, C, 2 * C, out, (vt_stream)s);
+}
+
+int ewise(const float *a, const float *b, float *out, long total, int op, hipStream_t s) {
+  hipLaunchKernelGGL(k_ewise, dim3(nblk(total)), dim3(GT), 0, s, a, b, out, total, op);
+  VT_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // namespace
+
+namespace vt {
+
+int gen_create(GenModel *g, const vt_dims *d, int maxN, int (*alloc)(void *, float **, size_t, const char *), void *ctx) {
+  g->Ci = d->image_channels; g->H = d->input_dim; g->P = g->H * g->H;
+  g->C2 = d->vt_channels; g->C1 = g->C2 / 2; g->L = d->tokens; g->D = d->token_channels;
+  g->heads = d->heads; g->hd = g->D / g->heads; g->K = d->num_classes; g->Q = g->C2 * 196; g->pk = g->H / 14;
+  g->maxN = maxN;
+  if (g->C1 > 1024 || g->C2 > 1024 || g->D > 1024) return VT_EUNSUPPORTED;  // finalize kernels: one workgroup per channel
+  const size_t N = maxN, NP = N * g->P, NL = N * g->L;
+  const int C1 = g->C1, C2 = g->C2, L = g->L, D = g->D, hd = g->hd, K = g->K, Q = g->Q;
+  int rc = 0;
+  auto A = [&](float **p, size_t n, const char *name) { rc |= alloc(ctx, p, n, name); };
+  A(&g->col, NP * g->Ci * 9, nullptr);
+  A(&g->conv, NP * C1, "fwd.conv_out");
+  A(&g->x, NP * C1, "fwd.x");
+  A(&g->tokA, NP * L, "fwd.tok_A");
+  A(&g->T0, NL * C1, "fwd.tok_T0");
+  A(&g->tok, NL * D, "fwd.tok_out");
+  A(&g->a, NL * D, "fwd.tr_a");
+  A(&g->hdn, NL * D, "fwd.tr_hdn");
+  A(&g->rl, NL * D, nullptr);
+  A(&g->s2, NL * D, "fwd.tr_s2");
+  A(&g->o, NL * D, "fwd.tr_out");
+  A(&g->q, NP * D, nullptr);
+  A(&g->k, NL * D, nullptr);
+  A(&g->v, NL * C2, nullptr);
+  A(&g->pa, NP * L, "fwd.proj_a");
+  A(&g->z, NP * C2, "fwd.proj_z");
+  A(&g->pooled, N * Q, "fwd.pooled");
+  A(&g->logits, N * K, "fwd.logits");
+  A(&g->probs, N * K, "fwd.preds");
+  float *pi = nullptr;
+  A(&pi, N * Q, "fwd.pool_idx");  // int32 offsets inside the [H, W] plane
+  g->pool_idx = (int *)pi;
+  A(&g->stat_bn, 2 * C1, "stat.bn");
+  A(&g->stat_n1, 2 * D, "stat.norm1");
+  A(&g->stat_n2, 2 * D, "stat.norm2");
+  A(&g->stat_pn, 2 * C2, "stat.proj.norm");
+  A(&g->coef, 2 * (size_t)std::max(std::max(C1, C2), D), nullptr);
+  g->part_floats = 4096L * 2 * std::max(std::max(C1, C2), std::max(D, 64)) + 1024;
+  A(&g->part, (size_t)g->part_floats, nullptr);
+  g->ws_floats = 16L << 20;
+  A(&g->ws, (size_t)g->ws_floats, nullptr);
+  // backward
+  A(&g->dlogits, N * K, "bwd.d_logits");
+  A(&g->dpool, N * Q, "bwd.d_pooled");
+  A(&g->du, NP * C2, "bwd.du");
+  A(&g->dz, NP * C2, "bwd.proj_dz");
+  A(&g->pdx, NP * C1, "bwd.proj_dx");
+  A(&g->dsa, NP * L, nullptr);
+  A(&g->dq, NP * D, nullptr);
+  A(&g->dv, NL * C2, "bwd.proj_dv");
+  A(&g->dk, NL * D, "bwd.proj_dk");
+  A(&g->pdt, NL * D, "bwd.proj_dt");
+  A(&g->d0, NL * D, nullptr);
+  A(&g->ds2, NL * D, "bwd.tr_ds2");
+  A(&g->dh, NL * D, nullptr);
+  A(&g->da, NL * D, nullptr);
+  A(&g->dr, NL * D, "bwd.tr_dr");
+  A(&g->dc, NL * D, nullptr);
+  A(&g->Qm, NL * hd, nullptr);
+  A(&g->Km, NL * hd, nullptr);
+  A(&g->Vm, NL * hd, nullptr);
+  A(&g->dQ, NL * hd, nullptr);
+  A(&g->dK, NL * hd, nullptr);
+  A(&g->dV, NL * hd, nullptr);
+  A(&g->attn, (size_t)L * N * N, nullptr);
+  A(&g->dat, (size_t)L * N * N, nullptr);
+  A(&g->dT0, NL * C1, nullptr);
+  A(&g->tdx, NP * C1, "bwd.tok_dx");
+  return rc ? VT_ENOMEM : 0;
+}
+
+// VTCNN::forward (model/vit_cnn.hpp:103-213)
+int gen_forward(GenModel *g, const float *arena, const vt_layout *lo, float *arena_rw, const float *X, int n, int training,
+                float *probs_out, hipStream_t s) {
+  const int P = g->P, C1 = g->C1, C2 = g->C2, L = g->L, D = g->D, K = g->K, Q = g->Q, CK = g->Ci * 9;
+  const long NP = (long)n * P, NL = (long)n * L;
+  auto W = [&](const char *name) { return arena + lo->t[vt_find(lo, name)].offset; };
+  auto RW = [&](const char *name) { return arena_rw + lo->t[vt_find(lo, name)].offset; };
+  const Gemm mm{g, s};
+  // Conv2DLayer::forward as im2col x W^T (conv2d_layer.hpp:35-87); output pixel-major [N*P, C1]
+  hipLaunchKernelGGL(k_im2col, dim3(nblk(NP * CK)), dim3(GT), 0, s, X, g->col, NP * CK, g->Ci, g->H, g->H);
+  VT_CHECK_LAUNCH();
+  VTG(mm(false, true, (int)NP, C1, CK, g->col, CK, W("conv.W"), CK, g->conv, C1, W("conv.b")));
+  // BatchNorm2DLayer::forward (batch_normalization_layer.hpp:262-298): the only norm that honours eval
+  VTG(bn_stats(g, g->conv, NP, C1, RW("bn.running_mean"), RW("bn.running_var"), g->stat_bn, !training, s));
+  hipLaunchKernelGGL(k_bn_apply, dim3(nblk(NP * C1)), dim3(GT), 0, s, g->conv, g->stat_bn, W("bn.gamma"), W("bn.beta"), g->x,
+                     NP * C1, C1, 0);
+  VT_CHECK_LAUNCH();
+  // FilterTokenizer::forward (layers/tokenizer.hpp:22-48)
+  VTG(mm(false, false, (int)NP, L, C1, g->x, C1, W("tok.linear1.W"), L, g->tokA, L, W("tok.linear1.b")));
+  {
+    const int cw = col_width(L);
+    hipLaunchKernelGGL(k_softmax_pixels, dim3((L + cw - 1) / cw, n), dim3(GT), 0, s, g->tokA, P, L, cw);
+    VT_CHECK_LAUNCH();
+  }
+  VTG(mm(true, false, L, C1, P, g->tokA, L, g->x, C1, g->T0, C1, nullptr, false, 1.f, n, (long)P * L, (long)P * C1,
+         (long)L * C1));
+  VTG(mm(false, false, (int)NL, D, C1, g->T0, C1, W("tok.linear2.W"), D, g->tok, D, W("tok.linear2.b")));
+  // TransformerLayer::forward (transformer_layer.hpp:43-131); the attention output is the zero concat
+  // (multi_head_attention.hpp:100-104), so the first residual is the tokens themselves
+  VTG(bn_stats(g, g->tok, NL, D, RW("norm1.running_mean"), RW("norm1.running_var"), g->stat_n1, false, s));
+  hipLaunchKernelGGL(k_bn_apply, dim3(nblk(NL * D)), dim3(GT), 0, s, g->tok, g->stat_n1, W("norm1.gamma"), W("norm1.beta"),
+                     g->a, NL * D, D, 0);
+  VT_CHECK_LAUNCH();
+  VTG(mm(false, false, (int)NL, D, D, g->a, D, W("ffn.linear1.W"), D, g->hdn, D, W("ffn.linear1.b")));
+  VTG(ewise(g->hdn, nullptr, g->rl, NL * D, 2, s));
+  VTG(mm(false, false, (int)NL, D, D, g->rl, D, W("ffn.linear2.W"), D, g->s2, D, W("ffn.linear2.b")));
+  VTG(ewise(g->a, g->s2, g->s2, NL * D, 0, s));
+  VTG(bn_stats(g, g->s2, NL, D, RW("norm2.running_mean"), RW("norm2.running_var"), g->stat_n2, false, s));
+  hipLaunchKernelGGL(k_bn_apply, dim3(nblk(NL * D)), dim3(GT), 0, s, g->s2, g->stat_n2, W("norm2.gamma"), W("norm2.beta"),
+                     g->o, NL * D, D, 0);
+  VT_CHECK_LAUNCH();
+  // ProjectorLayer::forward (projector_layer.hpp:43-116)
+  VTG(mm(false, false, (int)NP, D, C1, g->x, C1, W("proj.linear1.W"), D, g->q, D));
+  VTG(mm(false, false, (int)NL, D, D, g->o, D, W("proj.linear2.W"), D, g->k, D));
+  VTG(mm(false, false, (int)NL, C2, D, g->o, D, W("proj.linear3.W"), C2, g->v, C2, W("proj.linear3.b")));
+  VTG(mm(false, false, (int)NP, C2, C1, g->x, C1, W("proj.downsample.W"), C2, g->z, C2, W("proj.downsample.b")));
+  VTG(mm(false, true, P, L, D, g->q, D, g->k, D, g->pa, L, nullptr, false, 1.f, n, (long)P * D, (long)L * D, (long)P * L));
+  hipLaunchKernelGGL(k_softmax_rows, dim3((unsigned)((NP + 3) / 4)), dim3(GT), 0, s, g->pa, NP, L);
+  VT_CHECK_LAUNCH();
+  VTG(mm(false, false, P, C2, L, g->pa, L, g->v, C2, g->z, C2, nullptr, true, 1.f, n, (long)P * L, (long)L * C2,
+         (long)P * C2));
+  VTG(bn_stats(g, g->z, NP, C2, RW("proj.norm.running_mean"), RW("proj.norm.running_var"), g->stat_pn, false, s));
+  // reshape, max-pool, fc, softmax (vit_cnn.hpp:179-203)
+  hipLaunchKernelGGL(k_pool_fwd, dim3(nblk((long)n * Q)), dim3(GT), 0, s, g->z, g->stat_pn, W("proj.norm.gamma"),
+                     W("proj.norm.beta"), g->pooled, g->pool_idx, (long)n * Q, C2, g->H, g->pk);
+  VT_CHECK_LAUNCH();
+  VTG(mm(false, false, n, K, Q, g->pooled, Q, W("fc.W"), K, g->logits, K, W("fc.b")));
+  float *probs = probs_out ? probs_out : g->probs;
+  HIPCHK_G(hipMemcpyAsync(probs, g->logits, (size_t)n * K * sizeof(float), hipMemcpyDeviceToDevice, s));
+  hipLaunchKernelGGL(k_softmax_rows, dim3((unsigned)((n + 3) / 4)), dim3(GT), 0, s, probs, (long)n, K);
+  VT_CHECK_LAUNCH();
+  if (probs != g->probs) HIPCHK_G(hipMemcpyAsync(g->probs, probs, (size_t)n * K * sizeof(float), hipMemcpyDeviceToDevice, s));
+  return 0;
+}
+
+// VTCNN::backward (model/vit_cnn.hpp:215-242); gradients are written (not accumulated) into grads
+int gen_backward(GenModel *g, const float *arena, const vt_layout *lo, float *grads, const float *X, const int *labels, int n,
+                 int phase, hipStream_t s) {
+  const int P = g->P, C1 = g->C1, C2 = g->C2, L = g->L, D = g->D, K = g->K, Q = g->Q, CK = g->Ci * 9, hd = g->hd;
+  const long NP = (long)n * P, NL = (long)n * L;
+  auto W = [&](const char *name) { return arena + lo->t[vt_find(lo, name)].offset; };
+  auto G = [&](const char *name) { return grads + lo->t[vt_find(lo, name)].offset; };
+  const Gemm mm{g, s};
+  if (phase & 1) {
+    // softmax - onehot, fc (softmax_layer.hpp:29, dense_layer.hpp:92-99)
+    hipLaunchKernelGGL(k_dlogits, dim3((n * K + GT - 1) / GT), dim3(GT), 0, s, g->probs, labels, g->dlogits, n * K, K);
+    VT_CHECK_LAUNCH();
+    VTG(mm(true, false, Q, K, n, g->pooled, Q, g->dlogits, K, G("fc.W"), K));
+    VTG(col_sums(g, g->dlogits, n, K, G("fc.b"), s));
+    VTG(mm(false, true, n, Q, K, g->dlogits, K, W("fc.W"), K, g->dpool, Q));
+    // max-pool scatter + ReLU mask (pooling_layer.hpp:68-97, relu_layer.hpp:20-33)
+    hipLaunchKernelGGL(k_pool_bwd, dim3(nblk(NP * C2)), dim3(GT), 0, s, g->z, g->stat_pn, W("proj.norm.gamma"),
+                       W("proj.norm.beta"), g->dpool, g->pool_idx, g->du, NP * C2, C2, g->H, g->pk);
+    VT_CHECK_LAUNCH();
+    // ProjectorLayer::backward (projector_layer.hpp:118-214)
+    VTG(bn_backward(g, g->du, g->z, g->stat_pn, W("proj.norm.gamma"), NP, C2, G("proj.norm.gamma"), G("proj.norm.beta"),
+                    g->coef, g->dz, s));
+    VTG(mm(true, false, C1, C2, (int)NP, g->x, C1, g->dz, C2, G("proj.downsample.W"), C2));
+    VTG(col_sums(g, g->dz, NP, C2, G("proj.downsample.b"), s));
+    VTG(mm(false, true, (int)NP, C1, C2, g->dz, C2, W("proj.downsample.W"), C2, g->pdx, C1));
+    // delta of the attention map, softmax backward over tokens, deltas of q / k / v
+    VTG(mm(false, true, P, L, C2, g->dz, C2, g->v, C2, g->dsa, L, nullptr, false, 1.f, n, (long)P * C2, (long)L * C2,
+           (long)P * L));
+    VTG(mm(true, false, L, C2, P, g->pa, L, g->dz, C2, g->dv, C2, nullptr, false, 1.f, n, (long)P * L, (long)P * C2,
+           (long)L * C2));
+    hipLaunchKernelGGL(k_softmax_bwd_rows, dim3((unsigned)((NP + 3) / 4)), dim3(GT), 0, s, g->pa, g->dsa, NP, L);
+    VT_CHECK_LAUNCH();
+    VTG(mm(false, false, P, D, L, g->dsa, L, g->k, D, g->dq, D, nullptr, false, 1.f, n, (long)P * L, (long)L * D,
+           (long)P * D));
+    VTG(mm(true, false, L, D, P, g->dsa, L, g->q, D, g->dk, D, nullptr, false, 1.f, n, (long)P * L, (long)P * D,
+           (long)L * D));
+    VTG(mm(true, false, D, C2, (int)NL, g->o, D, g->dv, C2, G("proj.linear3.W"), C2));
+    VTG(col_sums(g, g->dv, NL, C2, G("proj.linear3.b"), s));
+    VTG(mm(false, true, (int)NL, D, C2, g->dv, C2, W("proj.linear3.W"), C2, g->pdt, D));
+    VTG(mm(true, false, D, D, (int)NL, g->o, D, g->dk, D, G("proj.linear2.W"), D));
+    VTG(mm(false, true, (int)NL, D, D, g->dk, D, W("proj.linear2.W"), D, g->pdt, D, nullptr, true));
+    VTG(mm(true, false, C1, D, (int)NP, g->x, C1, g->dq, D, G("proj.linear1.W"), D));
+    VTG(mm(false, true, (int)NP, C1, D, g->dq, D, W("proj.linear1.W"), D, g->pdx, C1, nullptr, true));
+    // TransformerLayer::backward with targets = projector token delta: seed = out - delta
+    // (visual_transformer.hpp:153-157, transformer_layer.hpp:133-207); no ReLU derivative (:174-181)
+    VTG(ewise(g->o, g->pdt, g->d0, NL * D, 1, s));
+    VTG(bn_backward(g, g->d0, g->s2, g->stat_n2, W("norm2.gamma"), NL, D, G("norm2.gamma"), G("norm2.beta"), g->coef, g->ds2,
+                    s));
+    VTG(mm(true, false, D, D, (int)NL, g->rl, D, g->ds2, D, G("ffn.linear2.W"), D));
+    VTG(col_sums(g, g->ds2, NL, D, G("ffn.linear2.b"), s));
+    VTG(mm(false, true, (int)NL, D, D, g->ds2, D, W("ffn.linear2.W"), D, g->dh, D));
+    VTG(mm(true, false, D, D, (int)NL, g->a, D, g->dh, D, G("ffn.linear1.W"), D));
+    VTG(col_sums(g, g->dh, NL, D, G("ffn.linear1.b"), s));
+    VTG(mm(false, true, (int)NL, D, D, g->dh, D, W("ffn.linear1.W"), D, g->da, D));
+    VTG(ewise(g->da, g->ds2, g->da, NL * D, 0, s));
+    VTG(bn_backward(g, g->da, g->tok, g->stat_n1, W("norm1.gamma"), NL, D, G("norm1.gamma"), G("norm1.beta"), g->coef, g->dr,
+                    s));
+    // the output projection's cached input is the zero concat: its gradient is zero
+    VTG(ewise(nullptr, nullptr, G("mha.o.W"), (long)D * D, 3, s));
+    // FilterTokenizer::backward2 (tokenizer.hpp:50-107): the softmax over pixels is differentiated over
+    // the token axis (:91); the tokenizer's own weights stay frozen (their gradients are never applied)
+    VTG(mm(false, true, (int)NL, C1, D, g->pdt, D, W("tok.linear2.W"), D, g->dT0, C1));
+    VTG(mm(false, true, P, L, C1, g->x, C1, g->dT0, C1, g->dsa, L, nullptr, false, 1.f, n, (long)P * C1, (long)L * C1,
+           (long)P * L));
+    hipLaunchKernelGGL(k_softmax_bwd_rows, dim3((unsigned)((NP + 3) / 4)), dim3(GT), 0, s, g->tokA, g->dsa, NP, L);
+    VT_CHECK_LAUNCH();
+    VTG(mm(false, false, P, C1, L, g->tokA, L, g->dT0, C1, g->tdx, C1, nullptr, false, 1.f, n, (long)P * L, (long)L * C1,
+           (long)P * C1));
+    VTG(mm(false, true, (int)NP, C1, L, g->dsa, L, W("tok.linear1.W"), L, g->tdx, C1, nullptr, true));
+    VTG(ewise(g->tdx, g->pdx, g->tdx, NP * C1, 0, s));
+    // BatchNorm2DLayer::backward + Conv2DLayer::backward gradients (batch_normalization_layer.hpp:300-327,
+    // conv2d_layer.hpp:115-147); the conv input delta is never consumed
+    VTG(bn_backward(g, g->tdx, g->conv, g->stat_bn, W("bn.gamma"), NP, C1, G("bn.gamma"), G("bn.beta"), g->coef, g->tdx, s));
+    VTG(mm(true, false, C1, CK, (int)NP, g->tdx, C1, g->col, CK, G("conv.W"), CK));
+    VTG(col_sums(g, g->tdx, NP, C1, G("conv.b"), s));
+  }
+  if (phase & 2) {
+    // MultiHeadAttention::backward (multi_head_attention.hpp:109-193): L groups of n consecutive token
+    // rows; scores = key . query^T * scale; only the q / k / v weight gradients leave this block
+    VTG(mm(false, true, (int)NL, D, D, g->dr, D, W("mha.o.W"), D, g->dc, D));
+    const float scale = 1.0f / sqrtf((float)hd);
+    const long sG = (long)n * hd, sS = (long)n * n;
+    for (int h = 0; h < g->heads; ++h) {
+      const std::string hs = std::to_string(h);
+      const std::string nq = "mha.q" + hs + ".W", nk = "mha.k" + hs + ".W", nv = "mha.v" + hs + ".W";
+      VTG(mm(false, false, (int)NL, hd, D, g->tok, D, W(nq.c_str()), hd, g->Qm, hd));
+      VTG(mm(false, false, (int)NL, hd, D, g->tok, D, W(nk.c_str()), hd, g->Km, hd));
+      VTG(mm(false, false, (int)NL, hd, D, g->tok, D, W(nv.c_str()), hd, g->Vm, hd));
+      VTG(mm(false, true, n, n, hd, g->Km, hd, g->Qm, hd, g->attn, n, nullptr, false, scale, L, sG, sG, sS));
+      hipLaunchKernelGGL(k_softmax_rows, dim3((unsigned)((NL + 3) / 4)), dim3(GT), 0, s, g->attn, NL, n);
+      VT_CHECK_LAUNCH();
+      const float *dhd = g->dc + h * hd;  // this head's columns of the concat delta, row stride D
+      VTG(mm(false, true, n, n, hd, dhd, D, g->Vm, hd, g->dat, n, nullptr, false, 1.f, L, (long)n * D, sG, sS));
+      VTG(mm(true, false, n, hd, n, g->attn, n, dhd, D, g->dV, hd, nullptr, false, 1.f, L, sS, (long)n * D, sG));
+      hipLaunchKernelGGL(k_softmax_bwd_rows, dim3((unsigned)((NL + 3) / 4)), dim3(GT), 0, s, g->attn, g->dat, NL, n);
+      VT_CHECK_LAUNCH();
+      VTG(mm(false, false, n, hd, n, g->dat, n, g->Qm, hd, g->dK, hd, nullptr, false, 1.f, L, sS, sG, sG));
+      VTG(mm(true, false, n, hd, n, g->dat, n, g->Km, hd, g->dQ, hd, nullptr, false, 1.f, L, sS, sG, sG));
+      VTG(mm(true, false, D, hd, (int)NL, g->tok, D, g->dK, hd, G(nk.c_str()), hd));
+      VTG(mm(true, false, D, hd, (int)NL, g->tok, D, g->dQ, hd, G(nq.c_str()), hd));
+      VTG(mm(true, false, D, hd, (int)NL, g->tok, D, g->dV, hd, G(nv.c_str()), hd));
+    }
+  }
+  (void)X;
+  return 0;
+}
+
+}  // namespace vt

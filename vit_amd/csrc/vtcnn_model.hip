@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "vtcnn_common.h"
+#include "vtcnn_generic.h"
 
 using namespace vt;
 
@@ -59,6 +60,9 @@ struct vt_model {
   std::vector<std::string> prof_names;
   size_t prof_used = 0;
 
+  // shapes outside the compiled headline kernels run the general, GEMM-based step instead
+  GenModel *gen = nullptr;
+
   float *P_(const char *name) { return arena + lo.t[vt_find(&lo, name)].offset; }
   float *G_(const char *name) { return grads + lo.t[vt_find(&lo, name)].offset; }
 };
@@ -90,9 +94,9 @@ extern "C" int vt_model_create(const vt_dims *dims, int max_batch, int device, f
   if (!dims || !out || max_batch < 1) return VT_EINVAL;
   vt_layout lo;
   if (vt_make_layout(dims, &lo) != 0) return VT_EINVAL;
-  if (dims->vt_channels != C2 || dims->tokens != L || dims->token_channels != D || dims->heads != HEADS ||
-      dims->input_dim * dims->input_dim > PPT * TPB || dims->num_classes > KMAX || dims->image_channels > 4)
-    return VT_EUNSUPPORTED;
+  const bool headline = dims->vt_channels == C2 && dims->tokens == L && dims->token_channels == D && dims->heads == HEADS &&
+                        dims->input_dim * dims->input_dim <= PPT * TPB && dims->num_classes <= KMAX &&
+                        dims->image_channels <= 4;
   HIPCHK(hipSetDevice(device));
   vt_model *m = new vt_model();
   m->d = *dims;
@@ -100,12 +104,31 @@ extern "C" int vt_model_create(const vt_dims *dims, int max_batch, int device, f
   m->maxN = max_batch;
   m->device = device;
   m->P = dims->input_dim * dims->input_dim;
-  m->Q = C2 * 196;
+  m->Q = dims->vt_channels * 196;
   m->K = dims->num_classes;
   const size_t N = max_batch, P = m->P, NL = N * L, Q = m->Q, K = m->K;
   int rc = 0;
   if (ext_arena) m->arena = ext_arena; else { rc |= dalloc(m, &m->arena, lo.n_total); m->own_arena = true; }
   if (ext_grads) m->grads = ext_grads; else { rc |= dalloc(m, &m->grads, lo.n_trainable); m->own_grads = true; }
+  if (!headline) {
+    m->gen = new GenModel();
+    auto alloc = [](void *ctx, float **p, size_t floats, const char *name) { return dalloc((vt_model *)ctx, p, floats, name); };
+    const int grc = rc ? VT_ENOMEM : gen_create(m->gen, dims, max_batch, alloc, m);
+    if (grc != 0) {
+      vt_model_destroy(m);
+      return grc;
+    }
+    m->probs = m->gen->probs;
+    rc |= dalloc(m, &m->loss_buf, 4);
+    if (rc != 0) {
+      vt_model_destroy(m);
+      return VT_ENOMEM;
+    }
+    (void)hipMemset(m->arena, 0, lo.n_total * sizeof(float));
+    (void)hipMemset(m->grads, 0, lo.n_trainable * sizeof(float));
+    *out = m;
+    return 0;
+  }
   rc |= dalloc(m, &m->conv, N * P * C1, "fwd.conv_out");
   rc |= dalloc(m, &m->tokstat, N * 2 * L, "fwd.tok_stat");
   rc |= dalloc(m, &m->tok, NL * D, "fwd.tok_out");
@@ -176,6 +199,7 @@ extern "C" int vt_model_destroy(vt_model *m) {
   if (m->gstream) (void)hipStreamDestroy(m->gstream);
   for (void *p : m->allocs) (void)hipFree(p);
   for (hipEvent_t e : m->prof_ev) (void)hipEventDestroy(e);
+  delete m->gen;
   delete m;
   return 0;
 }
@@ -635,6 +659,7 @@ extern "C" int vt_model_profile_read(vt_model *m, int idx, char *name_out, int n
 }
 extern "C" int vt_model_keep_internals(vt_model *m, int on) {
   if (!m) return VT_EINVAL;
+  if (m->gen) return 0;  // the general step stores both maps anyway
   if (on && !m->tokA) {
     HIPCHK(hipSetDevice(m->device));
     const size_t n = (size_t)m->maxN * m->P * L;
@@ -657,6 +682,14 @@ extern "C" int vt_model_set_training(vt_model *m, int training) {
 static int forward_impl(vt_model *m, const float *d_images, int n, int group, float *d_probs, vt_stream s) {
   if (!m || !d_images || n < 1 || n > m->maxN) return VT_EINVAL;
   if (group > 0 && (m->training || group % 4 != 0)) return VT_EUNSUPPORTED;
+  if (m->gen) {
+    if (group > 0) return VT_EUNSUPPORTED;
+    m->lastN = n;
+    m->last_images = d_images;
+    m->last_grouped = false;
+    STEP("generic_forward", gen_forward(m->gen, m->arena, &m->lo, m->arena, d_images, n, m->training, d_probs, (hipStream_t)s));
+    return 0;
+  }
   if (group >= n) group = 0;
   const int H = m->d.input_dim, P = m->P, Ci = m->d.image_channels, K = m->K;
   const long NL = (long)n * L;
@@ -718,8 +751,10 @@ extern "C" int vt_model_forward_grouped(vt_model *m, const float *d_images, int 
 // every weight-gradient slab reduction requested inside a scope is queued and runs as one launch at flush
 struct BatchScope {
   ReduceBatch b;
-  BatchScope() { reduce_batch_begin(&b); }
-  ~BatchScope() { reduce_batch_abandon(); }
+  bool on;
+  // the general step reuses one partial buffer between reductions, so its reductions run at once
+  explicit BatchScope(const vt_model *m) : on(m->gen == nullptr) { if (on) reduce_batch_begin(&b); }
+  ~BatchScope() { if (on) reduce_batch_abandon(); }
 };
 
 // Backward of everything except the attention block: head, projector, feed-forward half of the
@@ -727,6 +762,10 @@ struct BatchScope {
 // transformer's input delta (transformer_bwd_a) and the projector's input delta, so it runs here
 // and the attention block, which nothing else waits for, closes the step.
 static int backward_main(vt_model *m, const int *d_labels, vt_stream s) {
+  if (m->gen) {
+    STEP("generic_backward", gen_backward(m->gen, m->arena, &m->lo, m->grads, m->last_images, d_labels, m->lastN, 1, (hipStream_t)s));
+    return 0;
+  }
   const int n = m->lastN, H = m->d.input_dim, P = m->P, Ci = m->d.image_channels, K = m->K, Q = m->Q;
   const long NL = (long)n * L;
   const int nrb = (int)((NL + RB - 1) / RB);
@@ -769,6 +808,11 @@ static int backward_main(vt_model *m, const int *d_labels, vt_stream s) {
 // Backward of the attention block (MultiHeadAttention::backward's q/k/v weight gradients): reads the
 // delta of the first residual (transformer_bwd_b) and writes only the mha.q*/k*/v* gradients.
 static int backward_attention(vt_model *m, float *g_out, vt_stream s) {
+  if (m->gen) {
+    if (g_out) return VT_EUNSUPPORTED;
+    STEP("generic_backward_attention", gen_backward(m->gen, m->arena, &m->lo, m->grads, m->last_images, nullptr, m->lastN, 2, (hipStream_t)s));
+    return 0;
+  }
   const int n = m->lastN;
   const long NL = (long)n * L;
   STEP("transformer_bwd_c", vt_transformer_bwd_c(m->da, m->coef_n1, m->P_("mha.o.W"), m->tok, m->P_("mha.q0.W"), m->dr, m->dc, m->qkv, NL, s));
@@ -781,28 +825,28 @@ static bool backward_ready(const vt_model *m) { return m && m->lastN >= 1 && m->
 
 extern "C" int vt_model_backward(vt_model *m, const int *d_labels, vt_stream s) {
   if (!backward_ready(m) || !d_labels) return VT_EINVAL;
-  BatchScope batch;
+  BatchScope batch(m);
   VTCHK(backward_main(m, d_labels, s));
   VTCHK(backward_attention(m, nullptr, s));
-  STEP("reduce_rows", reduce_batch_flush((hipStream_t)s));
+  if (batch.on) STEP("reduce_rows", reduce_batch_flush((hipStream_t)s));
   m->attention_pending = false;
   return 0;
 }
 
 extern "C" int vt_model_backward_main(vt_model *m, const int *d_labels, vt_stream s) {
   if (!backward_ready(m) || !d_labels) return VT_EINVAL;
-  BatchScope batch;
+  BatchScope batch(m);
   VTCHK(backward_main(m, d_labels, s));
-  STEP("reduce_rows", reduce_batch_flush((hipStream_t)s));
+  if (batch.on) STEP("reduce_rows", reduce_batch_flush((hipStream_t)s));
   m->attention_pending = true;
   return 0;
 }
 
 extern "C" int vt_model_backward_attention(vt_model *m, float *d_grads_out, vt_stream s) {
   if (!backward_ready(m) || !m->attention_pending) return VT_EINVAL;
-  BatchScope batch;
+  BatchScope batch(m);
   VTCHK(backward_attention(m, d_grads_out, s));
-  STEP("reduce_rows", reduce_batch_flush((hipStream_t)s));
+  if (batch.on) STEP("reduce_rows", reduce_batch_flush((hipStream_t)s));
   m->attention_pending = false;
   return 0;
 }
