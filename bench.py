@@ -37,7 +37,7 @@ def attention_bwd_flops(d, batch):
     return 5 * 2 * batch * batch * hd * d.heads * d.tokens
 
 
-def algorithmic_bytes_per_image(d, forward_only=False):
+def algorithmic_bytes_per_image(d, forward_only=False, generic=False):
     """Layer-boundary fp32 traffic per image apportioned to the launcher that performs it.
     Each tensor that crosses a top-level reference Layer interface counts once per write and once
     per read; tensors internal to a composite layer and parameters do not count.  The sum over
@@ -57,13 +57,22 @@ def algorithmic_bytes_per_image(d, forward_only=False):
         "tokenizer_bwd": 4 * C1 * P + L * D,
         "conv3x3_wgrad": 3 * C1 * P + Ci * P,
     }
+    fwd_total = 4 * (Ci * P + 5 * C1 * P + 2 * C2 * P + 2 * Q + 4 * L * D + 3 * K)
+    if generic:  # the general-shape step is profiled as two launchers: the whole forward, the whole backward
+        total = 4 * (2 * Ci * P + 14 * C1 * P + 5 * C2 * P + 4 * Q + 11 * L * D + 5 * K)
+        return {"generic_forward": fwd_total, "generic_backward": total - fwd_total}, (fwd_total if forward_only else total)
     t = {k: 4 * v for k, v in t.items()}
     total = 4 * (2 * Ci * P + 14 * C1 * P + 5 * C2 * P + 4 * Q + 11 * L * D + 5 * K)
     assert sum(t.values()) == total, (sum(t.values()), total)
-    fwd_total = 4 * (Ci * P + 5 * C1 * P + 2 * C2 * P + 2 * Q + 4 * L * D + 3 * K)
     assert sum(v for k, v in t.items() if k.endswith("_fwd")) == fwd_total
     return t, (fwd_total if forward_only else total)
 
+
+SHAPES = {  # hyper-parameters besides the class count
+    "blood": dict(image_channels=1, input_dim=28, tokens=16, token_channels=32, vt_channels=16, heads=2),
+    "scaled": dict(image_channels=3, input_dim=224, tokens=16, token_channels=64, vt_channels=128, heads=8),
+    "wide": dict(image_channels=3, input_dim=224, tokens=196, token_channels=512, vt_channels=128, heads=8),
+}
 
 LAUNCHER_KERNEL = {  # launcher name (vt_model_profile) -> device kernel it launches
     "conv3x3_fwd": "k_conv_fwd", "tokenizer_fwd": "k_tokenizer_fwd", "transformer_ffn_fwd": "k_tr_ffn_fwd",
@@ -130,6 +139,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=1024, help="images per mini-batch per GPU")
     ap.add_argument("--classes", type=int, default=8)
+    ap.add_argument("--shape", choices=tuple(SHAPES), default="blood",
+                    help="blood: the headline 1x28x28 shape; scaled / wide: the 224x224x3 shapes (general-shape step)")
     ap.add_argument("--mode", choices=("train", "predict"), default="train",
                     help="train: the headline metric; predict: forward-only images/sec (eval mode)")
     ap.add_argument("--group", type=int, default=0,
@@ -160,12 +171,13 @@ def main():
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local))
 
     from vit_amd import VTCNN, Dims
-    dims = Dims(num_classes=a.classes)
+    dims = Dims(num_classes=a.classes, **SHAPES[a.shape])
+    generic = a.shape != "blood"
     B = a.batch
     m = VTCNN(dims, max_batch=B, seed=42)
     nb = 4  # resident mini-batches cycled through
     rng = np.random.default_rng(123 + rank)
-    xs = torch.from_numpy(rng.integers(0, 256, size=(nb, B, 1, 28, 28)).astype(np.float32) / np.float32(255.0)).cuda()
+    xs = torch.from_numpy(rng.integers(0, 256, size=(nb, B, dims.image_channels, dims.input_dim, dims.input_dim), dtype=np.uint8).astype(np.float32) / np.float32(255.0)).cuda()
     ys = torch.from_numpy(rng.integers(0, a.classes, size=(nb, B)).astype(np.int32)).cuda()
     from vit_amd.parallel import DataParallel
     # world 1: plain forward / backward / SGD; world > 1: one blocking all-reduce of the gradient arena
@@ -215,7 +227,7 @@ def main():
     sync()
     breakdown = m.profile_read()
     per_launch_ms = {k: v[0] / v[1] for k, v in breakdown.items()}
-    tbl, total_bytes = algorithmic_bytes_per_image(dims, a.mode == "predict")
+    tbl, total_bytes = algorithmic_bytes_per_image(dims, a.mode == "predict", generic)
     candidates = {k: v for k, v in breakdown.items() if k in tbl or k == "mha_bwd_rows"}
     dominant = a.kernel or (max(candidates, key=lambda k: candidates[k][0]) if candidates else "projector_bwd")
     m.profile(dominant)
@@ -256,12 +268,14 @@ def main():
                     "algorithmic_bytes_per_launch": tbl.get(dominant, 0) * B,
                     "avg_launch_us": None if not k_cnt else round(avg_s * 1e6, 2), "launches_timed": k_cnt}
         res = {
-            "metric": ("train" if a.mode == "train" else "predict") + " images/sec (whole node) VTCNN BloodMNIST", "value": round(value, 1), "unit": "images/sec",
+            "metric": ("train" if a.mode == "train" else "predict") + " images/sec (whole node) VTCNN " + {"blood": "BloodMNIST"}.get(a.shape, a.shape), "value": round(value, 1), "unit": "images/sec",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("VTCNN train step (forward+backward+SGD)" if a.mode == "train" else
-                                    "VTCNN predict step (eval-mode forward)") + ", BloodMNIST shape 1x28x28, %d classes, "
-                                   "mini-batch %d per GPU, fp32, seed-42 reference init" % (a.classes, B),
+                                    "VTCNN predict step (eval-mode forward)") + ", %s shape %dx%dx%d, %d classes, "
+                                   "mini-batch %d per GPU, fp32, seed-42 reference init" % (
+                                       {"blood": "BloodMNIST"}.get(a.shape, a.shape), dims.image_channels, dims.input_dim,
+                                       dims.input_dim, a.classes, B),
                        "hip_graph": bool(use_graph), "statistics_group": a.group if a.mode == "predict" else 0, "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world,
                        "exchange_overlapped": bool(dp.overlap and a.mode == "train" and not use_graph),
                        "grad_allreduce_floats": int(m.layout.n_trainable) if world > 1 else 0},
@@ -270,7 +284,7 @@ def main():
             "algorithmic_bytes_per_image": total_bytes,
             "launcher_us": {k: round(1e3 * v, 2) for k, v in sorted(per_launch_ms.items(), key=lambda kv: -kv[1])},
         }
-        if world == 1 and not a.no_cpu_baseline and a.mode == "train":
+        if world == 1 and not a.no_cpu_baseline and a.mode == "train" and not generic:
             res["cpu_baseline"] = cpu_baseline(B, a.classes)
         print(json.dumps(res), flush=True)
     if dist is not None:

@@ -26,11 +26,58 @@ struct GemmP {
   int M, N, K, lda, ldb, ldc;
   long sA, sB, sC;
   float alpha;
-  int accumulate, ksplit, kchunk, batch;
+  int accumulate, ksplit, kchunk, batch, vecA, vecB;
   float *part;  // [ksplit][batch][M*N] when ksplit > 1
 };
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// One operand tile (64 rows of the M or N side x 16 of K) from global memory into four registers per
+// thread.  `along_k`: the K index is the contiguous one in memory (A not transposed / B transposed).
+// Vector form (one 16-byte load) when the host found the operand aligned and its sizes multiples of 4.
+template <bool ALONG_K>
+__device__ __forceinline__ void load_tile(const float *__restrict__ base, int ld, int r0, int rows, int k0, int kend,
+                                          bool vec, int tid, float (&reg)[4]) {
+  if (vec) {
+    int r, k;
+    if (ALONG_K) { r = tid >> 2; k = (tid & 3) * 4; } else { k = tid >> 4; r = (tid & 15) * 4; }
+    const int gr = r0 + r, gk = k0 + k;
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (gr < rows && gk < kend)
+      t = *reinterpret_cast<const float4 *>(base + (ALONG_K ? (long)gr * ld + gk : (long)gk * ld + gr));
+    reg[0] = t.x; reg[1] = t.y; reg[2] = t.z; reg[3] = t.w;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int idx = tid + e * 256;
+      int r, k;
+      if (ALONG_K) { k = idx & (GBK - 1); r = idx >> 4; } else { r = idx & 63; k = idx >> 6; }
+      const int gr = r0 + r, gk = k0 + k;
+      reg[e] = (gr < rows && gk < kend) ? base[ALONG_K ? (long)gr * ld + gk : (long)gk * ld + gr] : 0.f;
+    }
+  }
+}
+// registers -> LDS tile [k][row]
+template <bool ALONG_K>
+__device__ __forceinline__ void store_tile(float (*T)[GBM + GPAD], bool vec, int tid, const float (&reg)[4]) {
+  if (vec) {
+    if (ALONG_K) {
+      const int r = tid >> 2, k = (tid & 3) * 4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) T[k + e][r] = reg[e];
+    } else {
+      const int k = tid >> 4, r = (tid & 15) * 4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) T[k][r + e] = reg[e];
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int idx = tid + e * 256;
+      if (ALONG_K) T[idx & (GBK - 1)][idx >> 4] = reg[e]; else T[idx >> 6][idx & 63] = reg[e];
+    }
+  }
+}
 
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256) void k_gemm(GemmP p) {
@@ -43,38 +90,26 @@ __global__ __launch_bounds__(256) void k_gemm(GemmP p) {
   const float *__restrict__ A = p.A + (long)b * p.sA;
   const float *__restrict__ B = p.B + (long)b * p.sB;
   const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+  const bool vecA = p.vecA != 0, vecB = p.vecB != 0;
   f32x4 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  // the next K step's tiles travel from memory while the matrix cores work on the current one
+  float ra[4], rb[4];
+  load_tile<!TA>(A, p.lda, m0, p.M, kbeg, kend, vecA, tid, ra);
+  load_tile<TB>(B, p.ldb, n0, p.N, kbeg, kend, vecB, tid, rb);
   for (int k0 = kbeg; k0 < kend; k0 += GBK) {
-    float ra[4], rb[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int idx = tid + e * 256;
-      int m, k;
-      if (TA) { m = idx & (GBM - 1); k = idx >> 6; } else { k = idx & (GBK - 1); m = idx >> 4; }
-      const int gm = m0 + m, gk = k0 + k;
-      const bool ok = gm < p.M && gk < kend;
-      const long off = TA ? (long)gk * p.lda + gm : (long)gm * p.lda + gk;
-      ra[e] = ok ? A[off] : 0.f;
-      int n, kb;
-      if (TB) { kb = idx & (GBK - 1); n = idx >> 4; } else { n = idx & (GBN - 1); kb = idx >> 6; }
-      const int gn = n0 + n, gkb = k0 + kb;
-      const bool okb = gn < p.N && gkb < kend;
-      const long offb = TB ? (long)gn * p.ldb + gkb : (long)gkb * p.ldb + gn;
-      rb[e] = okb ? B[offb] : 0.f;
-    }
     __syncthreads();  // the previous step's tile reads are over
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int idx = tid + e * 256;
-      if (TA) As[idx >> 6][idx & (GBM - 1)] = ra[e]; else As[idx & (GBK - 1)][idx >> 4] = ra[e];
-      if (TB) Bs[idx & (GBK - 1)][idx >> 4] = rb[e]; else Bs[idx >> 6][idx & (GBN - 1)] = rb[e];
-    }
+    store_tile<!TA>(As, vecA, tid, ra);
+    store_tile<TB>(Bs, vecB, tid, rb);
     __syncthreads();
+    if (k0 + GBK < kend) {
+      load_tile<!TA>(A, p.lda, m0, p.M, k0 + GBK, kend, vecA, tid, ra);
+      load_tile<TB>(B, p.ldb, n0, p.N, k0 + GBK, kend, vecB, tid, rb);
+    }
 #pragma unroll
     for (int kk = 0; kk < GBK; kk += 4) {
       const int kr = kk + (lane >> 4), c = lane & 15;
@@ -132,12 +167,20 @@ extern "C" int vt_gemm_f32(int transA, int transB, int M, int N, int K, float al
                            const float *bias, int batch, float *workspace, long workspace_floats, vt_stream s) {
   if (M < 1 || N < 1 || K < 1 || batch < 1 || !A || !B || !C) return VT_EINVAL;
   if (lda < (transA ? M : K) || ldb < (transB ? K : N) || ldc < N) return VT_EINVAL;
-  GemmP p{A, B, C, bias, M, N, K, lda, ldb, ldc, strideA, strideB, strideC, alpha, accumulate ? 1 : 0, 1, K, batch, nullptr};
+  GemmP p{A, B, C, bias, M, N, K, lda, ldb, ldc, strideA, strideB, strideC, alpha, accumulate ? 1 : 0, 1, K, batch, 0, 0, nullptr};
+  // 16-byte loads need the contiguous extent and the leading dimension in multiples of 4 floats, the
+  // batch strides too, and a 16-byte aligned base; K slices are multiples of 16, so with K % 4 == 0 no
+  // vector straddles a slice end
+  auto aligned = [](const float *q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  p.vecA = aligned(A) && lda % 4 == 0 && strideA % 4 == 0 && (transA ? M % 4 == 0 : K % 4 == 0);
+  p.vecB = aligned(B) && ldb % 4 == 0 && strideB % 4 == 0 && (transB ? K % 4 == 0 : N % 4 == 0);
   const long tiles = (long)((M + GBM - 1) / GBM) * ((N + GBN - 1) / GBN) * batch;
-  // a long contraction over few output tiles: slice K so that about 1024 workgroups exist
-  if (workspace && K >= 4096 && tiles < 256) {
+  // a contraction that is long for the few output tiles it feeds: slice K so that several hundred
+  // workgroups exist (a lone workgroup walking 1024 rows costs 50 us of pure latency)
+  if (workspace && K >= 256 && tiles < 256) {
     long want = (1024 + tiles - 1) / tiles;
-    want = want < (K + 511) / 512 ? want : (K + 511) / 512;
+    const long most = K >= 4096 ? (K + 511) / 512 : K / 64;
+    want = want < most ? want : most;
     const long fit = workspace_floats / ((long)M * N * batch);
     if (want > fit) want = fit;
     if (want > 1) {

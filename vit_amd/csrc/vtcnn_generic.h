@@ -16,7 +16,7 @@ struct GenModel {
   // forward
   float *col, *conv, *x, *tokA, *T0, *tok, *a, *hdn, *rl, *s2, *o, *q, *k, *v, *pa, *z, *pooled, *logits, *probs;
   int *pool_idx;
-  float *stat_bn, *stat_n1, *stat_n2, *stat_pn, *coef, *part, *ws;
+  float *stat_bn, *stat_n1, *stat_n2, *stat_pn, *coef, *part, *ws, *spx;
   long part_floats, ws_floats;
   // backward
   float *dlogits, *dpool, *du, *dz, *pdx, *dsa, *dq, *dv, *dk, *pdt, *d0, *ds2, *dh, *da, *dr, *dc;

@@ -21,12 +21,47 @@ namespace vt {
 
 constexpr int GT = 256;  // threads per workgroup of the row-matrix kernels
 
-// column-tile geometry shared by the column-wise kernels: `cw` columns (16, 32 or 64) side by
-// side, GT / cw row lanes; a block covers rows [blockIdx.x * rpb, ...) and loops over column tiles
-static int col_width(int C) { return C <= 16 ? 16 : (C <= 32 ? 32 : 64); }
+// Geometry of the column-wise kernels over a row matrix [R, C]: a thread owns VEC adjacent columns
+// (4 when C is a multiple of 4: one 16-byte access per row) and walks down the rows, so per-column
+// parameters stay in registers and no index is ever divided.  tx = column group, ty = row lane.
+struct ColGeo {
+  int vec, groups, tx_n, ty_n;  // groups = C / vec column groups; tx_n = min(groups, GT); ty_n = GT / tx_n row lanes
+};
+static ColGeo col_geo(int C) {
+  ColGeo g;
+  g.vec = (C % 4 == 0) ? 4 : 1;
+  g.groups = C / g.vec;
+  g.tx_n = g.groups < GT ? g.groups : GT;
+  g.ty_n = GT / g.tx_n;
+  return g;
+}
+
+template <int VEC>
+struct Vecf {
+  float v[VEC];
+};
+template <int VEC>
+__device__ __forceinline__ Vecf<VEC> ldv(const float *p) {
+  Vecf<VEC> r;
+  if (VEC == 4) {
+    const float4 t = *reinterpret_cast<const float4 *>(p);
+    r.v[0] = t.x; r.v[1] = t.y; r.v[VEC - 2] = t.z; r.v[VEC - 1] = t.w;
+  } else {
+    r.v[0] = *p;
+  }
+  return r;
+}
+template <int VEC>
+__device__ __forceinline__ void stv(float *p, const Vecf<VEC> &r) {
+  if (VEC == 4)
+    *reinterpret_cast<float4 *>(p) = make_float4(r.v[0], r.v[1], r.v[VEC - 2], r.v[VEC - 1]);
+  else
+    *p = r.v[0];
+}
 
 // ---- im2col for the 3x3, stride 1, pad 1 convolution (layers/conv2d_layer.hpp:35-87) ----------
-// col[(n*P + p)][ci*9 + kh*3 + kw] = X[n][ci][h+kh-1][w+kw-1] (0 outside the image)
+// col[(n*P + p)][ci*9 + kh*3 + kw] = X[n][ci][h+kh-1][w+kw-1] (0 outside the image); one thread per
+// element of col, so that the writes are contiguous
 __global__ __launch_bounds__(GT) void k_im2col(const float *__restrict__ X, float *__restrict__ col, long total, int Ci,
                                                int H, int W) {
   const int CK = Ci * 9;
@@ -43,102 +78,147 @@ __global__ __launch_bounds__(GT) void k_im2col(const float *__restrict__ X, floa
 
 // ---- per-column partial statistics of a row matrix: part[b][0][c] = sum, part[b][1][c] = sum of
 // squared distances from the block's own mean (merged by vt_bn_stats_finalize) ---------------------
-__global__ __launch_bounds__(GT) void k_colstats(const float *__restrict__ in, long R, int C, int rpb, int cw,
+template <int VEC>
+__global__ __launch_bounds__(GT) void k_colstats(const float *__restrict__ in, long R, int C, int rpb, ColGeo geo,
                                                  float *__restrict__ part) {
-  __shared__ float sh[GT];
-  __shared__ float mean_s[64];
-  const int cl = threadIdx.x % cw, rl = threadIdx.x / cw, nrl = GT / cw;
+  __shared__ float sh[GT * VEC];
+  const int tx = threadIdx.x % geo.tx_n, ty = threadIdx.x / geo.tx_n;
   const long r0 = (long)blockIdx.x * rpb, r1 = r0 + rpb < R ? r0 + rpb : R;
-  for (int c0 = 0; c0 < C; c0 += cw) {
-    const int c = c0 + cl;
-    float s = 0.f;
-    if (c < C)
-      for (long r = r0 + rl; r < r1; r += nrl) s += in[r * C + c];
-    sh[threadIdx.x] = s;
+  const float inv_cnt = 1.0f / (float)(r1 - r0);
+  const bool lane_on = ty < geo.ty_n;
+  for (int g0 = 0; g0 < geo.groups; g0 += geo.tx_n) {
+    const int grp = g0 + tx;
+    const bool on = lane_on && grp < geo.groups;
+    const float *__restrict__ base = in + (size_t)grp * VEC;
+    float s[VEC], q[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) s[e] = q[e] = 0.f;
+    if (on)
+      for (long r = r0 + ty; r < r1; r += geo.ty_n) {
+        const Vecf<VEC> x = ldv<VEC>(base + r * C);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) s[e] += x.v[e];
+      }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) sh[threadIdx.x * VEC + e] = s[e];
     __syncthreads();
-    if (rl == 0) {
+    float mu[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {  // every thread of a column group forms the group's block sum
       float t = 0.f;
-      for (int k = 0; k < nrl; ++k) t += sh[k * cw + cl];
-      if (c < C) part[(size_t)blockIdx.x * 2 * C + c] = t;
-      mean_s[cl] = t / (float)(r1 - r0);
+      for (int k = 0; k < geo.ty_n; ++k) t += sh[(k * geo.tx_n + tx) * VEC + e];
+      s[e] = t;
+      mu[e] = t * inv_cnt;
     }
     __syncthreads();
-    const float mu = mean_s[cl];
-    float q = 0.f;
-    if (c < C)
-      for (long r = r0 + rl; r < r1; r += nrl) {
-        const float d = in[r * C + c] - mu;
-        q += d * d;
+    if (on)
+      for (long r = r0 + ty; r < r1; r += geo.ty_n) {
+        const Vecf<VEC> x = ldv<VEC>(base + r * C);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const float d = x.v[e] - mu[e];
+          q[e] += d * d;
+        }
       }
-    sh[threadIdx.x] = q;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) sh[threadIdx.x * VEC + e] = q[e];
     __syncthreads();
-    if (rl == 0 && c < C) {
-      float t = 0.f;
-      for (int k = 0; k < nrl; ++k) t += sh[k * cw + cl];
-      part[(size_t)blockIdx.x * 2 * C + C + c] = t;
+    if (on && ty == 0) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        float t = 0.f;
+        for (int k = 0; k < geo.ty_n; ++k) t += sh[(k * geo.tx_n + tx) * VEC + e];
+        part[(size_t)blockIdx.x * 2 * C + grp * VEC + e] = s[e];
+        part[(size_t)blockIdx.x * 2 * C + C + grp * VEC + e] = t;
+      }
     }
     __syncthreads();
   }
 }
 
-// ---- BatchNorm apply: out = (in - mean) * inv * gamma + beta (optionally ReLU) -------------------
-__global__ __launch_bounds__(GT) void k_bn_apply(const float *__restrict__ in, const float *__restrict__ stat,
-                                                 const float *__restrict__ g, const float *__restrict__ b,
-                                                 float *__restrict__ out, long total, int C, int relu) {
-  for (long i = (long)blockIdx.x * GT + threadIdx.x; i < total; i += (long)gridDim.x * GT) {
-    const int c = (int)(i % C);
-    float y = (in[i] - stat[c]) * stat[C + c] * g[c] + b[c];
-    if (relu) y = fmaxf(y, 0.f);
-    out[i] = y;
+// ---- out = (in - mean) * inv * gamma + beta  (MODE 0, BatchNorm apply; p = stat, q = gamma, r = beta)
+//      out = in * scale + shift               (MODE 1, BatchNorm backward apply; p = coef) -----------
+template <int VEC, int MODE>
+__global__ __launch_bounds__(GT) void k_colaffine(const float *__restrict__ in, const float *__restrict__ p,
+                                                  const float *__restrict__ q, const float *__restrict__ rr,
+                                                  float *__restrict__ out, long R, int C, int rpb, ColGeo geo) {
+  const int tx = threadIdx.x % geo.tx_n, ty = threadIdx.x / geo.tx_n;
+  if (ty >= geo.ty_n) return;
+  const long r0 = (long)blockIdx.x * rpb, r1 = r0 + rpb < R ? r0 + rpb : R;
+  for (int grp = tx; grp < geo.groups; grp += geo.tx_n) {
+    float a[VEC], b[VEC], g[VEC], be[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const int c = grp * VEC + e;
+      a[e] = p[c];
+      b[e] = p[C + c];
+      g[e] = MODE == 0 ? q[c] : 0.f;
+      be[e] = MODE == 0 ? rr[c] : 0.f;
+    }
+    for (long r = r0 + ty; r < r1; r += geo.ty_n) {
+      Vecf<VEC> x = ldv<VEC>(in + r * C + (size_t)grp * VEC);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) x.v[e] = MODE == 0 ? (x.v[e] - a[e]) * b[e] * g[e] + be[e] : x.v[e] * a[e] + b[e];
+      stv<VEC>(out + r * C + (size_t)grp * VEC, x);
+    }
   }
 }
 
 // ---- BatchNorm backward partial sums: part[b][0][c] = sum delta, part[b][1][c] = sum delta*xhat --
-// (batch_normalization_layer.hpp:187-188, 316-317); also used, with stat == NULL, for plain column
-// sums (bias gradients), where only part[b][0][c] is meaningful
+// (batch_normalization_layer.hpp:187-188, 316-317); with stat == NULL plain column sums (bias
+// gradients), where only part[b][0][c] is meaningful
+template <int VEC>
 __global__ __launch_bounds__(GT) void k_bnbwd_partial(const float *__restrict__ delta, const float *__restrict__ in,
-                                                      const float *__restrict__ stat, long R, int C, int rpb, int cw,
+                                                      const float *__restrict__ stat, long R, int C, int rpb, ColGeo geo,
                                                       float *__restrict__ part) {
-  __shared__ float sh[2][GT];
-  const int cl = threadIdx.x % cw, rl = threadIdx.x / cw, nrl = GT / cw;
+  __shared__ float sh[2][GT * VEC];
+  const int tx = threadIdx.x % geo.tx_n, ty = threadIdx.x / geo.tx_n;
   const long r0 = (long)blockIdx.x * rpb, r1 = r0 + rpb < R ? r0 + rpb : R;
-  for (int c0 = 0; c0 < C; c0 += cw) {
-    const int c = c0 + cl;
-    float s1 = 0.f, s2 = 0.f;
-    if (c < C) {
-      const float mu = stat ? stat[c] : 0.f, iv = stat ? stat[C + c] : 0.f;
-      for (long r = r0 + rl; r < r1; r += nrl) {
-        const float d = delta[r * C + c];
-        s1 += d;
-        if (stat) s2 += d * ((in[r * C + c] - mu) * iv);
-      }
+  const bool lane_on = ty < geo.ty_n;
+  for (int g0 = 0; g0 < geo.groups; g0 += geo.tx_n) {
+    const int grp = g0 + tx;
+    const bool on = lane_on && grp < geo.groups;
+    float s1[VEC], s2[VEC], mu[VEC], iv[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      s1[e] = s2[e] = 0.f;
+      mu[e] = (on && stat) ? stat[grp * VEC + e] : 0.f;
+      iv[e] = (on && stat) ? stat[C + grp * VEC + e] : 0.f;
     }
-    sh[0][threadIdx.x] = s1;
-    sh[1][threadIdx.x] = s2;
-    __syncthreads();
-    if (rl == 0 && c < C) {
-      float t1 = 0.f, t2 = 0.f;
-      for (int k = 0; k < nrl; ++k) {
-        t1 += sh[0][k * cw + cl];
-        t2 += sh[1][k * cw + cl];
+    if (on)
+      for (long r = r0 + ty; r < r1; r += geo.ty_n) {
+        const Vecf<VEC> d = ldv<VEC>(delta + r * C + (size_t)grp * VEC);
+        if (stat) {
+          const Vecf<VEC> x = ldv<VEC>(in + r * C + (size_t)grp * VEC);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) s2[e] += d.v[e] * ((x.v[e] - mu[e]) * iv[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) s1[e] += d.v[e];
       }
-      part[(size_t)blockIdx.x * 2 * C + c] = t1;
-      part[(size_t)blockIdx.x * 2 * C + C + c] = t2;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      sh[0][threadIdx.x * VEC + e] = s1[e];
+      sh[1][threadIdx.x * VEC + e] = s2[e];
+    }
+    __syncthreads();
+    if (on && ty == 0) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        float t1 = 0.f, t2 = 0.f;
+        for (int k = 0; k < geo.ty_n; ++k) {
+          t1 += sh[0][(k * geo.tx_n + tx) * VEC + e];
+          t2 += sh[1][(k * geo.tx_n + tx) * VEC + e];
+        }
+        part[(size_t)blockIdx.x * 2 * C + grp * VEC + e] = t1;
+        part[(size_t)blockIdx.x * 2 * C + C + grp * VEC + e] = t2;
+      }
     }
     __syncthreads();
   }
 }
 
-// delta_in = delta * scale[c] + shift[c] (coef from vt_bn_bwd_finalize)
-__global__ __launch_bounds__(GT) void k_scale_shift(const float *__restrict__ d, const float *__restrict__ coef,
-                                                    float *__restrict__ out, long total, int C) {
-  for (long i = (long)blockIdx.x * GT + threadIdx.x; i < total; i += (long)gridDim.x * GT) {
-    const int c = (int)(i % C);
-    out[i] = d[i] * coef[c] + coef[C + c];
-  }
-}
-
-// ---- elementwise: out = a + b (op 0), a - b (1), max(a, 0) (2), fill with b-less constant 0 (3) --
+// ---- elementwise: out = a + b (op 0), a - b (1), max(a, 0) (2), 0 (3) -------------------------------
 __global__ __launch_bounds__(GT) void k_ewise(const float *__restrict__ a, const float *__restrict__ b,
                                               float *__restrict__ out, long total, int op) {
   for (long i = (long)blockIdx.x * GT + threadIdx.x; i < total; i += (long)gridDim.x * GT) {
@@ -154,45 +234,99 @@ __global__ __launch_bounds__(GT) void k_ewise(const float *__restrict__ a, const
 }
 
 // ---- softmax over the pixel axis of S[n][p][l], per (n, l) (tokenizer.hpp:36, Tensor::softmax over
-// dim 1, tensor_cpu.hpp:894-944); in place ------------------------------------------------------------
-__global__ __launch_bounds__(GT) void k_softmax_pixels(float *__restrict__ S, int P, int Lt, int cw) {
-  __shared__ float sh[GT];
-  __shared__ float bc[64];
-  const int cl = threadIdx.x % cw, rl = threadIdx.x / cw, nrl = GT / cw;
-  const int l = blockIdx.x * cw + cl;
-  float *__restrict__ base = S + (size_t)blockIdx.y * P * Lt;
-  const bool on = l < Lt;
-  float mx = -INFINITY;
-  if (on)
-    for (int p = rl; p < P; p += nrl) mx = fmaxf(mx, base[(size_t)p * Lt + l]);
-  sh[threadIdx.x] = mx;
-  __syncthreads();
-  if (rl == 0) {
-    float t = -INFINITY;
-    for (int k = 0; k < nrl; ++k) t = fmaxf(t, sh[k * cw + cl]);
-    bc[cl] = t;
-  }
-  __syncthreads();
-  mx = bc[cl];
-  float s = 0.f;
-  if (on)
-    for (int p = rl; p < P; p += nrl) {
-      const float e = expf(base[(size_t)p * Lt + l] - mx);
-      base[(size_t)p * Lt + l] = e;
-      s += e;
+// dim 1, tensor_cpu.hpp:894-944), in place, in two launches over pixel chunks: per-chunk (max, sum of
+// exp relative to it), then each workgroup merges its sample's chunk records and normalises its chunk
+constexpr int SPX_CHUNK = 512;  // pixels per workgroup
+template <int VEC>
+__global__ __launch_bounds__(GT) void k_softpix_partial(const float *__restrict__ S, int P, int Lt, ColGeo geo,
+                                                        float *__restrict__ rec) {
+  __shared__ float sh[GT * VEC];
+  const int tx = threadIdx.x % geo.tx_n, ty = threadIdx.x / geo.tx_n;
+  const int chunk = blockIdx.x, n = blockIdx.y, nch = gridDim.x;
+  const int p0 = chunk * SPX_CHUNK, p1 = min(P, p0 + SPX_CHUNK);
+  const float *__restrict__ base = S + (size_t)n * P * Lt;
+  float *__restrict__ out = rec + ((size_t)n * nch + chunk) * 2 * Lt;
+  const bool lane_on = ty < geo.ty_n;
+  for (int g0 = 0; g0 < geo.groups; g0 += geo.tx_n) {
+    const int grp = g0 + tx;
+    const bool on = lane_on && grp < geo.groups;
+    float mx[VEC], sm[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) mx[e] = -INFINITY;
+    if (on)
+      for (int p = p0 + ty; p < p1; p += geo.ty_n) {
+        const Vecf<VEC> x = ldv<VEC>(base + (size_t)p * Lt + grp * VEC);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) mx[e] = fmaxf(mx[e], x.v[e]);
+      }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) sh[threadIdx.x * VEC + e] = mx[e];
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      float t = -INFINITY;
+      for (int k = 0; k < geo.ty_n; ++k) t = fmaxf(t, sh[(k * geo.tx_n + tx) * VEC + e]);
+      mx[e] = t;
+      sm[e] = 0.f;
     }
-  __syncthreads();
-  sh[threadIdx.x] = s;
-  __syncthreads();
-  if (rl == 0) {
-    float t = 0.f;
-    for (int k = 0; k < nrl; ++k) t += sh[k * cw + cl];
-    bc[cl] = t;
+    __syncthreads();
+    if (on)
+      for (int p = p0 + ty; p < p1; p += geo.ty_n) {
+        const Vecf<VEC> x = ldv<VEC>(base + (size_t)p * Lt + grp * VEC);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) sm[e] += expf(x.v[e] - mx[e]);
+      }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) sh[threadIdx.x * VEC + e] = sm[e];
+    __syncthreads();
+    if (on && ty == 0) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        float t = 0.f;
+        for (int k = 0; k < geo.ty_n; ++k) t += sh[(k * geo.tx_n + tx) * VEC + e];
+        out[grp * VEC + e] = mx[e];
+        out[Lt + grp * VEC + e] = t;
+      }
+    }
+    __syncthreads();
   }
-  __syncthreads();
-  const float sum = bc[cl];
-  if (on)
-    for (int p = rl; p < P; p += nrl) base[(size_t)p * Lt + l] /= sum;
+}
+
+// merges the chunk records of one sample: fin[n][0][l] = max, fin[n][1][l] = sum of exp relative to it
+__global__ __launch_bounds__(GT) void k_softpix_merge(const float *__restrict__ rec, int nch, int Lt, float *__restrict__ fin) {
+  const int l = blockIdx.x * GT + threadIdx.x, n = blockIdx.y;
+  if (l >= Lt) return;
+  const float *__restrict__ r0 = rec + (size_t)n * nch * 2 * Lt;
+  float m = -INFINITY;
+  for (int k = 0; k < nch; ++k) m = fmaxf(m, r0[(size_t)k * 2 * Lt + l]);
+  float z = 0.f;
+  for (int k = 0; k < nch; ++k) z += r0[(size_t)k * 2 * Lt + Lt + l] * expf(r0[(size_t)k * 2 * Lt + l] - m);
+  fin[(size_t)n * 2 * Lt + l] = m;
+  fin[(size_t)n * 2 * Lt + Lt + l] = z;
+}
+
+template <int VEC>
+__global__ __launch_bounds__(GT) void k_softpix_apply(float *__restrict__ S, int P, int Lt, ColGeo geo,
+                                                      const float *__restrict__ fin) {
+  const int tx = threadIdx.x % geo.tx_n, ty = threadIdx.x / geo.tx_n;
+  if (ty >= geo.ty_n) return;
+  const int chunk = blockIdx.x, n = blockIdx.y;
+  const int p0 = chunk * SPX_CHUNK, p1 = min(P, p0 + SPX_CHUNK);
+  float *__restrict__ base = S + (size_t)n * P * Lt;
+  for (int grp = tx; grp < geo.groups; grp += geo.tx_n) {
+    float M[VEC], Z[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      M[e] = fin[(size_t)n * 2 * Lt + grp * VEC + e];
+      Z[e] = fin[(size_t)n * 2 * Lt + Lt + grp * VEC + e];
+    }
+    for (int p = p0 + ty; p < p1; p += geo.ty_n) {
+      Vecf<VEC> x = ldv<VEC>(base + (size_t)p * Lt + grp * VEC);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) x.v[e] = expf(x.v[e] - M[e]) / Z[e];
+      stv<VEC>(base + (size_t)p * Lt + grp * VEC, x);
+    }
+  }
 }
 
 // ---- softmax over the last axis, one wave per row (projector_layer.hpp:84, attention scores
@@ -215,6 +349,22 @@ __global__ __launch_bounds__(GT) void k_softmax_rows(float *__restrict__ S, long
   for (int j = lane; j < Wd; j += 64) r[j] /= s;
 }
 
+// narrow rows (Wd = 16: the scaled shape's 16 tokens): four rows per wave, 16 lanes each
+__global__ __launch_bounds__(GT) void k_softmax_rows16(float *__restrict__ S, long rows) {
+  const long row = ((long)blockIdx.x * GT + threadIdx.x) >> 4;
+  if (row >= rows) return;
+  float *__restrict__ p = S + row * 16 + (threadIdx.x & 15);
+  const float x = *p;
+  float mx = x;
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  const float e = expf(x - mx);
+  float s = e;
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  *p = e / s;
+}
+
 // Tensor::softmax_backward over the last axis (tensor_cpu.hpp:946-950): ds = a * (da - sum a*da); in
 // place on da
 __global__ __launch_bounds__(GT) void k_softmax_bwd_rows(const float *__restrict__ a, float *__restrict__ da, long rows,
@@ -230,53 +380,109 @@ __global__ __launch_bounds__(GT) void k_softmax_bwd_rows(const float *__restrict
   for (int j = lane; j < Wd; j += 64) dr[j] = ar[j] * (dr[j] - dot);
 }
 
+__global__ __launch_bounds__(GT) void k_softmax_bwd_rows16(const float *__restrict__ a, float *__restrict__ da, long rows) {
+  const long row = ((long)blockIdx.x * GT + threadIdx.x) >> 4;
+  if (row >= rows) return;
+  const long i = row * 16 + (threadIdx.x & 15);
+  const float av = a[i], dv = da[i];
+  float dot = av * dv;
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
+  da[i] = av * (dv - dot);
+}
+
 // ---- reshape [N,P,C2] -> [N,C2,H,W] without moving data (vit_cnn.hpp:179) + MaxPool2DLayer::forward
 // (layers/pooling_layer.hpp:18-66) over the ReLU of the normalised projector output; the first
-// maximum of a window wins ---------------------------------------------------------------------------
+// maximum of a window (row-major inside the window) wins.  One wave per strip of pk image rows of one
+// plane: lanes run along the row (coalesced), keep the best of their column, then one lane per
+// window merges its pk columns. ------------------------------------------------------------------------
 __global__ __launch_bounds__(GT) void k_pool_fwd(const float *__restrict__ z, const float *__restrict__ stat,
                                                  const float *__restrict__ g, const float *__restrict__ b,
-                                                 float *__restrict__ pooled, int *__restrict__ pool_idx, long total, int C2,
+                                                 float *__restrict__ pooled, int *__restrict__ pool_idx, long strips, int C2,
                                                  int H, int pk) {
-  const int W = H, P = H * W;
-  for (long i = (long)blockIdx.x * GT + threadIdx.x; i < total; i += (long)gridDim.x * GT) {
-    const int j = (int)(i % 14), ii = (int)((i / 14) % 14);
-    const long nc = i / 196;  // n * C2 + ch
-    const float *__restrict__ plane = z + nc * P;
-    const long f0 = (nc % C2) * (long)P;  // flat offset of the plane inside its sample
-    float mv = -INFINITY;
-    int mi = -1;
-    for (int ki = 0; ki < pk; ++ki)
-      for (int kj = 0; kj < pk; ++kj) {
-        const int rem = (ii * pk + ki) * W + j * pk + kj;
-        const int c = (int)((f0 + rem) % C2);
-        const float y = fmaxf((plane[rem] - stat[c]) * stat[C2 + c] * g[c] + b[c], 0.f);
-        if (y > mv) {
-          mv = y;
-          mi = rem;
-        }
+  extern __shared__ float lds[];  // [4 waves][W] best value, [4 waves][W] best row
+  const int W = H, P = H * W, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long sid_raw = (long)blockIdx.x * (GT / 64) + wave;
+  const bool active = sid_raw < strips;
+  const long sid = active ? sid_raw : strips - 1;  // idle waves redo the last strip's reads and write nothing
+  float *__restrict__ bv = lds + wave * W;
+  int *__restrict__ bk = reinterpret_cast<int *>(lds + (GT / 64) * W) + wave * W;
+  const long nc = sid / 14;
+  const int ii = (int)(sid - nc * 14);
+  const float *__restrict__ plane = z + nc * P;
+  const int c_plane = (int)(((nc % C2) * (long)P) % C2);  // BatchNorm channel of the plane's first element
+  const int stepW = W % C2;
+  for (int w = lane; w < W; w += 64) {
+    int c = (c_plane + (int)(((long)ii * pk * W + w) % C2)) % C2;
+    float best = -INFINITY;
+    int bki = 0;
+    for (int ki = 0; ki < pk; ++ki) {
+      const float y = fmaxf((plane[(ii * pk + ki) * W + w] - stat[c]) * stat[C2 + c] * g[c] + b[c], 0.f);
+      if (y > best) {
+        best = y;
+        bki = ki;
       }
-    pooled[i] = mv;
-    pool_idx[i] = mi;
+      c += stepW;
+      if (c >= C2) c -= C2;
+    }
+    bv[w] = best;
+    bk[w] = bki;
+  }
+  __syncthreads();
+  if (active && lane < 14) {
+    float best = -INFINITY;
+    int bki = 0, bkj = 0;
+    for (int kj = 0; kj < pk; ++kj) {
+      const float v = bv[lane * pk + kj];
+      const int ki = bk[lane * pk + kj];
+      if (v > best || (v == best && ki < bki)) {
+        best = v;
+        bki = ki;
+        bkj = kj;
+      }
+    }
+    pooled[sid * 14 + lane] = best;
+    pool_idx[sid * 14 + lane] = (ii * pk + bki) * W + lane * pk + bkj;
   }
 }
 
 // MaxPool2DLayer::backward (pooling_layer.hpp:68-97) as a gather + the ReLU mask on the flat
 // reinterpretation (relu_layer.hpp:20-33): du[F] = dpool[window(F)] if F is the window's arg-max and
-// the activation was positive
+// the activation was positive.  One wave per image row of one plane.
 __global__ __launch_bounds__(GT) void k_pool_bwd(const float *__restrict__ z, const float *__restrict__ stat,
                                                  const float *__restrict__ g, const float *__restrict__ b,
                                                  const float *__restrict__ dpool, const int *__restrict__ pool_idx,
-                                                 float *__restrict__ du, long total, int C2, int H, int pk) {
-  const int W = H, P = H * W;
-  const long per = (long)P * C2;
-  for (long i = (long)blockIdx.x * GT + threadIdx.x; i < total; i += (long)gridDim.x * GT) {
-    const long n = i / per, F = i - n * per;
-    const int ch = (int)(F / P), rem = (int)(F - (long)ch * P);
-    const int h = rem / W, w = rem - h * W;
-    const long win = (n * C2 + ch) * 196 + (h / pk) * 14 + (w / pk);
-    const int c = (int)(F % C2);
-    const float y = (z[i] - stat[c]) * stat[C2 + c] * g[c] + b[c];
-    du[i] = (y > 0.f && pool_idx[win] == rem) ? dpool[win] : 0.f;
+                                                 float *__restrict__ du, long rows, int C2, int H, int pk) {
+  const int W = H, P = H * W, lane = threadIdx.x & 63;
+  const long rid = (long)blockIdx.x * (GT / 64) + (threadIdx.x >> 6);  // (n * C2 + ch) * H + h
+  if (rid >= rows) return;
+  const long nc = rid / H;
+  const int h = (int)(rid - nc * H);
+  const int c_row = (int)(((nc % C2) * (long)P + (long)h * W) % C2);
+  const long win0 = nc * 196 + (h / pk) * 14;
+  const float *__restrict__ zr = z + rid * W;
+  float *__restrict__ dr = du + rid * W;
+  if ((W & 3) == 0) {  // four pixels per lane: one 16-byte load and store
+    for (int w = lane * 4; w < W; w += 256) {
+      const float4 zv = *reinterpret_cast<const float4 *>(zr + w);
+      const float zz[4] = {zv.x, zv.y, zv.z, zv.w};
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = (c_row + w + e) % C2;
+        const float y = (zz[e] - stat[c]) * stat[C2 + c] * g[c] + b[c];
+        const long win = win0 + (w + e) / pk;
+        o[e] = (y > 0.f && pool_idx[win] == h * W + w + e) ? dpool[win] : 0.f;
+      }
+      *reinterpret_cast<float4 *>(dr + w) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+    return;
+  }
+  for (int w = lane; w < W; w += 64) {
+    const int c = (c_row + w) % C2;
+    const float y = (zr[w] - stat[c]) * stat[C2 + c] * g[c] + b[c];
+    const long win = win0 + w / pk;
+    dr[w] = (y > 0.f && pool_idx[win] == h * W + w) ? dpool[win] : 0.f;
   }
 }
 
@@ -317,14 +523,51 @@ int rows_per_block(long R) {
   return (int)std::min<long>(rpb, 1 << 20);
 }
 
+// rows per workgroup of the streaming column kernels: about 16K elements each
+int stream_rpb(int C, const ColGeo &geo) {
+  int rpb = std::max(geo.ty_n, 16384 / std::max(C, 1));
+  return (rpb + geo.ty_n - 1) / geo.ty_n * geo.ty_n;
+}
+
+// out = BatchNorm apply (mode 0: p = stat, q = gamma, r = beta) or in * coef (mode 1: p = coef)
+int col_affine(int mode, const float *in, const float *p, const float *q, const float *r, float *out, long R, int C,
+               hipStream_t s) {
+  const ColGeo geo = col_geo(C);
+  const int rpb = stream_rpb(C, geo);
+  const dim3 grid((unsigned)((R + rpb - 1) / rpb));
+  if (geo.vec == 4) {
+    if (mode == 0) hipLaunchKernelGGL((k_colaffine<4, 0>), grid, dim3(GT), 0, s, in, p, q, r, out, R, C, rpb, geo);
+    else hipLaunchKernelGGL((k_colaffine<4, 1>), grid, dim3(GT), 0, s, in, p, q, r, out, R, C, rpb, geo);
+  } else {
+    if (mode == 0) hipLaunchKernelGGL((k_colaffine<1, 0>), grid, dim3(GT), 0, s, in, p, q, r, out, R, C, rpb, geo);
+    else hipLaunchKernelGGL((k_colaffine<1, 1>), grid, dim3(GT), 0, s, in, p, q, r, out, R, C, rpb, geo);
+  }
+  VT_CHECK_LAUNCH();
+  return 0;
+}
+
+int bnbwd_partial(vt::GenModel *g, const float *delta, const float *in, const float *stat, long R, int C, int *nb_out,
+                  hipStream_t s) {
+  const int rpb = rows_per_block(R), nb = (int)((R + rpb - 1) / rpb);
+  if ((long)nb * 2 * C > g->part_floats) return VT_EUNSUPPORTED;
+  const ColGeo geo = col_geo(C);
+  if (geo.vec == 4) hipLaunchKernelGGL(k_bnbwd_partial<4>, dim3(nb), dim3(GT), 0, s, delta, in, stat, R, C, rpb, geo, g->part);
+  else hipLaunchKernelGGL(k_bnbwd_partial<1>, dim3(nb), dim3(GT), 0, s, delta, in, stat, R, C, rpb, geo, g->part);
+  VT_CHECK_LAUNCH();
+  *nb_out = nb;
+  return 0;
+}
+
 // BatchNorm forward statistics of in [R, C] (training: batch statistics + running update; eval with
-// eval_ok: the running buffers)
+// use_running: the running buffers)
 int bn_stats(vt::GenModel *g, const float *in, long R, int C, float *run_mean, float *run_var, float *stat, bool use_running,
              hipStream_t s) {
   if (use_running) return vt_bn_stats_eval(run_mean, run_var, C, stat, (vt_stream)s);
   const int rpb = rows_per_block(R), nb = (int)((R + rpb - 1) / rpb);
   if ((long)nb * 2 * C > g->part_floats) return VT_EUNSUPPORTED;
-  hipLaunchKernelGGL(k_colstats, dim3(nb), dim3(GT), 0, s, in, R, C, rpb, col_width(C), g->part);
+  const ColGeo geo = col_geo(C);
+  if (geo.vec == 4) hipLaunchKernelGGL(k_colstats<4>, dim3(nb), dim3(GT), 0, s, in, R, C, rpb, geo, g->part);
+  else hipLaunchKernelGGL(k_colstats<1>, dim3(nb), dim3(GT), 0, s, in, R, C, rpb, geo, g->part);
   VT_CHECK_LAUNCH();
   return vt_bn_stats_finalize(g->part, nb, C, rpb, R, run_mean, run_var, stat, (vt_stream)s);
 }
@@ -333,28 +576,54 @@ int bn_stats(vt::GenModel *g, const float *in, long R, int C, float *run_mean, f
 // gradients of gamma / beta and din = delta * scale + shift with the row-0 variance term
 int bn_backward(vt::GenModel *g, const float *delta, const float *in, const float *stat, const float *gamma, long R, int C,
                 float *ggamma, float *gbeta, float *coef, float *din, hipStream_t s) {
-  const int rpb = rows_per_block(R), nb = (int)((R + rpb - 1) / rpb);
-  if ((long)nb * 2 * C > g->part_floats) return VT_EUNSUPPORTED;
-  hipLaunchKernelGGL(k_bnbwd_partial, dim3(nb), dim3(GT), 0, s, delta, in, stat, R, C, rpb, col_width(C), g->part);
-  VT_CHECK_LAUNCH();
+  int nb = 0;
+  VTG(bnbwd_partial(g, delta, in, stat, R, C, &nb, s));
   VTG(vt_bn_bwd_finalize(g->part, nb, C, R, gamma, stat, in, ggamma, gbeta, coef, (vt_stream)s));
-  hipLaunchKernelGGL(k_scale_shift, dim3(nblk(R * C)), dim3(GT), 0, s, delta, coef, din, R * C, C);
-  VT_CHECK_LAUNCH();
-  return 0;
+  return col_affine(1, delta, coef, nullptr, nullptr, din, R, C, s);
 }
 
 // bias gradient of a DenseLayer: column sums of dY [R, C] (dense_layer.hpp:95-96)
 int col_sums(vt::GenModel *g, const float *dY, long R, int C, float *out, hipStream_t s) {
-  const int rpb = rows_per_block(R), nb = (int)((R + rpb - 1) / rpb);
-  if ((long)nb * 2 * C > g->part_floats) return VT_EUNSUPPORTED;
-  hipLaunchKernelGGL(k_bnbwd_partial, dim3(nb), dim3(GT), 0, s, dY, (const float *)nullptr, (const float *)nullptr, R, C, rpb,
-                     col_width(C), g->part);
-  VT_CHECK_LAUNCH();
+  int nb = 0;
+  VTG(bnbwd_partial(g, dY, nullptr, nullptr, R, C, &nb, s));
   return vt_reduce_rows(g->part, nb, C, 2 * C, out, (vt_stream)s);
 }
 
 int ewise(const float *a, const float *b, float *out, long total, int op, hipStream_t s) {
   hipLaunchKernelGGL(k_ewise, dim3(nblk(total)), dim3(GT), 0, s, a, b, out, total, op);
+  VT_CHECK_LAUNCH();
+  return 0;
+}
+
+// softmax over the pixel axis of S [n][P][Lt], in place
+int softmax_pixels(vt::GenModel *g, float *S, int n, int P, int Lt, hipStream_t s) {
+  const ColGeo geo = col_geo(Lt);
+  const dim3 grid((P + SPX_CHUNK - 1) / SPX_CHUNK, n);
+  float *fin = g->spx + (size_t)n * grid.x * 2 * Lt;  // merged records sit behind the chunk records
+  const dim3 mgrid((Lt + GT - 1) / GT, n);
+  if (geo.vec == 4) {
+    hipLaunchKernelGGL(k_softpix_partial<4>, grid, dim3(GT), 0, s, S, P, Lt, geo, g->spx);
+    hipLaunchKernelGGL(k_softpix_merge, mgrid, dim3(GT), 0, s, g->spx, (int)grid.x, Lt, fin);
+    hipLaunchKernelGGL(k_softpix_apply<4>, grid, dim3(GT), 0, s, S, P, Lt, geo, fin);
+  } else {
+    hipLaunchKernelGGL(k_softpix_partial<1>, grid, dim3(GT), 0, s, S, P, Lt, geo, g->spx);
+    hipLaunchKernelGGL(k_softpix_merge, mgrid, dim3(GT), 0, s, g->spx, (int)grid.x, Lt, fin);
+    hipLaunchKernelGGL(k_softpix_apply<1>, grid, dim3(GT), 0, s, S, P, Lt, geo, fin);
+  }
+  VT_CHECK_LAUNCH();
+  return 0;
+}
+
+int softmax_rows(float *S, long rows, int Wd, hipStream_t s) {
+  if (Wd == 16) hipLaunchKernelGGL(k_softmax_rows16, dim3((unsigned)((rows * 16 + GT - 1) / GT)), dim3(GT), 0, s, S, rows);
+  else hipLaunchKernelGGL(k_softmax_rows, dim3((unsigned)((rows + 3) / 4)), dim3(GT), 0, s, S, rows, Wd);
+  VT_CHECK_LAUNCH();
+  return 0;
+}
+
+int softmax_bwd_rows(const float *a, float *da, long rows, int Wd, hipStream_t s) {
+  if (Wd == 16) hipLaunchKernelGGL(k_softmax_bwd_rows16, dim3((unsigned)((rows * 16 + GT - 1) / GT)), dim3(GT), 0, s, a, da, rows);
+  else hipLaunchKernelGGL(k_softmax_bwd_rows, dim3((unsigned)((rows + 3) / 4)), dim3(GT), 0, s, a, da, rows, Wd);
   VT_CHECK_LAUNCH();
   return 0;
 }
@@ -402,6 +671,7 @@ int gen_create(GenModel *g, const vt_dims *d, int maxN, int (*alloc)(void *, flo
   A(&g->coef, 2 * (size_t)std::max(std::max(C1, C2), D), nullptr);
   g->part_floats = 4096L * 2 * std::max(std::max(C1, C2), std::max(D, 64)) + 1024;
   A(&g->part, (size_t)g->part_floats, nullptr);
+  A(&g->spx, N * ((g->P + SPX_CHUNK - 1) / SPX_CHUNK + 1) * 2 * L, nullptr);
   g->ws_floats = 16L << 20;
   A(&g->ws, (size_t)g->ws_floats, nullptr);
   // backward
@@ -448,53 +718,45 @@ int gen_forward(GenModel *g, const float *arena, const vt_layout *lo, float *are
   VTG(mm(false, true, (int)NP, C1, CK, g->col, CK, W("conv.W"), CK, g->conv, C1, W("conv.b")));
   // BatchNorm2DLayer::forward (batch_normalization_layer.hpp:262-298): the only norm that honours eval
   VTG(bn_stats(g, g->conv, NP, C1, RW("bn.running_mean"), RW("bn.running_var"), g->stat_bn, !training, s));
-  hipLaunchKernelGGL(k_bn_apply, dim3(nblk(NP * C1)), dim3(GT), 0, s, g->conv, g->stat_bn, W("bn.gamma"), W("bn.beta"), g->x,
-                     NP * C1, C1, 0);
-  VT_CHECK_LAUNCH();
+  VTG(col_affine(0, g->conv, g->stat_bn, W("bn.gamma"), W("bn.beta"), g->x, NP, C1, s));
   // FilterTokenizer::forward (layers/tokenizer.hpp:22-48)
   VTG(mm(false, false, (int)NP, L, C1, g->x, C1, W("tok.linear1.W"), L, g->tokA, L, W("tok.linear1.b")));
-  {
-    const int cw = col_width(L);
-    hipLaunchKernelGGL(k_softmax_pixels, dim3((L + cw - 1) / cw, n), dim3(GT), 0, s, g->tokA, P, L, cw);
-    VT_CHECK_LAUNCH();
-  }
+  VTG(softmax_pixels(g, g->tokA, n, P, L, s));
   VTG(mm(true, false, L, C1, P, g->tokA, L, g->x, C1, g->T0, C1, nullptr, false, 1.f, n, (long)P * L, (long)P * C1,
          (long)L * C1));
   VTG(mm(false, false, (int)NL, D, C1, g->T0, C1, W("tok.linear2.W"), D, g->tok, D, W("tok.linear2.b")));
   // TransformerLayer::forward (transformer_layer.hpp:43-131); the attention output is the zero concat
   // (multi_head_attention.hpp:100-104), so the first residual is the tokens themselves
   VTG(bn_stats(g, g->tok, NL, D, RW("norm1.running_mean"), RW("norm1.running_var"), g->stat_n1, false, s));
-  hipLaunchKernelGGL(k_bn_apply, dim3(nblk(NL * D)), dim3(GT), 0, s, g->tok, g->stat_n1, W("norm1.gamma"), W("norm1.beta"),
-                     g->a, NL * D, D, 0);
-  VT_CHECK_LAUNCH();
+  VTG(col_affine(0, g->tok, g->stat_n1, W("norm1.gamma"), W("norm1.beta"), g->a, NL, D, s));
   VTG(mm(false, false, (int)NL, D, D, g->a, D, W("ffn.linear1.W"), D, g->hdn, D, W("ffn.linear1.b")));
   VTG(ewise(g->hdn, nullptr, g->rl, NL * D, 2, s));
   VTG(mm(false, false, (int)NL, D, D, g->rl, D, W("ffn.linear2.W"), D, g->s2, D, W("ffn.linear2.b")));
   VTG(ewise(g->a, g->s2, g->s2, NL * D, 0, s));
   VTG(bn_stats(g, g->s2, NL, D, RW("norm2.running_mean"), RW("norm2.running_var"), g->stat_n2, false, s));
-  hipLaunchKernelGGL(k_bn_apply, dim3(nblk(NL * D)), dim3(GT), 0, s, g->s2, g->stat_n2, W("norm2.gamma"), W("norm2.beta"),
-                     g->o, NL * D, D, 0);
-  VT_CHECK_LAUNCH();
+  VTG(col_affine(0, g->s2, g->stat_n2, W("norm2.gamma"), W("norm2.beta"), g->o, NL, D, s));
   // ProjectorLayer::forward (projector_layer.hpp:43-116)
   VTG(mm(false, false, (int)NP, D, C1, g->x, C1, W("proj.linear1.W"), D, g->q, D));
   VTG(mm(false, false, (int)NL, D, D, g->o, D, W("proj.linear2.W"), D, g->k, D));
   VTG(mm(false, false, (int)NL, C2, D, g->o, D, W("proj.linear3.W"), C2, g->v, C2, W("proj.linear3.b")));
   VTG(mm(false, false, (int)NP, C2, C1, g->x, C1, W("proj.downsample.W"), C2, g->z, C2, W("proj.downsample.b")));
   VTG(mm(false, true, P, L, D, g->q, D, g->k, D, g->pa, L, nullptr, false, 1.f, n, (long)P * D, (long)L * D, (long)P * L));
-  hipLaunchKernelGGL(k_softmax_rows, dim3((unsigned)((NP + 3) / 4)), dim3(GT), 0, s, g->pa, NP, L);
-  VT_CHECK_LAUNCH();
+  VTG(softmax_rows(g->pa, NP, L, s));
   VTG(mm(false, false, P, C2, L, g->pa, L, g->v, C2, g->z, C2, nullptr, true, 1.f, n, (long)P * L, (long)L * C2,
          (long)P * C2));
   VTG(bn_stats(g, g->z, NP, C2, RW("proj.norm.running_mean"), RW("proj.norm.running_var"), g->stat_pn, false, s));
   // reshape, max-pool, fc, softmax (vit_cnn.hpp:179-203)
-  hipLaunchKernelGGL(k_pool_fwd, dim3(nblk((long)n * Q)), dim3(GT), 0, s, g->z, g->stat_pn, W("proj.norm.gamma"),
-                     W("proj.norm.beta"), g->pooled, g->pool_idx, (long)n * Q, C2, g->H, g->pk);
-  VT_CHECK_LAUNCH();
+  {
+    const long strips = (long)n * C2 * 14;
+    hipLaunchKernelGGL(k_pool_fwd, dim3((unsigned)((strips + 3) / 4)), dim3(GT), (size_t)2 * (GT / 64) * g->H * sizeof(float), s,
+                       g->z, g->stat_pn, W("proj.norm.gamma"), W("proj.norm.beta"), g->pooled, g->pool_idx, strips, C2, g->H,
+                       g->pk);
+    VT_CHECK_LAUNCH();
+  }
   VTG(mm(false, false, n, K, Q, g->pooled, Q, W("fc.W"), K, g->logits, K, W("fc.b")));
   float *probs = probs_out ? probs_out : g->probs;
   HIPCHK_G(hipMemcpyAsync(probs, g->logits, (size_t)n * K * sizeof(float), hipMemcpyDeviceToDevice, s));
-  hipLaunchKernelGGL(k_softmax_rows, dim3((unsigned)((n + 3) / 4)), dim3(GT), 0, s, probs, (long)n, K);
-  VT_CHECK_LAUNCH();
+  VTG(softmax_rows(probs, (long)n, K, s));
   if (probs != g->probs) HIPCHK_G(hipMemcpyAsync(g->probs, probs, (size_t)n * K * sizeof(float), hipMemcpyDeviceToDevice, s));
   return 0;
 }
@@ -515,9 +777,12 @@ int gen_backward(GenModel *g, const float *arena, const vt_layout *lo, float *gr
     VTG(col_sums(g, g->dlogits, n, K, G("fc.b"), s));
     VTG(mm(false, true, n, Q, K, g->dlogits, K, W("fc.W"), K, g->dpool, Q));
     // max-pool scatter + ReLU mask (pooling_layer.hpp:68-97, relu_layer.hpp:20-33)
-    hipLaunchKernelGGL(k_pool_bwd, dim3(nblk(NP * C2)), dim3(GT), 0, s, g->z, g->stat_pn, W("proj.norm.gamma"),
-                       W("proj.norm.beta"), g->dpool, g->pool_idx, g->du, NP * C2, C2, g->H, g->pk);
-    VT_CHECK_LAUNCH();
+    {
+      const long rows = (long)n * C2 * g->H;
+      hipLaunchKernelGGL(k_pool_bwd, dim3((unsigned)((rows + 3) / 4)), dim3(GT), 0, s, g->z, g->stat_pn, W("proj.norm.gamma"),
+                         W("proj.norm.beta"), g->dpool, g->pool_idx, g->du, rows, C2, g->H, g->pk);
+      VT_CHECK_LAUNCH();
+    }
     // ProjectorLayer::backward (projector_layer.hpp:118-214)
     VTG(bn_backward(g, g->du, g->z, g->stat_pn, W("proj.norm.gamma"), NP, C2, G("proj.norm.gamma"), G("proj.norm.beta"),
                     g->coef, g->dz, s));
@@ -529,8 +794,7 @@ int gen_backward(GenModel *g, const float *arena, const vt_layout *lo, float *gr
            (long)P * L));
     VTG(mm(true, false, L, C2, P, g->pa, L, g->dz, C2, g->dv, C2, nullptr, false, 1.f, n, (long)P * L, (long)P * C2,
            (long)L * C2));
-    hipLaunchKernelGGL(k_softmax_bwd_rows, dim3((unsigned)((NP + 3) / 4)), dim3(GT), 0, s, g->pa, g->dsa, NP, L);
-    VT_CHECK_LAUNCH();
+    VTG(softmax_bwd_rows(g->pa, g->dsa, NP, L, s));
     VTG(mm(false, false, P, D, L, g->dsa, L, g->k, D, g->dq, D, nullptr, false, 1.f, n, (long)P * L, (long)L * D,
            (long)P * D));
     VTG(mm(true, false, L, D, P, g->dsa, L, g->q, D, g->dk, D, nullptr, false, 1.f, n, (long)P * L, (long)P * D,
@@ -563,8 +827,7 @@ int gen_backward(GenModel *g, const float *arena, const vt_layout *lo, float *gr
     VTG(mm(false, true, (int)NL, C1, D, g->pdt, D, W("tok.linear2.W"), D, g->dT0, C1));
     VTG(mm(false, true, P, L, C1, g->x, C1, g->dT0, C1, g->dsa, L, nullptr, false, 1.f, n, (long)P * C1, (long)L * C1,
            (long)P * L));
-    hipLaunchKernelGGL(k_softmax_bwd_rows, dim3((unsigned)((NP + 3) / 4)), dim3(GT), 0, s, g->tokA, g->dsa, NP, L);
-    VT_CHECK_LAUNCH();
+    VTG(softmax_bwd_rows(g->tokA, g->dsa, NP, L, s));
     VTG(mm(false, false, P, C1, L, g->tokA, L, g->dT0, C1, g->tdx, C1, nullptr, false, 1.f, n, (long)P * L, (long)L * C1,
            (long)P * C1));
     VTG(mm(false, true, (int)NP, C1, L, g->dsa, L, W("tok.linear1.W"), L, g->tdx, C1, nullptr, true));
@@ -588,13 +851,11 @@ int gen_backward(GenModel *g, const float *arena, const vt_layout *lo, float *gr
       VTG(mm(false, false, (int)NL, hd, D, g->tok, D, W(nk.c_str()), hd, g->Km, hd));
       VTG(mm(false, false, (int)NL, hd, D, g->tok, D, W(nv.c_str()), hd, g->Vm, hd));
       VTG(mm(false, true, n, n, hd, g->Km, hd, g->Qm, hd, g->attn, n, nullptr, false, scale, L, sG, sG, sS));
-      hipLaunchKernelGGL(k_softmax_rows, dim3((unsigned)((NL + 3) / 4)), dim3(GT), 0, s, g->attn, NL, n);
-      VT_CHECK_LAUNCH();
+      VTG(softmax_rows(g->attn, NL, n, s));
       const float *dhd = g->dc + h * hd;  // this head's columns of the concat delta, row stride D
       VTG(mm(false, true, n, n, hd, dhd, D, g->Vm, hd, g->dat, n, nullptr, false, 1.f, L, (long)n * D, sG, sS));
       VTG(mm(true, false, n, hd, n, g->attn, n, dhd, D, g->dV, hd, nullptr, false, 1.f, L, sS, (long)n * D, sG));
-      hipLaunchKernelGGL(k_softmax_bwd_rows, dim3((unsigned)((NL + 3) / 4)), dim3(GT), 0, s, g->attn, g->dat, NL, n);
-      VT_CHECK_LAUNCH();
+      VTG(softmax_bwd_rows(g->attn, g->dat, NL, n, s));
       VTG(mm(false, false, n, hd, n, g->dat, n, g->Qm, hd, g->dK, hd, nullptr, false, 1.f, L, sS, sG, sG));
       VTG(mm(true, false, n, hd, n, g->dat, n, g->Km, hd, g->dQ, hd, nullptr, false, 1.f, L, sS, sG, sG));
       VTG(mm(true, false, D, hd, (int)NL, g->tok, D, g->dK, hd, G(nk.c_str()), hd));
