@@ -150,6 +150,8 @@ def main():
                     help="replay the step as one HIP graph (single GPU, train mode; for small batches)")
     ap.add_argument("--overlap", type=int, default=0,
                     help="1: data-parallel gradient exchange hidden behind compute (vit_amd/parallel.py)")
+    ap.add_argument("--bf16", action="store_true",
+                    help="general shapes only: forward-type products through bf16 operands (parity 1e-2, not 1e-4)")
     ap.add_argument("--exchange-alone", action="store_true",
                     help="rehearsal on one GPU: a one-rank RCCL group whose all-reduces are really launched")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -175,6 +177,8 @@ def main():
     generic = a.shape != "blood"
     B = a.batch
     m = VTCNN(dims, max_batch=B, seed=42)
+    if a.bf16:
+        m.set_matmul_precision(True)
     nb = 4  # resident mini-batches cycled through
     rng = np.random.default_rng(123 + rank)
     xs = torch.from_numpy(rng.integers(0, 256, size=(nb, B, dims.image_channels, dims.input_dim, dims.input_dim), dtype=np.uint8).astype(np.float32) / np.float32(255.0)).cuda()
@@ -270,7 +274,7 @@ def main():
         res = {
             "metric": ("train" if a.mode == "train" else "predict") + " images/sec (whole node) VTCNN " + {"blood": "BloodMNIST"}.get(a.shape, a.shape), "value": round(value, 1), "unit": "images/sec",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if a.bf16 else "f32", "data": "synthetic",
             "config": {"workload": ("VTCNN train step (forward+backward+SGD)" if a.mode == "train" else
                                     "VTCNN predict step (eval-mode forward)") + ", %s shape %dx%dx%d, %d classes, "
                                    "mini-batch %d per GPU, fp32, seed-42 reference init" % (

@@ -77,6 +77,11 @@ int vt_model_keep_internals(vt_model *m, int on);
 /* VTCNN::set_training (model/vit_cnn.hpp:262-269): only BatchNorm2D honours eval mode; the three
  * BatchNorm1D layers always use batch statistics (layers/visual_transformer.hpp:221). */
 int vt_model_set_training(vt_model *m, int training);
+/* Optional reduced-precision mode of the general-shape step: bf16 != 0 sends the activation x weight
+ * and score products through vt_gemm_bf16_mfma (gradient contractions, statistics, softmax and
+ * everything else stay fp32); results then agree with the reference to 1e-2 instead of 1e-4.  Models
+ * of the headline shape run fused fp32 kernels and accept only 0.  No counterpart in the reference. */
+int vt_model_set_matmul_precision(vt_model *m, int bf16);
 
 /* VTCNN::forward (model/vit_cnn.hpp:103-213).  d_images: device [n, Ci, H, W] fp32.
  * d_probs: device [n, K] softmax output (may be NULL: the model's own buffer is used). */
@@ -355,6 +360,12 @@ int vt_reduce_rows(const float *slab, long rows, int cols, int ld, float *out, v
 int vt_gemm_f32(int transA, int transB, int M, int N, int K, float alpha, const float *A, int lda, long strideA,
                 const float *B, int ldb, long strideB, int accumulate, float *C, int ldc, long strideC,
                 const float *bias, int batch, float *workspace, long workspace_floats, vt_stream s);
+/* The same product with both operands rounded to bf16 (nearest even) on their way into the matrix
+ * cores and fp32 accumulation (v_mfma_f32_16x16x16_bf16): operands and result stay fp32 in memory.
+ * The optional reduced-precision mode for the wide shapes; not what the parity tests at 1e-4 run. */
+int vt_gemm_bf16_mfma(int transA, int transB, int M, int N, int K, float alpha, const float *A, int lda, long strideA,
+                      const float *B, int ldb, long strideB, int accumulate, float *C, int ldc, long strideC,
+                      const float *bias, int batch, float *workspace, long workspace_floats, vt_stream s);
 /* update_weights + SGD::update (utils/optimizer.hpp:22-28) over n floats. */
 int vt_sgd_update(float *w, float *g, int n, float lr, float divisor, int zero_grad, vt_stream s);
 /* Textbook Adam over the arena.  NOT in the reference (utils/optimizer.hpp has SGD only):

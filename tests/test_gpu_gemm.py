@@ -64,3 +64,40 @@ def test_gemm_sliced_contraction():
     _run(1, 0, 27, 64, 9001, ws_floats=1 << 20, seed=6)
     # without a workspace the same product runs unsliced: 50 000 sequential fp32 additions per element
     _run(1, 0, 64, 16, 50000, seed=7, tol=5e-5)
+
+
+def _bf16_round(a):
+    u = a.astype(np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) >> 16 << 16
+    return u.astype(np.uint32).view(np.float32)
+
+
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_gemm_bf16_operands(ta, tb):
+    """vt_gemm_bf16_mfma = the fp32 product of the bf16-rounded operands (fp32 accumulation): exact
+    to accumulation order against numpy on rounded inputs, within 1e-2 of the unrounded product."""
+    import torch
+    from vit_amd._lib import check, lib
+    rng = np.random.default_rng(11 + 2 * ta + tb)
+    for (M, N, K, batch, pad) in ((64, 64, 64, 1, 0), (130, 75, 37, 2, 3), (100, 196, 512, 3, 0)):
+        ar, ac = (K, M) if ta else (M, K)
+        br, bc = (N, K) if tb else (K, N)
+        lda, ldb, ldc = ac + pad, bc + pad, N + pad
+        A = rng.standard_normal((batch, ar, lda)).astype(np.float32)
+        B = rng.standard_normal((batch, br, ldb)).astype(np.float32)
+        bias = rng.standard_normal(N).astype(np.float32)
+        dA, dB = torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda()
+        dC = torch.zeros(batch, M, ldc, device="cuda")
+        db = torch.from_numpy(bias).cuda()
+        check(lib.vt_gemm_bf16_mfma(ta, tb, M, N, K, 0.5, C.c_void_p(dA.data_ptr()), lda, ar * lda, C.c_void_p(dB.data_ptr()),
+                                    ldb, br * ldb, 0, C.c_void_p(dC.data_ptr()), ldc, M * ldc, C.c_void_p(db.data_ptr()), batch,
+                                    None, 0, C.c_void_p(torch.cuda.current_stream().cuda_stream)), "vt_gemm_bf16_mfma")
+        got = dC.cpu().numpy()[:, :, :N]
+
+        def prod(a, b):
+            a, b = a[:, :, :ac].astype(np.float64), b[:, :, :bc].astype(np.float64)
+            a = a.transpose(0, 2, 1) if ta else a
+            b = b.transpose(0, 2, 1) if tb else b
+            return 0.5 * np.matmul(a, b) + bias
+        assert rel_err(got, prod(_bf16_round(A), _bf16_round(B))) < 2e-6, (M, N, K)
+        assert rel_err(got, prod(A, B)) < 1e-2, (M, N, K)

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from conftest import load_golden, rel_err
-from tests_util import compare_compact, shape_case
+from tests_util import STRIDE, compare_compact, shape_case
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -126,3 +126,42 @@ def test_irregular_shape_against_oracle():
     m.backward_attention()
     # (running statistics moved between the two forwards; the weights did not, so gradients agree)
     assert np.array_equal(m.get_grads(), gg)
+
+
+def test_wide_shape_bf16_mode_within_1e_2():
+    """The optional bf16-MFMA mode at the wide shape against the reference's fp32 step: predictions,
+    loss and the weights after one update within 1e-2 (the bar stated for that mode)."""
+    import torch
+    from vit_amd import VTCNN, Dims
+    g = load_golden("shape_wide_n2.npz")
+    dims, n, k, seed, x, y = shape_case(g)
+    m = VTCNN(Dims(**dims), max_batch=n, seed=42)
+    m.set_matmul_precision(True)
+    lo = m.layout
+    arena0 = m.get_arena().copy()
+    xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    p = m.forward(xd).cpu().numpy()
+    compare_compact(g, "fwd.preds", p, 1e-2)
+    loss = float(-np.log(p[np.arange(n), y]).mean())
+    assert abs(loss - float(g["fwd.loss"][0])) < 1e-2 * float(g["fwd.loss"][0])
+    m.backward(yd)
+    gr = m.get_grads()
+    m.update_weights(32.0)
+    arena1 = m.get_arena()
+    # bf16 noise (4e-3) in the projector output re-decides near-tied pooling windows, and the deltas
+    # behind the pool are sparse, so gradients upstream of it agree in direction, not to 1e-2
+    # (tools/diag_bf16.py lists them: cosine 0.94-0.99 upstream, 1e-2 element-wise downstream).
+    for nm, (off, size, shape, kind) in lo.tensors.items():
+        if kind != 0 or "g." + nm not in g or not np.abs(g["g." + nm]).max() > 0:
+            continue
+        a, b = gr[off:off + size], g["g." + nm].ravel()
+        a = a if b.size == size else a[::STRIDE]
+        assert float(a @ b) / (np.linalg.norm(a) * np.linalg.norm(b)) > 0.9, nm
+        if nm.startswith(("mha.", "ffn.", "norm1.")) or nm == "fc.b":
+            assert rel_err(a, b) < 2e-2, nm  # measured: up to 1.03e-2 (mha.k2.W)
+        w0 = arena0[off:off + size]
+        if np.abs(w0).max() > 0 and b.size == size:  # weights after the update, where there were weights before
+            want = w0 - (b * np.float32(1 / 32.0)) * np.float32(0.001)
+            assert rel_err(arena1[off:off + size], want) < 1e-2, nm
+    with pytest.raises(RuntimeError):
+        VTCNN(Dims(num_classes=8), max_batch=2, seed=42).set_matmul_precision(True)  # headline kernels: fp32 only

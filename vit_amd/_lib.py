@@ -50,6 +50,7 @@ SIGNATURES = {
     "vt_model_grads_ptr": (p, [p]),
     "vt_model_save": (i, [p, C.c_char_p]),
     "vt_model_load": (i, [p, C.c_char_p]),
+    "vt_model_set_matmul_precision": (i, [p, i]),
     "vt_model_set_training": (i, [p, i]),
     "vt_model_keep_internals": (i, [p, i]),
     "vt_model_forward": (i, [p, p, i, p, p]),
@@ -103,6 +104,7 @@ SIGNATURES = {
     "vt_conv3x3_wgrad": (i, [p, p, p, p, i, i, i, i, p]),
     "vt_reduce_rows": (i, [p, l, i, i, p, p]),
     "vt_gemm_f32": (i, [i, i, i, i, i, f, p, i, C.c_long, p, i, C.c_long, i, p, i, C.c_long, p, i, p, C.c_long, p]),
+    "vt_gemm_bf16_mfma": (i, [i, i, i, i, i, f, p, i, C.c_long, p, i, C.c_long, i, p, i, C.c_long, p, i, p, C.c_long, p]),
     "vt_sgd_update": (i, [p, p, i, f, f, i, p]),
     "vt_adam_update": (i, [p, p, p, p, i, f, f, f, f, i, f, p]),
     "vt_projector_tokens_bwd": (i, [p] * 8 + [l, p]),

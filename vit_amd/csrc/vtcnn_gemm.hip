@@ -79,10 +79,42 @@ __device__ __forceinline__ void store_tile(float (*T)[GBM + GPAD], bool vec, int
   }
 }
 
-template <bool TA, bool TB>
+// bf16 mode: tiles are kept [row][k] in bf16 (round to nearest even), four consecutive k per lane feed
+// v_mfma_f32_16x16x16_bf16 (fp32 accumulation): a quarter of the matrix instructions of the fp32 form
+constexpr int HPAD = 4;
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned short to_bf16(float x) {
+  unsigned u = __float_as_uint(x);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+template <bool ALONG_K>
+__device__ __forceinline__ void store_tile_bf16(unsigned short (*T)[GBK + HPAD], bool vec, int tid, const float (&reg)[4]) {
+  if (vec) {
+    if (ALONG_K) {
+      const int r = tid >> 2, k = (tid & 3) * 4;
+      const unsigned lo = to_bf16(reg[0]) | ((unsigned)to_bf16(reg[1]) << 16), hi = to_bf16(reg[2]) | ((unsigned)to_bf16(reg[3]) << 16);
+      *reinterpret_cast<uint2 *>(&T[r][k]) = make_uint2(lo, hi);
+    } else {
+      const int k = tid >> 4, r = (tid & 15) * 4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) T[r + e][k] = to_bf16(reg[e]);
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int idx = tid + e * 256;
+      if (ALONG_K) T[idx >> 4][idx & (GBK - 1)] = to_bf16(reg[e]); else T[idx & 63][idx >> 6] = to_bf16(reg[e]);
+    }
+  }
+}
+
+template <bool TA, bool TB, bool BF>
 __global__ __launch_bounds__(256) void k_gemm(GemmP p) {
-  __shared__ float As[GBK][GBM + GPAD];
-  __shared__ float Bs[GBK][GBN + GPAD];
+  __shared__ float As[BF ? 1 : GBK][GBM + GPAD];
+  __shared__ float Bs[BF ? 1 : GBK][GBN + GPAD];
+  __shared__ __attribute__((aligned(8))) unsigned short Ah[BF ? GBM : 1][GBK + HPAD];
+  __shared__ __attribute__((aligned(8))) unsigned short Bh[BF ? GBN : 1][GBK + HPAD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.z / p.ksplit, ks = blockIdx.z - b * p.ksplit;
   const int m0 = blockIdx.x * GBM, n0 = blockIdx.y * GBN;  // rows on x: the batch's pixel rows run into the millions
@@ -103,22 +135,37 @@ __global__ __launch_bounds__(256) void k_gemm(GemmP p) {
   load_tile<TB>(B, p.ldb, n0, p.N, kbeg, kend, vecB, tid, rb);
   for (int k0 = kbeg; k0 < kend; k0 += GBK) {
     __syncthreads();  // the previous step's tile reads are over
-    store_tile<!TA>(As, vecA, tid, ra);
-    store_tile<TB>(Bs, vecB, tid, rb);
+    if constexpr (BF) {
+      store_tile_bf16<!TA>(Ah, vecA, tid, ra);
+      store_tile_bf16<TB>(Bh, vecB, tid, rb);
+    } else {
+      store_tile<!TA>(As, vecA, tid, ra);
+      store_tile<TB>(Bs, vecB, tid, rb);
+    }
     __syncthreads();
     if (k0 + GBK < kend) {
       load_tile<!TA>(A, p.lda, m0, p.M, k0 + GBK, kend, vecA, tid, ra);
       load_tile<TB>(B, p.ldb, n0, p.N, k0 + GBK, kend, vecB, tid, rb);
     }
+    if constexpr (BF) {
+      const int kq = 4 * (lane >> 4), c = lane & 15;
+      const s16x4 a0 = *reinterpret_cast<const s16x4 *>(&Ah[wm + c][kq]), a1 = *reinterpret_cast<const s16x4 *>(&Ah[wm + 16 + c][kq]);
+      const s16x4 b0 = *reinterpret_cast<const s16x4 *>(&Bh[wn + c][kq]), b1 = *reinterpret_cast<const s16x4 *>(&Bh[wn + 16 + c][kq]);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a1, b1, acc[1][1], 0, 0, 0);
+    } else {
 #pragma unroll
-    for (int kk = 0; kk < GBK; kk += 4) {
-      const int kr = kk + (lane >> 4), c = lane & 15;
-      const float a0 = As[kr][wm + c], a1 = As[kr][wm + 16 + c];
-      const float b0 = Bs[kr][wn + c], b1 = Bs[kr][wn + 16 + c];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][1], 0, 0, 0);
+      for (int kk = 0; kk < GBK; kk += 4) {
+        const int kr = kk + (lane >> 4), c = lane & 15;
+        const float a0 = As[kr][wm + c], a1 = As[kr][wm + 16 + c];
+        const float b0 = Bs[kr][wn + c], b1 = Bs[kr][wn + 16 + c];
+        acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][1], 0, 0, 0);
+      }
     }
   }
   const bool direct = p.ksplit == 1;
@@ -162,9 +209,9 @@ __global__ __launch_bounds__(256) void k_gemm_splitk_reduce(GemmP p, int batch) 
 
 using namespace vt;
 
-extern "C" int vt_gemm_f32(int transA, int transB, int M, int N, int K, float alpha, const float *A, int lda, long strideA,
-                           const float *B, int ldb, long strideB, int accumulate, float *C, int ldc, long strideC,
-                           const float *bias, int batch, float *workspace, long workspace_floats, vt_stream s) {
+static int gemm_launch(bool bf16, int transA, int transB, int M, int N, int K, float alpha, const float *A, int lda,
+                       long strideA, const float *B, int ldb, long strideB, int accumulate, float *C, int ldc, long strideC,
+                       const float *bias, int batch, float *workspace, long workspace_floats, vt_stream s) {
   if (M < 1 || N < 1 || K < 1 || batch < 1 || !A || !B || !C) return VT_EINVAL;
   if (lda < (transA ? M : K) || ldb < (transB ? K : N) || ldc < N) return VT_EINVAL;
   GemmP p{A, B, C, bias, M, N, K, lda, ldb, ldc, strideA, strideB, strideC, alpha, accumulate ? 1 : 0, 1, K, batch, 0, 0, nullptr};
@@ -195,10 +242,17 @@ extern "C" int vt_gemm_f32(int transA, int transB, int M, int N, int K, float al
   if ((N + GBN - 1) / GBN > 65535) return VT_EUNSUPPORTED;
   const dim3 grid((M + GBM - 1) / GBM, (N + GBN - 1) / GBN, (unsigned)gz);
   hipStream_t hs = (hipStream_t)s;
-  if (transA && transB) hipLaunchKernelGGL((k_gemm<true, true>), grid, dim3(256), 0, hs, p);
-  else if (transA) hipLaunchKernelGGL((k_gemm<true, false>), grid, dim3(256), 0, hs, p);
-  else if (transB) hipLaunchKernelGGL((k_gemm<false, true>), grid, dim3(256), 0, hs, p);
-  else hipLaunchKernelGGL((k_gemm<false, false>), grid, dim3(256), 0, hs, p);
+  if (bf16) {
+    if (transA && transB) hipLaunchKernelGGL((k_gemm<true, true, true>), grid, dim3(256), 0, hs, p);
+    else if (transA) hipLaunchKernelGGL((k_gemm<true, false, true>), grid, dim3(256), 0, hs, p);
+    else if (transB) hipLaunchKernelGGL((k_gemm<false, true, true>), grid, dim3(256), 0, hs, p);
+    else hipLaunchKernelGGL((k_gemm<false, false, true>), grid, dim3(256), 0, hs, p);
+  } else {
+    if (transA && transB) hipLaunchKernelGGL((k_gemm<true, true, false>), grid, dim3(256), 0, hs, p);
+    else if (transA) hipLaunchKernelGGL((k_gemm<true, false, false>), grid, dim3(256), 0, hs, p);
+    else if (transB) hipLaunchKernelGGL((k_gemm<false, true, false>), grid, dim3(256), 0, hs, p);
+    else hipLaunchKernelGGL((k_gemm<false, false, false>), grid, dim3(256), 0, hs, p);
+  }
   VT_CHECK_LAUNCH();
   if (p.ksplit > 1) {
     const long total = (long)M * N * batch;
@@ -207,4 +261,19 @@ extern "C" int vt_gemm_f32(int transA, int transB, int M, int N, int K, float al
     VT_CHECK_LAUNCH();
   }
   return 0;
+}
+
+extern "C" int vt_gemm_f32(int transA, int transB, int M, int N, int K, float alpha, const float *A, int lda, long strideA,
+                           const float *B, int ldb, long strideB, int accumulate, float *C, int ldc, long strideC,
+                           const float *bias, int batch, float *workspace, long workspace_floats, vt_stream s) {
+  return gemm_launch(false, transA, transB, M, N, K, alpha, A, lda, strideA, B, ldb, strideB, accumulate, C, ldc, strideC, bias,
+                     batch, workspace, workspace_floats, s);
+}
+
+extern "C" int vt_gemm_bf16_mfma(int transA, int transB, int M, int N, int K, float alpha, const float *A, int lda,
+                                 long strideA, const float *B, int ldb, long strideB, int accumulate, float *C, int ldc,
+                                 long strideC, const float *bias, int batch, float *workspace, long workspace_floats,
+                                 vt_stream s) {
+  return gemm_launch(true, transA, transB, M, N, K, alpha, A, lda, strideA, B, ldb, strideB, accumulate, C, ldc, strideC, bias,
+                     batch, workspace, workspace_floats, s);
 }

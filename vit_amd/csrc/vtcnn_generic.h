@@ -13,6 +13,7 @@ namespace vt {
 
 struct GenModel {
   int Ci, H, P, C1, C2, L, D, heads, hd, K, Q, pk, maxN;
+  int bf16;  // 1: products other than the gradient contractions run through bf16 operands
   // forward
   float *col, *conv, *x, *tokA, *T0, *tok, *a, *hdn, *rl, *s2, *o, *q, *k, *v, *pa, *z, *pooled, *logits, *probs;
   int *pool_idx;

@@ -511,8 +511,10 @@ struct Gemm {
   int operator()(bool ta, bool tb, int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *C, int ldc,
                  const float *bias = nullptr, bool acc = false, float alpha = 1.f, int batch = 1, long sA = 0, long sB = 0,
                  long sC = 0) const {
-    return vt_gemm_f32(ta, tb, M, N, K, alpha, A, lda, sA, B, ldb, sB, acc, C, ldc, sC, bias, batch, g->ws, g->ws_floats,
-                       (vt_stream)s);
+    // reduced-precision mode: the activation x weight and score products go through bf16; the
+    // gradient contractions over the batch's rows (transposed A) stay in fp32
+    auto fn = (g->bf16 && !ta) ? vt_gemm_bf16_mfma : vt_gemm_f32;
+    return fn(ta, tb, M, N, K, alpha, A, lda, sA, B, ldb, sB, acc, C, ldc, sC, bias, batch, g->ws, g->ws_floats, (vt_stream)s);
   }
 };
 
@@ -637,6 +639,7 @@ int gen_create(GenModel *g, const vt_dims *d, int maxN, int (*alloc)(void *, flo
   g->C2 = d->vt_channels; g->C1 = g->C2 / 2; g->L = d->tokens; g->D = d->token_channels;
   g->heads = d->heads; g->hd = g->D / g->heads; g->K = d->num_classes; g->Q = g->C2 * 196; g->pk = g->H / 14;
   g->maxN = maxN;
+  g->bf16 = 0;
   if (g->C1 > 1024 || g->C2 > 1024 || g->D > 1024) return VT_EUNSUPPORTED;  // finalize kernels: one workgroup per channel
   const size_t N = maxN, NP = N * g->P, NL = N * g->L;
   const int C1 = g->C1, C2 = g->C2, L = g->L, D = g->D, hd = g->hd, K = g->K, Q = g->Q;

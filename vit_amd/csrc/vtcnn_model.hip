@@ -669,6 +669,13 @@ extern "C" int vt_model_keep_internals(vt_model *m, int on) {
   return 0;
 }
 
+extern "C" int vt_model_set_matmul_precision(vt_model *m, int bf16) {
+  if (!m) return VT_EINVAL;
+  if (!m->gen) return bf16 ? VT_EUNSUPPORTED : 0;  // the fused headline kernels are fp32 only
+  m->gen->bf16 = bf16 != 0;
+  return 0;
+}
+
 extern "C" int vt_model_set_training(vt_model *m, int training) {
   if (!m) return VT_EINVAL;
   m->training = training ? 1 : 0;

@@ -100,6 +100,11 @@ class VTCNN:
         self.training = bool(is_training)
         check(lib.vt_model_set_training(self._h, int(self.training)))
 
+    def set_matmul_precision(self, bf16):
+        """General-shape models only: route the forward-type products through bf16 operands
+        (vt_model_set_matmul_precision); parity drops from 1e-4 to 1e-2."""
+        check(lib.vt_model_set_matmul_precision(self._h, int(bool(bf16))), "vt_model_set_matmul_precision")
+
     def keep_internals(self, on=True):
         """Test aid: also store the attention maps "fwd.tok_A" / "fwd.proj_a" for read()."""
         check(lib.vt_model_keep_internals(self._h, int(bool(on))))
