@@ -27,6 +27,10 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense f32-input MFMA peak (v_mfma_f32_32x32x2_f32), spec
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16), spec
+# the attention backward forms every fp32 product from bf16 hi / lo halves: 19 matrix instructions of
+# 32x32x16 per 32 x 32 tile pair where the fp32 formulation counts 5 contractions of 32x32x16
+MHA_EXECUTED_PER_ALGORITHMIC = 19.0 / 5.0
 
 
 def attention_bwd_flops(d, batch):
@@ -257,12 +261,14 @@ def main():
         achieved = tbl.get(dominant, 0) * B / avg_s / 1e9 if k_cnt else None
         if dominant == "mha_bwd_rows":  # compute bound on the matrix cores, not an HBM kernel
             fl = attention_bwd_flops(dims, B)
-            ach = fl / avg_s / 1e12 if k_cnt else None
+            ach = fl * MHA_EXECUTED_PER_ALGORITHMIC / avg_s / 1e12 if k_cnt else None
             roof = {"bound": "mfma", "kernel": dominant, "achieved": None if ach is None else round(ach, 2),
-                    "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": None if ach is None else round(ach / MFMA_F32_PEAK_TFLOPS, 4),
+                    "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": None if ach is None else round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
                     "traffic": measured_traffic(dominant, B, a.classes),
                     "algorithmic_flops_per_launch": fl,
+                    "executed_bf16_flops_per_launch": int(fl * MHA_EXECUTED_PER_ALGORITHMIC),
+                    "fp32_equivalent_tflops": None if not k_cnt else round(fl / avg_s / 1e12, 2),
                     "avg_launch_us": None if not k_cnt else round(avg_s * 1e6, 2), "launches_timed": k_cnt}
         else:
             roof = {"bound": "hbm", "kernel": dominant, "achieved": None if achieved is None else round(achieved, 1),

@@ -15,9 +15,11 @@
  *
  * Device tensor layouts ("token-major"): feature maps are [N, P, C] with P = H*W pixels and C
  * channels innermost; token matrices are [N*L, D] row-major; parameters use the canonical arena
- * of vtcnn_layout.h.  The only instantiation compiled today is the reference's own
- * hyper-parameters (main.cpp:66-78): C1=8, C2=16, L=16, D=32, heads=2, P<=1024, K<=16;
- * vt_model_create rejects anything else with VT_EUNSUPPORTED.
+ * of vtcnn_layout.h.  The per-layer launchers are compiled for the reference's own
+ * hyper-parameters (main.cpp:66-78): C1=8, C2=16, L=16, D=32, heads=2, P<=1024, K<=16.  A model
+ * handle of any other shape (channel widths, token count and width and head count up to 1024
+ * channels, any image size that is a multiple of 14) runs a general step built from vt_gemm_f32 and
+ * row-matrix kernels behind the same vt_model_* calls.
  */
 #ifndef VTCNN_HIP_H
 #define VTCNN_HIP_H

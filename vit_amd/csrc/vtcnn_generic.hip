@@ -43,9 +43,9 @@ struct Vecf {
 template <int VEC>
 __device__ __forceinline__ Vecf<VEC> ldv(const float *p) {
   Vecf<VEC> r;
-  if (VEC == 4) {
+  if constexpr (VEC == 4) {
     const float4 t = *reinterpret_cast<const float4 *>(p);
-    r.v[0] = t.x; r.v[1] = t.y; r.v[VEC - 2] = t.z; r.v[VEC - 1] = t.w;
+    r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w;
   } else {
     r.v[0] = *p;
   }
@@ -53,8 +53,8 @@ __device__ __forceinline__ Vecf<VEC> ldv(const float *p) {
 }
 template <int VEC>
 __device__ __forceinline__ void stv(float *p, const Vecf<VEC> &r) {
-  if (VEC == 4)
-    *reinterpret_cast<float4 *>(p) = make_float4(r.v[0], r.v[1], r.v[VEC - 2], r.v[VEC - 1]);
+  if constexpr (VEC == 4)
+    *reinterpret_cast<float4 *>(p) = make_float4(r.v[0], r.v[1], r.v[2], r.v[3]);
   else
     *p = r.v[0];
 }

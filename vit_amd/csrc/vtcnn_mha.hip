@@ -1,5 +1,6 @@
 // MultiHeadAttention::backward, per-head part (reference layers/multi_head_attention.hpp:139-181),
-// for gfx950, on the matrix cores (exact-f32 MFMA, v_mfma_f32_32x32x2_f32).
+// for gfx950, on the matrix cores: fp32 products formed from bf16 hi / lo operand halves
+// (v_mfma_f32_32x32x16_bf16, fp32 accumulation) in the row sweep, exact-f32 MFMA in the weight gradients.
 //
 // The layer's "batch" axis is the token index and its "sequence" axis is the mini-batch, because
 // Tensor::permute relabels the shape without moving data (utils/tensor/tensor_cpu.hpp:719-747):
@@ -20,7 +21,7 @@
 // so that its accumulator layout (column i on the lane, rows j in the 16 registers) is directly
 // the B operand of the next product, which contracts over j:
 //   Y^T[d][i] += sum_j X[j][d] E^T[j][i],   W^T[d][i] += sum_j X[j][d] (E*dA)^T[j][i].
-// No LDS, no lane shuffles in the loop; per-row softmax quantities are per-lane scalars.
+// No lane shuffles in the loop; per-row softmax quantities are per-lane scalars.
 // Softmax uses a per-row upper bound of the scores instead of the exact row maximum
 // (|K_i.Q_j| <= |K_i| max_j |Q_j|): softmax is shift invariant, so only the rounding changes, and
 // a whole pass over j disappears.
@@ -40,62 +41,53 @@ __device__ __forceinline__ int acc_row(int v, int hh) { return (v & 3) + 8 * (v 
 // per-row score bound, partials from different splits simply add.
 //   yz [head][split][2 (Y~, W~)][D][rows]      st [head][split][2 (sum e, sum e*dattn)][rows]
 // (row index fastest: coalesced for both kernels)
-struct TileRegs {
-  float4 q0, q1, v0, v1;
-  float xa[16];
-};
 
-// One 32 x 32 tile pair: 16 MFMAs for the transposed score and dattn tiles, the softmax numerators
-// on the vector ALU, 32 MFMAs that contract the tile with the token rows.
-template <bool FULL>
-__device__ __forceinline__ void tile_step(const TileRegs &cur, const float (&kb)[8], const float (&db)[8], float scale,
-                                          float mx, int jt, int T, int hh, floatx16 &accY, floatx16 &accW, float &ssum,
-                                          float &tsum) {
-  const float qa[8] = {cur.q0.x, cur.q0.y, cur.q0.z, cur.q0.w, cur.q1.x, cur.q1.y, cur.q1.z, cur.q1.w};
-  const float va[8] = {cur.v0.x, cur.v0.y, cur.v0.z, cur.v0.w, cur.v1.x, cur.v1.y, cur.v1.z, cur.v1.w};
-  floatx16 accS, accD;
-#pragma unroll
-  for (int v = 0; v < 16; ++v) { accS[v] = 0.f; accD[v] = 0.f; }
-#pragma unroll
-  for (int t = 0; t < 8; ++t) {
-    accS = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[t], kb[t], accS, 0, 0, 0);
-    accD = __builtin_amdgcn_mfma_f32_32x32x2f32(va[t], db[t], accD, 0, 0, 0);
-  }
-  const float nmx = -mx;
-#pragma unroll
-  for (int v = 0; v < 16; ++v) {
-    float ev = __expf(fmaf(accS[v], scale, nmx));
-    if (!FULL) ev = (jt + acc_row(v, hh) < T) ? ev : 0.f;
-    const float ed = ev * accD[v];
-    ssum += ev;
-    tsum += ed;
-    accS[v] = ev;
-    accD[v] = ed;
-  }
-#pragma unroll
-  for (int v = 0; v < 16; ++v) {
-    accY = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.xa[v], accS[v], accY, 0, 0, 0);
-    accW = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.xa[v], accD[v], accW, 0, 0, 0);
-  }
+// fp32 products on the bf16 matrix pipe.  Every operand x is carried as two bf16 numbers,
+// hi = bf16(x) and lo = bf16(x - hi), so hi + lo holds 16 mantissa bits of x, and a product of two
+// tiles is the sum of the partial products hi.hi + hi.lo + lo.hi (+ lo.lo where the result feeds an
+// exponential), each one v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  The bf16 pipe runs 16
+// times the rate of the fp32 one, so three or four partial products still cost a fifth of the cycles;
+// the relative error per product is 2^-17, random in sign, far inside the 1e-4 of the parity tests
+// after the sums over the mini-batch.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+
+// (a, b) -> packed bf16 pair of the high parts and of the low parts
+__device__ __forceinline__ void split2(float a, float b, unsigned &hi, unsigned &lo) {
+  const floatx2 f = {a, b};
+  hi = __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2));
+  const floatx2 r = {a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u)};
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
+}
+__device__ __forceinline__ bf16x8 as_bf8(uint4 v) { return __builtin_bit_cast(bf16x8, v); }
+__device__ __forceinline__ floatx16 mfma_bf(bf16x8 a, bf16x8 b, floatx16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
 constexpr int MR_WAVES = 4;  // row tiles (waves) per workgroup sharing the staged j tiles
-constexpr int QS = 20;       // LDS row stride of the staged Q / V tiles (floats; keeps b128 reads aligned)
+constexpr int XT = 36;       // LDS row stride (bf16 elements) of the transposed token tile: 72 bytes, conflict-free b64 reads
+
+// One staged j tile: 32 token rows.  Q and V head slices as [row][16] bf16 (hi and lo arrays); the
+// token rows transposed, [feature][row], so that a lane owning feature d reads four consecutive rows
+// with one 8-byte load.
+struct StageBuf {
+  unsigned short qh[32 * HD], ql[32 * HD], vh[32 * HD], vl[32 * HD];
+  unsigned short xh[D * XT], xl[D * XT];
+};
 
 // FULL: T is a multiple of 32, so no row of any tile needs a mask.
-// Workgroup = MR_WAVES row tiles of one (head, group, j range).  The j tile (32 token rows, their
-// Q and V head slices: 8 KB) is fetched once per workgroup, two 16-byte loads per thread, and
-// double-buffered in LDS: the global loads of tile k+1 are issued before the arithmetic of tile k
-// and land in LDS after it, so their latency never reaches the matrix pipe.
+// Workgroup = MR_WAVES row tiles of one (head, group, j range).  The j tile is fetched once per
+// workgroup, two 16-byte loads per thread, split into bf16 hi / lo on its way into LDS (once, for
+// all four waves) and double-buffered: the global loads of tile k+1 are issued before the arithmetic
+// of tile k and land in LDS after it.
 template <bool FULL>
 __global__ __launch_bounds__(64 * MR_WAVES) void k_mha_rows(const float *__restrict__ qkv, const float *__restrict__ dc,
                                                             const float *__restrict__ tok, float *__restrict__ yz,
                                                             float *__restrict__ st, int T, long rows, int groups,
                                                             int nsplit) {
   static_assert(HD == 16 && D == 32 && MR_WAVES == 4, "tile shapes are written for head_dim 16, token channels 32");
-  __shared__ __attribute__((aligned(16))) float sX[2][32 * D];
-  __shared__ __attribute__((aligned(16))) float sQ[2][32 * QS];
-  __shared__ __attribute__((aligned(16))) float sV[2][32 * QS];
+  __shared__ __attribute__((aligned(16))) StageBuf sb[2];
   __shared__ float sred[MR_WAVES];
   const int itiles = (T + 31) / 32, iblocks = (itiles + MR_WAVES - 1) / MR_WAVES;
   int bi = blockIdx.x;
@@ -114,36 +106,48 @@ __global__ __launch_bounds__(64 * MR_WAVES) void k_mha_rows(const float *__restr
   const int jbeg = sp * tps * 32, jend = min(T, (sp + 1) * tps * 32);
   const int ntile = jbeg < jend ? (jend - jbeg + 31) / 32 : 0;
 
-  // B operands of the score products: element t of lane half hh is head column e = 8*hh + t
-  // (the order of the contraction index is free as long as A and B agree).
-  float kb[8], db[8];
+  // B operands of the score products (this wave's own rows, constant over the sweep): lane half hh
+  // carries head columns e = 8*hh .. 8*hh+7, the k slots of its half of the 32x32x16 product
+  bf16x8 kbh, kbl, dbh, dbl;
+  float kn2 = 0.f;
   {
     const float4 k0 = *reinterpret_cast<const float4 *>(Km + row_i * D + h * HD + 8 * hh);
     const float4 k1 = *reinterpret_cast<const float4 *>(Km + row_i * D + h * HD + 8 * hh + 4);
     const float4 d0 = *reinterpret_cast<const float4 *>(dc + row_i * D + h * HD + 8 * hh);
     const float4 d1 = *reinterpret_cast<const float4 *>(dc + row_i * D + h * HD + 8 * hh + 4);
-    kb[0] = k0.x; kb[1] = k0.y; kb[2] = k0.z; kb[3] = k0.w; kb[4] = k1.x; kb[5] = k1.y; kb[6] = k1.z; kb[7] = k1.w;
-    db[0] = d0.x; db[1] = d0.y; db[2] = d0.z; db[3] = d0.w; db[4] = d1.x; db[5] = d1.y; db[6] = d1.z; db[7] = d1.w;
+    uint4 ph, pl;
+    split2(k0.x, k0.y, ph.x, pl.x); split2(k0.z, k0.w, ph.y, pl.y); split2(k1.x, k1.y, ph.z, pl.z); split2(k1.z, k1.w, ph.w, pl.w);
+    kbh = as_bf8(ph); kbl = as_bf8(pl);
+    split2(d0.x, d0.y, ph.x, pl.x); split2(d0.z, d0.w, ph.y, pl.y); split2(d1.x, d1.y, ph.z, pl.z); split2(d1.z, d1.w, ph.w, pl.w);
+    dbh = as_bf8(ph); dbl = as_bf8(pl);
+    kn2 = k0.x * k0.x + k0.y * k0.y + k0.z * k0.z + k0.w * k0.w + k1.x * k1.x + k1.y * k1.y + k1.z * k1.z + k1.w * k1.w;
   }
   // staging roles: thread -> one float4 of the token tile and one of the Q (threads 0..127) or V tile
   const int xr = tid >> 3, xc = (tid & 7) * 4, t2 = tid & 127, qr = t2 >> 2, qc = (t2 & 3) * 4;
   const float *__restrict__ gx = tok + gbase * D + xc;
   const float *__restrict__ gq = (tid < 128 ? Qm : Vm) + gbase * D + h * HD + qc;
-  float *const sqv = tid < 128 ? &sQ[0][0] : &sV[0][0];
   float4 rx, rq;
   auto gload = [&](int jt) {
     rx = *reinterpret_cast<const float4 *>(gx + (long)min(jt + xr, T - 1) * D);
     rq = *reinterpret_cast<const float4 *>(gq + (long)min(jt + qr, T - 1) * D);
   };
   auto sstore = [&](int buf) {
-    *reinterpret_cast<float4 *>(&sX[buf][xr * D + xc]) = rx;
-    *reinterpret_cast<float4 *>(sqv + buf * 32 * QS + qr * QS + qc) = rq;
+    StageBuf &B = sb[buf];
+    uint2 hv, lv;
+    split2(rq.x, rq.y, hv.x, lv.x);
+    split2(rq.z, rq.w, hv.y, lv.y);
+    unsigned short *dh = tid < 128 ? B.qh : B.vh, *dl = tid < 128 ? B.ql : B.vl;
+    *reinterpret_cast<uint2 *>(dh + qr * HD + qc) = hv;
+    *reinterpret_cast<uint2 *>(dl + qr * HD + qc) = lv;
+    split2(rx.x, rx.y, hv.x, lv.x);
+    split2(rx.z, rx.w, hv.y, lv.y);
+    B.xh[(xc + 0) * XT + xr] = (unsigned short)hv.x; B.xh[(xc + 1) * XT + xr] = (unsigned short)(hv.x >> 16);
+    B.xh[(xc + 2) * XT + xr] = (unsigned short)hv.y; B.xh[(xc + 3) * XT + xr] = (unsigned short)(hv.y >> 16);
+    B.xl[(xc + 0) * XT + xr] = (unsigned short)lv.x; B.xl[(xc + 1) * XT + xr] = (unsigned short)(lv.x >> 16);
+    B.xl[(xc + 2) * XT + xr] = (unsigned short)lv.y; B.xl[(xc + 3) * XT + xr] = (unsigned short)(lv.y >> 16);
   };
   if (ntile > 0) gload(jbeg);
 
-  float kn2 = 0.f;
-#pragma unroll
-  for (int t = 0; t < 8; ++t) kn2 += kb[t] * kb[t];
   kn2 += __shfl_xor(kn2, 32);
   // largest |Q_j|^2 of the whole group (identical in every split and row tile)
   float qn2 = 0.f;
@@ -162,6 +166,7 @@ __global__ __launch_bounds__(64 * MR_WAVES) void k_mha_rows(const float *__restr
   __syncthreads();
   qn2 = fmaxf(fmaxf(sred[0], sred[1]), fmaxf(sred[2], sred[3]));
   const float mx = scale * sqrtf(kn2) * sqrtf(qn2);  // >= every scaled score of row i
+  const float nmx = -mx;
 
   floatx16 accY, accW;
 #pragma unroll
@@ -171,14 +176,66 @@ __global__ __launch_bounds__(64 * MR_WAVES) void k_mha_rows(const float *__restr
   for (int k = 0; k < ntile; ++k) {
     const int jt = jbeg + 32 * k, b = k & 1;
     gload(jbeg + 32 * min(k + 1, ntile - 1));  // unconditional: the last one re-reads the final tile
-    TileRegs cur;
-    cur.q0 = *reinterpret_cast<const float4 *>(&sQ[b][c * QS + 8 * hh]);
-    cur.q1 = *reinterpret_cast<const float4 *>(&sQ[b][c * QS + 8 * hh + 4]);
-    cur.v0 = *reinterpret_cast<const float4 *>(&sV[b][c * QS + 8 * hh]);
-    cur.v1 = *reinterpret_cast<const float4 *>(&sV[b][c * QS + 8 * hh + 4]);
+    const StageBuf &B = sb[b];
+    // transposed score and dattn tiles: rows j (this lane: j = c) x columns i, contraction over the 16
+    // head columns = one matrix instruction per partial product
+    const bf16x8 qh = as_bf8(*reinterpret_cast<const uint4 *>(B.qh + c * HD + 8 * hh));
+    const bf16x8 ql = as_bf8(*reinterpret_cast<const uint4 *>(B.ql + c * HD + 8 * hh));
+    const bf16x8 vh = as_bf8(*reinterpret_cast<const uint4 *>(B.vh + c * HD + 8 * hh));
+    const bf16x8 vl = as_bf8(*reinterpret_cast<const uint4 *>(B.vl + c * HD + 8 * hh));
+    floatx16 accS, accD;
 #pragma unroll
-    for (int v = 0; v < 16; ++v) cur.xa[v] = sX[b][acc_row(v, hh) * D + c];
-    tile_step<FULL>(cur, kb, db, scale, mx, jt, T, hh, accY, accW, ssum, tsum);
+    for (int v = 0; v < 16; ++v) { accS[v] = 0.f; accD[v] = 0.f; }
+    accS = mfma_bf(ql, kbl, accS);  // smallest partial product first
+    accS = mfma_bf(ql, kbh, accS);
+    accS = mfma_bf(qh, kbl, accS);
+    accS = mfma_bf(qh, kbh, accS);
+    accD = mfma_bf(vl, dbh, accD);
+    accD = mfma_bf(vh, dbl, accD);
+    accD = mfma_bf(vh, dbh, accD);
+    // softmax numerators e and e * dattn, then their hi / lo halves as the B operands of the second
+    // stage: registers 0..7 of lane half hh are tile rows {4hh..4hh+3, 8+4hh..}, registers 8..15 the
+    // same + 16; the token operand below presents its rows in that same order
+    uint4 eh[2], el[2], fh[2], fl[2];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      unsigned ph[4], pl[4], qh4[4], ql4[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float ev[2], ed[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int v = 8 * half + 2 * q + u;
+          float e = __expf(fmaf(accS[v], scale, nmx));
+          if (!FULL) e = (jt + acc_row(v, hh) < T) ? e : 0.f;
+          ev[u] = e;
+          ed[u] = e * accD[v];
+          ssum += e;
+          tsum += ed[u];
+        }
+        split2(ev[0], ev[1], ph[q], pl[q]);
+        split2(ed[0], ed[1], qh4[q], ql4[q]);
+      }
+      eh[half] = make_uint4(ph[0], ph[1], ph[2], ph[3]);
+      el[half] = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+      fh[half] = make_uint4(qh4[0], qh4[1], qh4[2], qh4[3]);
+      fl[half] = make_uint4(ql4[0], ql4[1], ql4[2], ql4[3]);
+    }
+    // Y^T[d][i] += sum_j X[j][d] e^T[j][i],  W^T[d][i] += sum_j X[j][d] (e*dattn)^T[j][i]: this lane owns
+    // feature d = c; two instructions (16 rows each) per partial product
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const unsigned short *ph = B.xh + c * XT + 16 * half + 4 * hh, *pl = B.xl + c * XT + 16 * half + 4 * hh;
+      const uint2 h0 = *reinterpret_cast<const uint2 *>(ph), h1 = *reinterpret_cast<const uint2 *>(ph + 8);
+      const uint2 l0 = *reinterpret_cast<const uint2 *>(pl), l1 = *reinterpret_cast<const uint2 *>(pl + 8);
+      const bf16x8 xh = as_bf8(make_uint4(h0.x, h0.y, h1.x, h1.y)), xl = as_bf8(make_uint4(l0.x, l0.y, l1.x, l1.y));
+      accY = mfma_bf(xl, as_bf8(eh[half]), accY);
+      accY = mfma_bf(xh, as_bf8(el[half]), accY);
+      accY = mfma_bf(xh, as_bf8(eh[half]), accY);
+      accW = mfma_bf(xl, as_bf8(fh[half]), accW);
+      accW = mfma_bf(xh, as_bf8(fl[half]), accW);
+      accW = mfma_bf(xh, as_bf8(fh[half]), accW);
+    }
     sstore(b ^ 1);
     __syncthreads();
   }
