@@ -165,8 +165,10 @@ __global__ __launch_bounds__(64 * MR_WAVES) void k_mha_rows(const float *__restr
   if (ntile > 0) sstore(0);
   __syncthreads();
   qn2 = fmaxf(fmaxf(sred[0], sred[1]), fmaxf(sred[2], sred[3]));
-  const float mx = scale * sqrtf(kn2) * sqrtf(qn2);  // >= every scaled score of row i
-  const float nmx = -mx;
+  // e = exp(scale * s - mx) with mx = scale |K_i| max|Q_j| >= every scaled score of row i, evaluated
+  // as one fused multiply-add and one exp2
+  const float sc2 = scale * 1.44269504088896341f;
+  const float nmx = -sc2 * sqrtf(kn2) * sqrtf(qn2);
 
   floatx16 accY, accW;
 #pragma unroll
@@ -206,7 +208,7 @@ __global__ __launch_bounds__(64 * MR_WAVES) void k_mha_rows(const float *__restr
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           const int v = 8 * half + 2 * q + u;
-          float e = __expf(fmaf(accS[v], scale, nmx));
+          float e = __builtin_amdgcn_exp2f(fmaf(accS[v], sc2, nmx));
           if (!FULL) e = (jt + acc_row(v, hh) < T) ? e : 0.f;
           ev[u] = e;
           ed[u] = e * accD[v];
