@@ -388,11 +388,13 @@ __global__ __launch_bounds__(TPB) void k_mha_wgrad(const float *__restrict__ yz,
 
 using namespace vt;
 
-// How many j ranges each row tile is split into so that the launch has ~2 waves per SIMD.
+// How many j ranges each row tile is split into so that the launch has one wave per SIMD (1024).
+// A second resident wave buys the sweep 10 % and costs the gradient kernel more than that: every
+// split adds a set of partial sums that it must read and merge.
 static int mha_splits(int N, int groups) {
   const int itiles = (N + 31) / 32;
   const long waves = (long)HEADS * groups * ((itiles + MR_WAVES - 1) / MR_WAVES) * MR_WAVES;
-  int ns = (int)((2048 + waves - 1) / waves);
+  int ns = (int)((1024 + waves - 1) / waves);
   if (ns > 4) ns = 4;
   if (ns > itiles) ns = itiles;
   return ns < 1 ? 1 : ns;
