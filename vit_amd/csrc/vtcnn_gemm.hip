@@ -254,6 +254,11 @@ static int gemm_launch(bool bf16, int transA, int transB, int M, int N, int K, f
     else hipLaunchKernelGGL((k_gemm<false, false, false>), grid, dim3(256), 0, hs, p);
   }
   VT_CHECK_LAUNCH();
+  if (p.ksplit > 1 && !bias && !accumulate && ldc == N && (batch == 1 || strideC == (long)M * N) &&
+      (long)M * N * batch < (1L << 30)) {
+    // plain case (the weight gradients): the partial tiles are rows of a [slices, batch*M*N] matrix
+    return vt_reduce_rows(workspace, p.ksplit, (int)((long)M * N * batch), (int)((long)M * N * batch), C, s);
+  }
   if (p.ksplit > 1) {
     const long total = (long)M * N * batch;
     const int nb = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);

@@ -831,13 +831,14 @@ int gen_backward(GenModel *g, const float *arena, const vt_layout *lo, float *gr
     VTG(mm(false, true, P, L, C1, g->x, C1, g->dT0, C1, g->dsa, L, nullptr, false, 1.f, n, (long)P * C1, (long)L * C1,
            (long)P * L));
     VTG(softmax_bwd_rows(g->tokA, g->dsa, NP, L, s));
-    VTG(mm(false, false, P, C1, L, g->tokA, L, g->dT0, C1, g->tdx, C1, nullptr, false, 1.f, n, (long)P * L, (long)L * C1,
+    // the three input deltas (tokenizer a^T path, tokenizer score path, projector) are summed in place
+    // in the projector's delta buffer
+    VTG(mm(false, false, P, C1, L, g->tokA, L, g->dT0, C1, g->pdx, C1, nullptr, true, 1.f, n, (long)P * L, (long)L * C1,
            (long)P * C1));
-    VTG(mm(false, true, (int)NP, C1, L, g->dsa, L, W("tok.linear1.W"), L, g->tdx, C1, nullptr, true));
-    VTG(ewise(g->tdx, g->pdx, g->tdx, NP * C1, 0, s));
+    VTG(mm(false, true, (int)NP, C1, L, g->dsa, L, W("tok.linear1.W"), L, g->pdx, C1, nullptr, true));
     // BatchNorm2DLayer::backward + Conv2DLayer::backward gradients (batch_normalization_layer.hpp:300-327,
     // conv2d_layer.hpp:115-147); the conv input delta is never consumed
-    VTG(bn_backward(g, g->tdx, g->conv, g->stat_bn, W("bn.gamma"), NP, C1, G("bn.gamma"), G("bn.beta"), g->coef, g->tdx, s));
+    VTG(bn_backward(g, g->pdx, g->conv, g->stat_bn, W("bn.gamma"), NP, C1, G("bn.gamma"), G("bn.beta"), g->coef, g->tdx, s));
     VTG(mm(true, false, C1, CK, (int)NP, g->tdx, C1, g->col, CK, G("conv.W"), CK));
     VTG(col_sums(g, g->tdx, NP, C1, G("conv.b"), s));
   }
