@@ -95,17 +95,22 @@ def _check_against_exact_math(m, dims, n, x, y, arena0, p, gr):
             assert rel_err(gr[off:off + size], go[off:off + size]) < TOL, nm
 
 
-def test_irregular_shape_against_oracle():
-    """Dimensions that are multiples of nothing convenient (24 conv channels, 10 tokens of 24
-    channels, 3 heads, 5 classes, 42x42x2 images, batch 9): forward, every gradient, SGD, eval."""
+@pytest.mark.parametrize("dims,n", [
+    (dict(num_classes=5, image_channels=2, input_dim=42, tokens=10, token_channels=24, vt_channels=48, heads=3), 9),
+    (dict(num_classes=3, image_channels=1, input_dim=14, tokens=7, token_channels=20, vt_channels=10, heads=5), 3),
+    (dict(num_classes=11, image_channels=4, input_dim=56, tokens=33, token_channels=36, vt_channels=6, heads=1), 70),
+])
+def test_irregular_shape_against_oracle(dims, n):
+    """Dimensions that are multiples of nothing convenient (odd channel counts, token counts, head
+    widths of 4 to 36, 1x1 to 4x4 pooling windows, a batch above one 64-row tile): forward, every
+    gradient, the two-call backward."""
     import torch
     from vit_amd import VTCNN, Dims
     from oracle.pyoracle import Oracle, make_dims
-    dims = dict(num_classes=5, image_channels=2, input_dim=42, tokens=10, token_channels=24, vt_channels=48, heads=3)
-    n = 9
     rng = np.random.default_rng(5)
-    x = (rng.integers(0, 256, size=(n, 2, 42, 42)).astype(np.float32) / np.float32(255.0))
-    y = rng.integers(0, 5, size=n).astype(np.int32)
+    ci, hw, k = dims["image_channels"], dims["input_dim"], dims["num_classes"]
+    x = (rng.integers(0, 256, size=(n, ci, hw, hw)).astype(np.float32) / np.float32(255.0))
+    y = rng.integers(0, k, size=n).astype(np.int32)
     m = VTCNN(Dims(**dims), max_batch=n, seed=42)
     arena = m.get_arena().copy()
     o = Oracle(make_dims(**dims), n)
