@@ -17,7 +17,7 @@
 
 namespace vt {
 
-constexpr int GBM = 64, GBN = 64, GBK = 16, GPAD = 4;
+constexpr int GBK = 16, GPAD = 4;
 
 struct GemmP {
   const float *A, *B;
@@ -32,49 +32,56 @@ struct GemmP {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// One operand tile (64 rows of the M or N side x 16 of K) from global memory into four registers per
-// thread.  `along_k`: the K index is the contiguous one in memory (A not transposed / B transposed).
-// Vector form (one 16-byte load) when the host found the operand aligned and its sizes multiples of 4.
-template <bool ALONG_K>
+// One operand tile (R = 64 or 128 rows of the M or N side x 16 of K) from global memory into R/16
+// registers per thread.  ALONG_K: the K index is the contiguous one in memory (A not transposed / B
+// transposed).  Vector form (16-byte loads) when the host found the operand aligned and its sizes
+// multiples of 4.
+template <bool ALONG_K, int R>
 __device__ __forceinline__ void load_tile(const float *__restrict__ base, int ld, int r0, int rows, int k0, int kend,
-                                          bool vec, int tid, float (&reg)[4]) {
+                                          bool vec, int tid, float (&reg)[R / 16]) {
   if (vec) {
-    int r, k;
-    if (ALONG_K) { r = tid >> 2; k = (tid & 3) * 4; } else { k = tid >> 4; r = (tid & 15) * 4; }
-    const int gr = r0 + r, gk = k0 + k;
-    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (gr < rows && gk < kend)
-      t = *reinterpret_cast<const float4 *>(base + (ALONG_K ? (long)gr * ld + gk : (long)gk * ld + gr));
-    reg[0] = t.x; reg[1] = t.y; reg[2] = t.z; reg[3] = t.w;
+#pragma unroll
+    for (int hb = 0; hb < R / 64; ++hb) {
+      int r, k;
+      if (ALONG_K) { r = (tid >> 2) + 64 * hb; k = (tid & 3) * 4; } else { k = tid >> 4; r = (tid & 15) * 4 + 64 * hb; }
+      const int gr = r0 + r, gk = k0 + k;
+      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gr < rows && gk < kend)
+        t = *reinterpret_cast<const float4 *>(base + (ALONG_K ? (long)gr * ld + gk : (long)gk * ld + gr));
+      reg[4 * hb + 0] = t.x; reg[4 * hb + 1] = t.y; reg[4 * hb + 2] = t.z; reg[4 * hb + 3] = t.w;
+    }
   } else {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < R / 16; ++e) {
       const int idx = tid + e * 256;
       int r, k;
-      if (ALONG_K) { k = idx & (GBK - 1); r = idx >> 4; } else { r = idx & 63; k = idx >> 6; }
+      if (ALONG_K) { k = idx & (GBK - 1); r = idx >> 4; } else { r = idx & (R - 1); k = idx / R; }
       const int gr = r0 + r, gk = k0 + k;
       reg[e] = (gr < rows && gk < kend) ? base[ALONG_K ? (long)gr * ld + gk : (long)gk * ld + gr] : 0.f;
     }
   }
 }
 // registers -> LDS tile [k][row]
-template <bool ALONG_K>
-__device__ __forceinline__ void store_tile(float (*T)[GBM + GPAD], bool vec, int tid, const float (&reg)[4]) {
+template <bool ALONG_K, int R>
+__device__ __forceinline__ void store_tile(float (*T)[R + GPAD], bool vec, int tid, const float (&reg)[R / 16]) {
   if (vec) {
-    if (ALONG_K) {
-      const int r = tid >> 2, k = (tid & 3) * 4;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) T[k + e][r] = reg[e];
-    } else {
-      const int k = tid >> 4, r = (tid & 15) * 4;
+    for (int hb = 0; hb < R / 64; ++hb) {
+      if (ALONG_K) {
+        const int r = (tid >> 2) + 64 * hb, k = (tid & 3) * 4;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) T[k][r + e] = reg[e];
+        for (int e = 0; e < 4; ++e) T[k + e][r] = reg[4 * hb + e];
+      } else {
+        const int k = tid >> 4, r = (tid & 15) * 4 + 64 * hb;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) T[k][r + e] = reg[4 * hb + e];
+      }
     }
   } else {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < R / 16; ++e) {
       const int idx = tid + e * 256;
-      if (ALONG_K) T[idx & (GBK - 1)][idx >> 4] = reg[e]; else T[idx >> 6][idx & 63] = reg[e];
+      if (ALONG_K) T[idx & (GBK - 1)][idx >> 4] = reg[e]; else T[idx / R][idx & (R - 1)] = reg[e];
     }
   }
 }
@@ -88,83 +95,97 @@ __device__ __forceinline__ unsigned short to_bf16(float x) {
   u += 0x7fffu + ((u >> 16) & 1u);
   return (unsigned short)(u >> 16);
 }
-template <bool ALONG_K>
-__device__ __forceinline__ void store_tile_bf16(unsigned short (*T)[GBK + HPAD], bool vec, int tid, const float (&reg)[4]) {
+template <bool ALONG_K, int R>
+__device__ __forceinline__ void store_tile_bf16(unsigned short (*T)[GBK + HPAD], bool vec, int tid, const float (&reg)[R / 16]) {
   if (vec) {
-    if (ALONG_K) {
-      const int r = tid >> 2, k = (tid & 3) * 4;
-      const unsigned lo = to_bf16(reg[0]) | ((unsigned)to_bf16(reg[1]) << 16), hi = to_bf16(reg[2]) | ((unsigned)to_bf16(reg[3]) << 16);
-      *reinterpret_cast<uint2 *>(&T[r][k]) = make_uint2(lo, hi);
-    } else {
-      const int k = tid >> 4, r = (tid & 15) * 4;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) T[r + e][k] = to_bf16(reg[e]);
+    for (int hb = 0; hb < R / 64; ++hb) {
+      if (ALONG_K) {
+        const int r = (tid >> 2) + 64 * hb, k = (tid & 3) * 4;
+        const unsigned lo = to_bf16(reg[4 * hb]) | ((unsigned)to_bf16(reg[4 * hb + 1]) << 16);
+        const unsigned hi = to_bf16(reg[4 * hb + 2]) | ((unsigned)to_bf16(reg[4 * hb + 3]) << 16);
+        *reinterpret_cast<uint2 *>(&T[r][k]) = make_uint2(lo, hi);
+      } else {
+        const int k = tid >> 4, r = (tid & 15) * 4 + 64 * hb;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) T[r + e][k] = to_bf16(reg[4 * hb + e]);
+      }
     }
   } else {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < R / 16; ++e) {
       const int idx = tid + e * 256;
-      if (ALONG_K) T[idx >> 4][idx & (GBK - 1)] = to_bf16(reg[e]); else T[idx & 63][idx >> 6] = to_bf16(reg[e]);
+      if (ALONG_K) T[idx >> 4][idx & (GBK - 1)] = to_bf16(reg[e]); else T[idx & (R - 1)][idx / R] = to_bf16(reg[e]);
     }
   }
 }
 
-template <bool TA, bool TB, bool BF>
+// BM x BN: the workgroup's tile of C (64x64 for narrow or small products, 64x128 when only N is
+// wide, 128x128 for the wide shapes: each wave then owns 64x64 = 4x4 MFMA tiles and an LDS operand
+// read feeds four matrix instructions instead of two).
+template <bool TA, bool TB, bool BF, int BM, int BN>
 __global__ __launch_bounds__(256) void k_gemm(GemmP p) {
-  __shared__ float As[BF ? 1 : GBK][GBM + GPAD];
-  __shared__ float Bs[BF ? 1 : GBK][GBN + GPAD];
-  __shared__ __attribute__((aligned(8))) unsigned short Ah[BF ? GBM : 1][GBK + HPAD];
-  __shared__ __attribute__((aligned(8))) unsigned short Bh[BF ? GBN : 1][GBK + HPAD];
+  constexpr int TM = BM / 32, TN = BN / 32;  // 16x16 tiles per wave along M and N (waves are laid out 2 x 2)
+  __shared__ float As[BF ? 1 : GBK][BM + GPAD];
+  __shared__ float Bs[BF ? 1 : GBK][BN + GPAD];
+  __shared__ __attribute__((aligned(8))) unsigned short Ah[BF ? BM : 1][GBK + HPAD];
+  __shared__ __attribute__((aligned(8))) unsigned short Bh[BF ? BN : 1][GBK + HPAD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.z / p.ksplit, ks = blockIdx.z - b * p.ksplit;
-  const int m0 = blockIdx.x * GBM, n0 = blockIdx.y * GBN;  // rows on x: the batch's pixel rows run into the millions
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;  // rows on x: the batch's pixel rows run into the millions
   const int kbeg = ks * p.kchunk, kend = min(p.K, kbeg + p.kchunk);
   const float *__restrict__ A = p.A + (long)b * p.sA;
   const float *__restrict__ B = p.B + (long)b * p.sB;
-  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+  const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
   const bool vecA = p.vecA != 0, vecB = p.vecB != 0;
-  f32x4 acc[2][2];
+  f32x4 acc[TM][TN];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // the next K step's tiles travel from memory while the matrix cores work on the current one
-  float ra[4], rb[4];
-  load_tile<!TA>(A, p.lda, m0, p.M, kbeg, kend, vecA, tid, ra);
-  load_tile<TB>(B, p.ldb, n0, p.N, kbeg, kend, vecB, tid, rb);
+  float ra[BM / 16], rb[BN / 16];
+  load_tile<!TA, BM>(A, p.lda, m0, p.M, kbeg, kend, vecA, tid, ra);
+  load_tile<TB, BN>(B, p.ldb, n0, p.N, kbeg, kend, vecB, tid, rb);
   for (int k0 = kbeg; k0 < kend; k0 += GBK) {
     __syncthreads();  // the previous step's tile reads are over
     if constexpr (BF) {
-      store_tile_bf16<!TA>(Ah, vecA, tid, ra);
-      store_tile_bf16<TB>(Bh, vecB, tid, rb);
+      store_tile_bf16<!TA, BM>(Ah, vecA, tid, ra);
+      store_tile_bf16<TB, BN>(Bh, vecB, tid, rb);
     } else {
-      store_tile<!TA>(As, vecA, tid, ra);
-      store_tile<TB>(Bs, vecB, tid, rb);
+      store_tile<!TA, BM>(As, vecA, tid, ra);
+      store_tile<TB, BN>(Bs, vecB, tid, rb);
     }
     __syncthreads();
     if (k0 + GBK < kend) {
-      load_tile<!TA>(A, p.lda, m0, p.M, k0 + GBK, kend, vecA, tid, ra);
-      load_tile<TB>(B, p.ldb, n0, p.N, k0 + GBK, kend, vecB, tid, rb);
+      load_tile<!TA, BM>(A, p.lda, m0, p.M, k0 + GBK, kend, vecA, tid, ra);
+      load_tile<TB, BN>(B, p.ldb, n0, p.N, k0 + GBK, kend, vecB, tid, rb);
     }
     if constexpr (BF) {
       const int kq = 4 * (lane >> 4), c = lane & 15;
-      const s16x4 a0 = *reinterpret_cast<const s16x4 *>(&Ah[wm + c][kq]), a1 = *reinterpret_cast<const s16x4 *>(&Ah[wm + 16 + c][kq]);
-      const s16x4 b0 = *reinterpret_cast<const s16x4 *>(&Bh[wn + c][kq]), b1 = *reinterpret_cast<const s16x4 *>(&Bh[wn + 16 + c][kq]);
-      acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a1, b1, acc[1][1], 0, 0, 0);
+      s16x4 av[TM], bv[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) av[i] = *reinterpret_cast<const s16x4 *>(&Ah[wm + 16 * i + c][kq]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bv[j] = *reinterpret_cast<const s16x4 *>(&Bh[wn + 16 * j + c][kq]);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av[i], bv[j], acc[i][j], 0, 0, 0);
     } else {
 #pragma unroll
       for (int kk = 0; kk < GBK; kk += 4) {
         const int kr = kk + (lane >> 4), c = lane & 15;
-        const float a0 = As[kr][wm + c], a1 = As[kr][wm + 16 + c];
-        const float b0 = Bs[kr][wn + c], b1 = Bs[kr][wn + 16 + c];
-        acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][1], 0, 0, 0);
+        float av[TM], bv[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) av[i] = As[kr][wm + 16 * i + c];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bv[j] = Bs[kr][wn + 16 * j + c];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
       }
     }
   }
@@ -172,9 +193,9 @@ __global__ __launch_bounds__(256) void k_gemm(GemmP p) {
   float *__restrict__ C = direct ? p.C + (long)b * p.sC : p.part + ((long)ks * p.batch + b) * (long)p.M * p.N;
   const int ldc = direct ? p.ldc : p.N;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         const int gm = m0 + wm + i * 16 + 4 * (lane >> 4) + v, gn = n0 + wn + j * 16 + (lane & 15);
@@ -221,7 +242,14 @@ static int gemm_launch(bool bf16, int transA, int transB, int M, int N, int K, f
   auto aligned = [](const float *q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
   p.vecA = aligned(A) && lda % 4 == 0 && strideA % 4 == 0 && (transA ? M % 4 == 0 : K % 4 == 0);
   p.vecB = aligned(B) && ldb % 4 == 0 && strideB % 4 == 0 && (transB ? K % 4 == 0 : N % 4 == 0);
-  const long tiles = (long)((M + GBM - 1) / GBM) * ((N + GBN - 1) / GBN) * batch;
+  // tile shape: 64x128 when N is wide (A is then read once per 128 columns); 128x128 when the product
+  // is also deep enough to be bound by the matrix pipe rather than by streaming its operands
+  int BM = 64, BN = 64;
+  if (N > 64) {
+    BN = 128;
+    if (K >= 256 && M >= 128 && (long)((M + 127) / 128) * ((N + 127) / 128) * batch >= 512) BM = 128;
+  }
+  const long tiles = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN) * batch;
   // a contraction that is long for the few output tiles it feeds: slice K so that several hundred
   // workgroups exist (a lone workgroup walking 1024 rows costs 50 us of pure latency)
   if (workspace && K >= 256 && tiles < 256) {
@@ -239,20 +267,27 @@ static int gemm_launch(bool bf16, int transA, int transB, int M, int N, int K, f
   }
   const long gz = (long)batch * p.ksplit;
   if (gz > 65535) return VT_EUNSUPPORTED;
-  if ((N + GBN - 1) / GBN > 65535) return VT_EUNSUPPORTED;
-  const dim3 grid((M + GBM - 1) / GBM, (N + GBN - 1) / GBN, (unsigned)gz);
+  if ((N + BN - 1) / BN > 65535) return VT_EUNSUPPORTED;
+  const dim3 grid((M + BM - 1) / BM, (N + BN - 1) / BN, (unsigned)gz);
   hipStream_t hs = (hipStream_t)s;
+#define VT_GEMM_LAUNCH(TA_, TB_, BF_)                                                                                  \
+  do {                                                                                                                 \
+    if (BM == 128) hipLaunchKernelGGL((k_gemm<TA_, TB_, BF_, 128, 128>), grid, dim3(256), 0, hs, p);                 \
+    else if (BN == 128) hipLaunchKernelGGL((k_gemm<TA_, TB_, BF_, 64, 128>), grid, dim3(256), 0, hs, p);              \
+    else hipLaunchKernelGGL((k_gemm<TA_, TB_, BF_, 64, 64>), grid, dim3(256), 0, hs, p);                             \
+  } while (0)
   if (bf16) {
-    if (transA && transB) hipLaunchKernelGGL((k_gemm<true, true, true>), grid, dim3(256), 0, hs, p);
-    else if (transA) hipLaunchKernelGGL((k_gemm<true, false, true>), grid, dim3(256), 0, hs, p);
-    else if (transB) hipLaunchKernelGGL((k_gemm<false, true, true>), grid, dim3(256), 0, hs, p);
-    else hipLaunchKernelGGL((k_gemm<false, false, true>), grid, dim3(256), 0, hs, p);
+    if (transA && transB) VT_GEMM_LAUNCH(true, true, true);
+    else if (transA) VT_GEMM_LAUNCH(true, false, true);
+    else if (transB) VT_GEMM_LAUNCH(false, true, true);
+    else VT_GEMM_LAUNCH(false, false, true);
   } else {
-    if (transA && transB) hipLaunchKernelGGL((k_gemm<true, true, false>), grid, dim3(256), 0, hs, p);
-    else if (transA) hipLaunchKernelGGL((k_gemm<true, false, false>), grid, dim3(256), 0, hs, p);
-    else if (transB) hipLaunchKernelGGL((k_gemm<false, true, false>), grid, dim3(256), 0, hs, p);
-    else hipLaunchKernelGGL((k_gemm<false, false, false>), grid, dim3(256), 0, hs, p);
+    if (transA && transB) VT_GEMM_LAUNCH(true, true, false);
+    else if (transA) VT_GEMM_LAUNCH(true, false, false);
+    else if (transB) VT_GEMM_LAUNCH(false, true, false);
+    else VT_GEMM_LAUNCH(false, false, false);
   }
+#undef VT_GEMM_LAUNCH
   VT_CHECK_LAUNCH();
   if (p.ksplit > 1 && !bias && !accumulate && ldc == N && (batch == 1 || strideC == (long)M * N) &&
       (long)M * N * batch < (1L << 30)) {
