@@ -254,6 +254,16 @@ def main():
     prof = m.profile_read()
     m.profile(None)
 
+    # what an event pair itself adds to the interval it brackets (the markers are queue packets of
+    # their own): the launcher's HIP-event time minus this is what a kernel trace reports
+    s0 = torch.cuda.current_stream()
+    pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(64)]
+    for e0, e1 in pairs:
+        e0.record(s0)
+        e1.record(s0)
+    torch.cuda.synchronize()
+    pair_us = float(np.median([e0.elapsed_time(e1) for e0, e1 in pairs])) * 1e3
+
     if rank == 0:
         value = a.steps * B * world / dt
         k_ms, k_cnt = prof.get(dominant, (0.0, 0))
@@ -269,14 +279,16 @@ def main():
                     "algorithmic_flops_per_launch": fl,
                     "executed_bf16_flops_per_launch": int(fl * MHA_EXECUTED_PER_ALGORITHMIC),
                     "fp32_equivalent_tflops": None if not k_cnt else round(fl / avg_s / 1e12, 2),
-                    "avg_launch_us": None if not k_cnt else round(avg_s * 1e6, 2), "launches_timed": k_cnt}
+                    "avg_launch_us": None if not k_cnt else round(avg_s * 1e6, 2), "launches_timed": k_cnt,
+                    "event_pair_overhead_us": round(pair_us, 2)}
         else:
             roof = {"bound": "hbm", "kernel": dominant, "achieved": None if achieved is None else round(achieved, 1),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 4),
                     "traffic": measured_traffic(dominant, B, a.classes),
                     "algorithmic_bytes_per_launch": tbl.get(dominant, 0) * B,
-                    "avg_launch_us": None if not k_cnt else round(avg_s * 1e6, 2), "launches_timed": k_cnt}
+                    "avg_launch_us": None if not k_cnt else round(avg_s * 1e6, 2), "launches_timed": k_cnt,
+                    "event_pair_overhead_us": round(pair_us, 2)}
         res = {
             "metric": ("train" if a.mode == "train" else "predict") + " images/sec (whole node) VTCNN " + {"blood": "BloodMNIST"}.get(a.shape, a.shape), "value": round(value, 1), "unit": "images/sec",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 4),
