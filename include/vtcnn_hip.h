@@ -115,6 +115,11 @@ int vt_model_forward_grouped(vt_model *m, const float *d_images, int n, int grou
  * utils/optimizer.hpp:22-28):  g <- g * (1/divisor);  w <- w - g * lr  over the trainable region.
  * The reference always passes divisor = Trainer::batch_size = 32 (utils/trainer.hpp:53). */
 int vt_model_sgd_step(vt_model *m, float lr, float divisor, vt_stream s);
+/* One fused Adam pass over the trainable region (g scaled by 1/divisor first, as update_weights
+ * scales it; bias-corrected moments; gradients cleared), the moments kept by the model and the step
+ * count advanced by every call.  The reference trains with SGD only (utils/optimizer.hpp:14-28):
+ * an extension, parity unpinned (checked against the textbook recurrences). */
+int vt_model_adam_step(vt_model *m, float lr, float beta1, float beta2, float eps, float divisor, vt_stream s);
 /* The same update over floats [first, first + count) of the trainable region (first a multiple of 4). */
 int vt_model_sgd_step_range(vt_model *m, float lr, float divisor, int first, int count, vt_stream s);
 /* One training step (forward, backward, SGD update) captured once as a HIP graph and replayed:

@@ -286,3 +286,32 @@ def _overlapped_steps(a, b, dp, xs, ys, n, first, count):
     dp.finish()
     assert np.array_equal(a.get_arena(), b.get_arena())
     assert not b.get_grads().any()
+
+
+@pytest.mark.gpu
+def test_adam_step_matches_textbook_recurrences():
+    """vt_model_adam_step (extension; the reference has SGD only): three steps against numpy's
+    m <- b1 m + (1-b1) g, v <- b2 v + (1-b2) g^2, w <- w - lr (m/(1-b1^t)) / (sqrt(v/(1-b2^t)) + eps)
+    on the gradients the model itself produced, g scaled by 1/32 first."""
+    import torch
+    from vit_amd import VTCNN, Dims
+    n = 16
+    rng = np.random.default_rng(3)
+    m = VTCNN(Dims(num_classes=8), max_batch=n, seed=42)
+    nt = m.layout.n_trainable
+    w = m.get_arena()[:nt].astype(np.float64)
+    m1, m2 = np.zeros(nt), np.zeros(nt)
+    for t in range(1, 4):
+        x = torch.from_numpy(rng.integers(0, 256, size=(n, 1, 28, 28)).astype(np.float32) / np.float32(255.0)).cuda()
+        y = torch.from_numpy(rng.integers(0, 8, size=n).astype(np.int32)).cuda()
+        m.forward(x)
+        m.backward(y)
+        g = m.get_grads().astype(np.float64) / 32.0
+        m.update_weights_adam(32.0, lr=1e-3)
+        m1 = 0.9 * m1 + 0.1 * g
+        m2 = 0.999 * m2 + 0.001 * g * g
+        w = w - 1e-3 * (m1 / (1 - 0.9 ** t)) / (np.sqrt(m2 / (1 - 0.999 ** t)) + 1e-8)
+        got = m.get_arena()[:nt]
+        assert rel_err(got, w) < 1e-5, t
+        assert not m.get_grads().any()
+        w = got.astype(np.float64)  # follow the device weights so that only one step's rounding is compared

@@ -60,6 +60,7 @@ SIGNATURES = {
     "vt_model_backward_attention": (i, [p, p, p]),
     "vt_model_attention_range": (i, [p, p, p]),
     "vt_model_sgd_step": (i, [p, f, f, p]),
+    "vt_model_adam_step": (i, [p, f, f, f, f, f, p]),
     "vt_model_sgd_step_range": (i, [p, f, f, i, i, p]),
     "vt_model_metrics": (i, [p, p, p, p, p]),
     "vt_model_graph_capture": (i, [p, p, p, i, f, f]),

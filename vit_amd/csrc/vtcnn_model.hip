@@ -60,6 +60,8 @@ struct vt_model {
   std::vector<std::string> prof_names;
   size_t prof_used = 0;
 
+  float *adam_m1 = nullptr, *adam_m2 = nullptr;  // Adam moments over the trainable region, allocated on first use
+  int adam_step = 0;
   // shapes outside the compiled headline kernels run the general, GEMM-based step instead
   GenModel *gen = nullptr;
 
@@ -869,6 +871,20 @@ extern "C" int vt_model_attention_range(const vt_model *m, int *first, int *coun
 extern "C" int vt_model_sgd_step(vt_model *m, float lr, float divisor, vt_stream s) {
   if (!m) return VT_EINVAL;
   STEP("sgd_update", vt_sgd_update(m->arena, m->grads, m->lo.n_trainable, lr, divisor, 1, s));
+  return 0;
+}
+
+extern "C" int vt_model_adam_step(vt_model *m, float lr, float beta1, float beta2, float eps, float divisor, vt_stream s) {
+  if (!m || divisor == 0.f) return VT_EINVAL;
+  if (!m->adam_m1) {
+    HIPCHK(hipSetDevice(m->device));
+    if (dalloc(m, &m->adam_m1, m->lo.n_trainable) != 0 || dalloc(m, &m->adam_m2, m->lo.n_trainable) != 0) return VT_ENOMEM;
+    HIPCHK(hipMemsetAsync(m->adam_m1, 0, m->lo.n_trainable * sizeof(float), (hipStream_t)s));
+    HIPCHK(hipMemsetAsync(m->adam_m2, 0, m->lo.n_trainable * sizeof(float), (hipStream_t)s));
+    m->adam_step = 0;
+  }
+  STEP("adam_update", vt_adam_update(m->arena, m->grads, m->adam_m1, m->adam_m2, m->lo.n_trainable, lr, beta1, beta2, eps,
+                                     ++m->adam_step, divisor, s));
   return 0;
 }
 

@@ -173,6 +173,11 @@ class VTCNN:
         """VTCNN::update_weights + zero_grad with the reference's constant divisor (trainer.hpp:53)."""
         check(lib.vt_model_sgd_step(self._h, self.lr, float(batch_size), _stream_handle()), "vt_model_sgd_step")
 
+    def update_weights_adam(self, batch_size=32.0, lr=None, beta1=0.9, beta2=0.999, eps=1e-8):
+        """One fused Adam pass over the trainable region (extension: the reference has SGD only)."""
+        check(lib.vt_model_adam_step(self._h, self.lr if lr is None else float(lr), beta1, beta2, eps, float(batch_size),
+                                     _stream_handle()), "vt_model_adam_step")
+
     def update_weights_range(self, batch_size, first, count):
         """The same update over floats [first, first + count) of the trainable region."""
         check(lib.vt_model_sgd_step_range(self._h, self.lr, float(batch_size), int(first), int(count), _stream_handle()),
