@@ -158,6 +158,8 @@ def main():
                     help="general shapes only: forward-type products through bf16 operands (parity 1e-2, not 1e-4)")
     ap.add_argument("--exchange-alone", action="store_true",
                     help="rehearsal on one GPU: a one-rank RCCL group whose all-reduces are really launched")
+    ap.add_argument("--concurrent", type=int, default=1,
+                    help="0: issue the whole backward on one stream (default: two independent chains on two streams)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel", default=None, help="launcher to time with HIP events (default: the slowest)")
     a = ap.parse_args()
@@ -183,6 +185,7 @@ def main():
     m = VTCNN(dims, max_batch=B, seed=42)
     if a.bf16:
         m.set_matmul_precision(True)
+    m.set_concurrency(bool(a.concurrent))
     nb = 4  # resident mini-batches cycled through
     rng = np.random.default_rng(123 + rank)
     xs = torch.from_numpy(rng.integers(0, 256, size=(nb, B, dims.image_channels, dims.input_dim, dims.input_dim), dtype=np.uint8).astype(np.float32) / np.float32(255.0)).cuda()
@@ -298,7 +301,7 @@ def main():
                                    "mini-batch %d per GPU, fp32, seed-42 reference init" % (
                                        {"blood": "BloodMNIST"}.get(a.shape, a.shape), dims.image_channels, dims.input_dim,
                                        dims.input_dim, a.classes, B),
-                       "hip_graph": bool(use_graph), "statistics_group": a.group if a.mode == "predict" else 0, "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world,
+                       "hip_graph": bool(use_graph), "two_stream_backward": bool(a.concurrent) and not generic, "statistics_group": a.group if a.mode == "predict" else 0, "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world,
                        "exchange_overlapped": bool(dp.overlap and a.mode == "train" and not use_graph),
                        "grad_allreduce_floats": int(m.layout.n_trainable) if world > 1 else 0},
             "roofline": roof,

@@ -84,9 +84,19 @@ int vt_model_set_training(vt_model *m, int training);
  * everything else stay fp32); results then agree with the reference to 1e-2 instead of 1e-4.  Models
  * of the headline shape run fused fp32 kernels and accept only 0.  No counterpart in the reference. */
 int vt_model_set_matmul_precision(vt_model *m, int bf16);
+/* Launch order of the headline-shape backward.  on != 0 (the default): once the projector's deltas
+ * exist, the tokenizer / BatchNorm2D / convolution backward (and the fc weight gradient before it)
+ * are issued on a stream of the model's own, beside the transformer and attention backward on the
+ * caller's stream, and joined before the gradient reduction; the two chains share no buffer
+ * (layers/visual_transformer.hpp:153-173: tokenizer.backward2 takes the projector's deltas, not the
+ * transformer's), so the result is the same bytes as with on == 0, where everything is issued on the
+ * caller's stream.  General-shape models ignore it.  No counterpart in the reference. */
+int vt_model_set_concurrency(vt_model *m, int on);
 
 /* VTCNN::forward (model/vit_cnn.hpp:103-213).  d_images: device [n, Ci, H, W] fp32.
- * d_probs: device [n, K] softmax output (may be NULL: the model's own buffer is used). */
+ * d_probs: device [n, K] softmax output, written in place by the head kernel and read again by the
+ * backward pass and vt_model_metrics, so it must stay untouched until those have run (NULL: the
+ * model's own buffer is used). */
 int vt_model_forward(vt_model *m, const float *d_images, int n, float *d_probs, vt_stream s);
 /* VTCNN::backward (model/vit_cnn.hpp:215-242) for the mini-batch of the last forward; d_labels:
  * device int32 [n].  Leaves the summed gradients in the gradient arena (overwrites it). */
@@ -149,6 +159,10 @@ int vt_model_metrics(vt_model *m, const int *d_labels, float *d_loss_sum, int *d
  * last vt_model_profile call.  No counterpart in the reference (it has no profiler hooks). */
 int vt_model_profile(vt_model *m, const char *filter);
 int vt_model_profile_read(vt_model *m, int idx, char *name_out, int name_cap, float *total_ms, int *count);
+/* Pair k of the launches timed since vt_model_profile: launcher name, start and end in microseconds
+ * after the first timed launch began (launches on the model's own stream included).  Returns the
+ * number of pairs; synchronises the device. */
+int vt_model_profile_timeline(vt_model *m, int k, char *name_out, int name_cap, float *start_us, float *end_us);
 
 /* Test / tooling access to the workspace: copies the named intermediate of the last
  * forward/backward to host.  Returns the number of floats, or a negative error. */

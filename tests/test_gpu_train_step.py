@@ -276,6 +276,37 @@ def test_two_call_backward_and_overlapped_update_are_bit_identical(n):
             dist.destroy_process_group()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [32, 1024])
+def test_two_stream_backward_is_bit_identical_to_one_stream(n):
+    """vt_model_set_concurrency: the tokenizer / BatchNorm2D / conv chain on the model's own stream
+    beside the transformer chain writes exactly the gradients and weights of the one-stream order,
+    step after step (a stale or racing buffer would show up from the second step on), also when the
+    step is replayed as a captured graph."""
+    import torch
+    from vit_amd import VTCNN, Dims
+    rng = np.random.default_rng(11 * n)
+    xs = [torch.from_numpy(rng.integers(0, 256, size=(n, 1, 28, 28)).astype(np.float32) / np.float32(255.0)).cuda()
+          for _ in range(4)]
+    ys = [torch.from_numpy(rng.integers(0, 8, size=n).astype(np.int32)).cuda() for _ in range(4)]
+    a, b, c = (VTCNN(Dims(num_classes=8), max_batch=n, seed=42) for _ in range(3))
+    a.set_concurrency(False)
+    b.set_concurrency(True)
+    c.set_concurrency(True)
+    xbuf, ybuf = torch.empty_like(xs[0]), torch.empty_like(ys[0])
+    c.capture_step(xbuf, ybuf, float(n))
+    for t in range(4):
+        a.forward(xs[t]); a.backward(ys[t])
+        b.forward(xs[t]); b.backward(ys[t])
+        assert np.array_equal(a.get_grads(), b.get_grads()), t
+        a.update_weights(float(n)); b.update_weights(float(n))
+        xbuf.copy_(xs[t]); ybuf.copy_(ys[t])
+        c.step_graph()
+        wa = a.get_arena()
+        assert np.array_equal(wa, b.get_arena()), t
+        assert np.array_equal(wa, c.get_arena()), t
+
+
 def _overlapped_steps(a, b, dp, xs, ys, n, first, count):
     for t in range(3):
         a.forward(xs[t]); a.backward(ys[t]); a.update_weights(float(n))

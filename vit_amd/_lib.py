@@ -52,6 +52,7 @@ SIGNATURES = {
     "vt_model_load": (i, [p, C.c_char_p]),
     "vt_model_set_matmul_precision": (i, [p, i]),
     "vt_model_set_training": (i, [p, i]),
+    "vt_model_set_concurrency": (i, [p, i]),
     "vt_model_keep_internals": (i, [p, i]),
     "vt_model_forward": (i, [p, p, i, p, p]),
     "vt_model_forward_grouped": (i, [p, p, i, i, p, p]),
@@ -69,6 +70,7 @@ SIGNATURES = {
     "vt_model_read": (l, [p, C.c_char_p, p, l]),
     "vt_model_profile": (i, [p, C.c_char_p]),
     "vt_model_profile_read": (i, [p, i, C.c_char_p, i, C.POINTER(f), C.POINTER(i)]),
+    "vt_model_profile_timeline": (i, [p, i, C.c_char_p, i, C.POINTER(f), C.POINTER(f)]),
     "vt_host_init_arena": (i, [C.POINTER(VtDims), u, p]),
     "vt_checkpoint_write": (i, [C.POINTER(VtDims), p, C.c_char_p]),
     "vt_checkpoint_read": (i, [C.POINTER(VtDims), p, C.c_char_p]),

@@ -34,6 +34,12 @@ struct vt_model {
   int maxN = 0, device = 0, lastN = 0, training = 1;
   int P = 0, Q = 0, K = 0;
   hipStream_t gstream = nullptr;  // capture stream of the step graph
+  // Backward runs two independent launch chains after the projector (the transformer/attention rows
+  // and the tokenizer/BatchNorm2D/conv pixels); the second one is issued on this stream between a
+  // fork event and a join event so that latency-bound row kernels overlap HBM-bound pixel kernels.
+  hipStream_t side = nullptr;
+  hipEvent_t ev_head = nullptr, ev_rows = nullptr, ev_join = nullptr;
+  bool concurrent = true, side_open = false;
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec = nullptr;
   bool keep_internals = false;  // also store the two attention maps (test aid)
@@ -44,10 +50,11 @@ struct vt_model {
   // forward workspace
   float *conv, *tokA = nullptr, *tokstat, *tok, *a, *hdn, *s2, *o, *pk, *projA = nullptr, *z, *pooled, *logits, *probs;
   unsigned char *pool_idx;
-  float *part, *stat_bn, *stat_n1, *stat_n2, *stat_pn, *batch_mv;
+  float *part, *part_side = nullptr, *stat_bn, *stat_n1, *stat_n2, *stat_pn, *batch_mv;
   bool last_grouped = false;  // the last forward was a grouped one: no backward for it
   bool attention_pending = false;  // vt_model_backward_main ran, vt_model_backward_attention has not yet
   const float *last_images = nullptr;
+  float *last_probs = nullptr;  // where the last forward left the probabilities (the caller's buffer or m->probs)
   // backward workspace
   float *dlogits, *du, *pdx, *pdt, *dv, *dk, *d0, *ds2, *dh, *da, *dr, *dc, *dT0, *dy, *qkv, *gslab, *gslab_conv;
   float *sc_fc, *sc_pt, *sc_ffn, *sc_mha;  // partial-gradient slabs, one per launcher: they stay live until the fused reduction
@@ -148,6 +155,7 @@ extern "C" int vt_model_create(const vt_dims *dims, int max_batch, int device, f
   m->pool_idx = (unsigned char *)pi;
   const size_t nrb = (NL + RB - 1) / RB;
   rc |= dalloc(m, &m->part, std::max(N, nrb) * 64);
+  rc |= dalloc(m, &m->part_side, std::max(N, nrb) * 64);
   rc |= dalloc(m, &m->stat_bn, 2 * C1, "stat.bn");
   // one (mean, inv) record per statistics group: grouped forward runs up to maxN/4 groups
   const size_t max_groups = N / 4 + 1;
@@ -182,6 +190,11 @@ extern "C" int vt_model_create(const vt_dims *dims, int max_batch, int device, f
   rc |= dalloc(m, &m->coef_n1, 2 * D, "coef.norm1");
   rc |= dalloc(m, &m->coef_bn, 2 * C1, "coef.bn");
   rc |= dalloc(m, &m->loss_buf, 4);
+  if (rc == 0 && (hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking) != hipSuccess ||
+                  hipEventCreateWithFlags(&m->ev_head, hipEventDisableTiming) != hipSuccess ||
+                  hipEventCreateWithFlags(&m->ev_rows, hipEventDisableTiming) != hipSuccess ||
+                  hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming) != hipSuccess))
+    rc = VT_ENOMEM;
   if (rc != 0) {
     vt_model_destroy(m);
     return VT_ENOMEM;
@@ -199,6 +212,9 @@ extern "C" int vt_model_destroy(vt_model *m) {
   if (m->graph_exec) (void)hipGraphExecDestroy(m->graph_exec);
   if (m->graph) (void)hipGraphDestroy(m->graph);
   if (m->gstream) (void)hipStreamDestroy(m->gstream);
+  if (m->side) (void)hipStreamDestroy(m->side);
+  for (hipEvent_t e : {m->ev_head, m->ev_rows, m->ev_join})
+    if (e) (void)hipEventDestroy(e);
   for (void *p : m->allocs) (void)hipFree(p);
   for (hipEvent_t e : m->prof_ev) (void)hipEventDestroy(e);
   delete m->gen;
@@ -619,13 +635,14 @@ void prof_end(vt_model *m, int slot, hipStream_t hs) {
 }
 }  // namespace
 
-#define STEP(name, call)                                      \
+#define STEP_ON(name, st, call)                               \
   do {                                                        \
-    const int slot__ = prof_begin(m, name, (hipStream_t)s);   \
+    const int slot__ = prof_begin(m, name, (hipStream_t)(st)); \
     const int r__ = (call);                                   \
-    prof_end(m, slot__, (hipStream_t)s);                      \
+    prof_end(m, slot__, (hipStream_t)(st));                   \
     if (r__ != 0) return r__;                                 \
   } while (0)
+#define STEP(name, call) STEP_ON(name, s, call)
 
 extern "C" int vt_model_profile(vt_model *m, const char *filter) {
   if (!m) return VT_EINVAL;
@@ -659,6 +676,26 @@ extern "C" int vt_model_profile_read(vt_model *m, int idx, char *name_out, int n
   }
   return (int)m->prof_names.size();
 }
+// Pair k of the launches timed since vt_model_profile: launcher name, start and end in microseconds
+// after the first timed launch's start (pairs on the model's own stream included, so the overlap of
+// the two backward chains can be read off).  Returns the number of pairs (synchronises).
+extern "C" int vt_model_profile_timeline(vt_model *m, int k, char *name_out, int name_cap, float *start_us, float *end_us) {
+  if (!m) return VT_EINVAL;
+  if (hipDeviceSynchronize() != hipSuccess) return VT_EINVAL;
+  if (k >= 0 && (size_t)k < m->prof_used) {
+    float a = 0.f, b = 0.f;
+    (void)hipEventElapsedTime(&a, m->prof_ev[0], m->prof_ev[2 * k]);
+    (void)hipEventElapsedTime(&b, m->prof_ev[0], m->prof_ev[2 * k + 1]);
+    if (name_out && name_cap > 0) {
+      std::strncpy(name_out, m->prof_names[m->prof_name[k]].c_str(), name_cap - 1);
+      name_out[name_cap - 1] = 0;
+    }
+    if (start_us) *start_us = a * 1e3f;
+    if (end_us) *end_us = b * 1e3f;
+  }
+  return (int)m->prof_used;
+}
+
 extern "C" int vt_model_keep_internals(vt_model *m, int on) {
   if (!m) return VT_EINVAL;
   if (m->gen) return 0;  // the general step stores both maps anyway
@@ -675,6 +712,12 @@ extern "C" int vt_model_set_matmul_precision(vt_model *m, int bf16) {
   if (!m) return VT_EINVAL;
   if (!m->gen) return bf16 ? VT_EUNSUPPORTED : 0;  // the fused headline kernels are fp32 only
   m->gen->bf16 = bf16 != 0;
+  return 0;
+}
+
+extern "C" int vt_model_set_concurrency(vt_model *m, int on) {
+  if (!m) return VT_EINVAL;
+  m->concurrent = on != 0;
   return 0;
 }
 
@@ -740,9 +783,8 @@ static int forward_impl(vt_model *m, const float *d_images, int n, int group, fl
     STEP("bn_stats_finalize", vt_bn_stats_finalize(m->part, n, C2, P, (long)n * P, m->P_("proj.norm.running_mean"), m->P_("proj.norm.running_var"),
                                m->stat_pn, s));
   STEP("head_fwd", vt_head_fwd_grouped(m->z, m->stat_pn, m->P_("proj.norm.gamma"), m->P_("proj.norm.beta"), m->P_("fc.W"), m->P_("fc.b"),
-                    m->pooled, m->pool_idx, m->logits, m->probs, n, H, K, group, s));
-  if (d_probs && d_probs != m->probs)
-    HIPCHK(hipMemcpyAsync(d_probs, m->probs, (size_t)n * K * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)s));
+                    m->pooled, m->pool_idx, m->logits, d_probs ? d_probs : m->probs, n, H, K, group, s));
+  m->last_probs = d_probs ? d_probs : m->probs;  // written in place: the backward reads it there
   return 0;
 }
 
@@ -779,12 +821,22 @@ static int backward_main(vt_model *m, const int *d_labels, vt_stream s) {
   const long NL = (long)n * L;
   const int nrb = (int)((NL + RB - 1) / RB);
   hipStream_t hs = (hipStream_t)s;
+  // The side chain: fc weight gradient (needs only the head's delta), later the tokenizer / BatchNorm2D /
+  // conv backward (needs the projector's input delta and transformer_bwd_a's token delta).  Its
+  // launchers write buffers nothing on the caller's stream touches before join_side().
+  const bool fork = m->concurrent && m->side != nullptr;
+  const vt_stream t = fork ? (vt_stream)m->side : s;
   // head: softmax/fc/pool/relu backward + projector BatchNorm1D backward sums
-  STEP("head_bwd", vt_head_bwd(m->probs, d_labels, m->P_("fc.W"), m->pool_idx, m->z, m->stat_pn, m->P_("proj.norm.gamma"),
+  STEP("head_bwd", vt_head_bwd(m->last_probs, d_labels, m->P_("fc.W"), m->pool_idx, m->z, m->stat_pn, m->P_("proj.norm.gamma"),
                     m->P_("proj.norm.beta"), m->dlogits, m->du, m->part, n, H, K, s));
+  if (fork) {
+    HIPCHK(hipEventRecord(m->ev_head, hs));
+    HIPCHK(hipStreamWaitEvent(m->side, m->ev_head, 0));
+    m->side_open = true;
+  }
+  STEP_ON("fc_wgrad", t, vt_fc_wgrad(m->pooled, m->dlogits, m->G_("fc.W"), m->G_("fc.b"), m->sc_fc, n, Q, K, t));
   STEP("bn_bwd_finalize", vt_bn_bwd_finalize(m->part, n, C2, (long)n * P, m->P_("proj.norm.gamma"), m->stat_pn, m->z,
                            m->G_("proj.norm.gamma"), m->G_("proj.norm.beta"), m->coef_pn, s));
-  STEP("fc_wgrad", vt_fc_wgrad(m->pooled, m->dlogits, m->G_("fc.W"), m->G_("fc.b"), m->sc_fc, n, Q, K, s));
   // projector
   STEP("projector_bwd", vt_projector_bwd(m->du, m->coef_pn, m->conv, m->stat_bn, m->P_("bn.gamma"), m->P_("bn.beta"), m->pk,
                          m->P_("proj.linear1.W"), m->P_("proj.downsample.W"), m->pdx, m->dv, m->dk, m->gslab, n, P, s));
@@ -794,6 +846,19 @@ static int backward_main(vt_model *m, const int *d_labels, vt_stream s) {
                                 m->G_("proj.linear2.W"), m->sc_pt, NL, s));
   // transformer (targets = projector token delta, same bytes: visual_transformer.hpp:153-157)
   STEP("transformer_bwd_a", vt_transformer_bwd_a(m->o, m->pdt, m->s2, m->stat_n2, m->P_("tok.linear2.W"), m->part, m->dT0, NL, s));
+  if (fork) {
+    HIPCHK(hipEventRecord(m->ev_rows, hs));
+    HIPCHK(hipStreamWaitEvent(m->side, m->ev_rows, 0));
+  }
+  // tokenizer.backward2(projector token delta, projector input delta) + BatchNorm2D + conv, with
+  // partial sums of their own (norm2's are still waiting in m->part for their finalize)
+  STEP_ON("tokenizer_bwd", t, vt_tokenizer_bwd(m->conv, m->stat_bn, m->P_("bn.gamma"), m->P_("bn.beta"), m->tokstat, m->dT0,
+                         m->P_("tok.linear1.W"), m->P_("tok.linear1.b"), m->pdx, m->dy, m->part_side, n, P, t));
+  STEP_ON("bn_bwd_finalize", t, vt_bn_bwd_finalize(m->part_side, n, C1, (long)n * P, m->P_("bn.gamma"), m->stat_bn, m->conv,
+                           m->G_("bn.gamma"), m->G_("bn.beta"), m->coef_bn, t));
+  STEP_ON("conv3x3_wgrad", t, vt_conv3x3_wgrad(m->last_images, m->dy, m->coef_bn, m->gslab_conv, n, Ci, H, H, t));
+  VTCHK(vt_reduce_rows(m->gslab_conv, n, C1 * Ci * 9 + C1, C1 * Ci * 9 + C1, m->G_("conv.W"), s));  // queued
+  // feed-forward half of the transformer layer
   STEP("bn_bwd_finalize", vt_bn_bwd_finalize(m->part, nrb, D, NL, m->P_("norm2.gamma"), m->stat_n2, m->s2, m->G_("norm2.gamma"),
                            m->G_("norm2.beta"), m->coef_n2, s));
   STEP("transformer_bwd_b", vt_transformer_bwd_b(m->o, m->pdt, m->coef_n2, m->hdn, m->a, m->tok, m->stat_n1, m->P_("ffn.linear1.W"),
@@ -804,13 +869,6 @@ static int backward_main(vt_model *m, const int *d_labels, vt_stream s) {
   // (a reduction over zero slab rows writes the zeros: it rides in the fused reduction launch and keeps
   // memset nodes, which did not replay reliably, out of the captured step graph)
   VTCHK(reduce_rows(m->gslab, 0, D * D, D * D, m->G_("mha.o.W"), hs));
-  // tokenizer.backward2(projector token delta, projector input delta) + BatchNorm2D + conv
-  STEP("tokenizer_bwd", vt_tokenizer_bwd(m->conv, m->stat_bn, m->P_("bn.gamma"), m->P_("bn.beta"), m->tokstat, m->dT0,
-                         m->P_("tok.linear1.W"), m->P_("tok.linear1.b"), m->pdx, m->dy, m->part, n, P, s));
-  STEP("bn_bwd_finalize", vt_bn_bwd_finalize(m->part, n, C1, (long)n * P, m->P_("bn.gamma"), m->stat_bn, m->conv, m->G_("bn.gamma"),
-                           m->G_("bn.beta"), m->coef_bn, s));
-  STEP("conv3x3_wgrad", vt_conv3x3_wgrad(m->last_images, m->dy, m->coef_bn, m->gslab_conv, n, Ci, H, H, s));
-  VTCHK(vt_reduce_rows(m->gslab_conv, n, C1 * Ci * 9 + C1, C1 * Ci * 9 + C1, m->G_("conv.W"), s));
   return 0;
 }
 
@@ -830,6 +888,15 @@ static int backward_attention(vt_model *m, float *g_out, vt_stream s) {
   return 0;
 }
 
+// Makes the caller's stream wait for the side chain; every gradient slab is complete after it.
+static int join_side(vt_model *m, vt_stream s) {
+  if (!m->side_open) return 0;
+  m->side_open = false;
+  HIPCHK(hipEventRecord(m->ev_join, m->side));
+  HIPCHK(hipStreamWaitEvent((hipStream_t)s, m->ev_join, 0));
+  return 0;
+}
+
 static bool backward_ready(const vt_model *m) { return m && m->lastN >= 1 && m->last_images && !m->last_grouped; }
 
 extern "C" int vt_model_backward(vt_model *m, const int *d_labels, vt_stream s) {
@@ -837,6 +904,7 @@ extern "C" int vt_model_backward(vt_model *m, const int *d_labels, vt_stream s) 
   BatchScope batch(m);
   VTCHK(backward_main(m, d_labels, s));
   VTCHK(backward_attention(m, nullptr, s));
+  VTCHK(join_side(m, s));
   if (batch.on) STEP("reduce_rows", reduce_batch_flush((hipStream_t)s));
   m->attention_pending = false;
   return 0;
@@ -846,6 +914,7 @@ extern "C" int vt_model_backward_main(vt_model *m, const int *d_labels, vt_strea
   if (!backward_ready(m) || !d_labels) return VT_EINVAL;
   BatchScope batch(m);
   VTCHK(backward_main(m, d_labels, s));
+  VTCHK(join_side(m, s));
   if (batch.on) STEP("reduce_rows", reduce_batch_flush((hipStream_t)s));
   m->attention_pending = true;
   return 0;
@@ -938,7 +1007,7 @@ extern "C" int vt_model_graph_launch(vt_model *m, vt_stream s) {
 
 extern "C" int vt_model_metrics(vt_model *m, const int *d_labels, float *d_loss_sum, int *d_argmax, vt_stream s) {
   if (!m || m->lastN < 1) return VT_EINVAL;
-  return vt_metrics(m->probs, d_labels, m->lastN, m->K, d_loss_sum, d_argmax, s);
+  return vt_metrics(m->last_probs ? m->last_probs : m->probs, d_labels, m->lastN, m->K, d_loss_sum, d_argmax, s);
 }
 
 extern "C" long vt_model_read(vt_model *m, const char *name, float *host, long capacity) {
@@ -955,6 +1024,8 @@ extern "C" long vt_model_read(vt_model *m, const char *name, float *host, long c
   if (capacity < cnt) return VT_EINVAL;
   if (hipSetDevice(m->device) != hipSuccess) return VT_EINVAL;
   if (hipDeviceSynchronize() != hipSuccess) return VT_EINVAL;
-  if (hipMemcpy(host, it->second.first, cnt * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return VT_EINVAL;
+  const float *src = it->second.first;
+  if (src == m->probs && m->last_probs) src = m->last_probs;
+  if (hipMemcpy(host, src, cnt * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return VT_EINVAL;
   return cnt;
 }

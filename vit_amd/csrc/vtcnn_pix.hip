@@ -807,7 +807,7 @@ extern "C" int vt_tokenizer_fwd(const float *conv_out, const float *bn_stat, con
 extern "C" int vt_tokenizer_bwd(const float *conv_out, const float *bn_stat, const float *bn_gamma, const float *bn_beta,
                                 const float *tok_stat, const float *dT0, const float *w1, const float *b1,
                                 const float *pdx, float *dy, float *part, int N, int P, vt_stream s) {
-  if (N < 1 || P < 1) return VT_EUNSUPPORTED;
+  if (N < 1 || P < 1 || !tok_stat) return VT_EUNSUPPORTED;
   hipLaunchKernelGGL(k_tokenizer_bwd, dim3(N), dim3(TPB), 0, (hipStream_t)s, conv_out, bn_stat, bn_gamma, bn_beta,
                      tok_stat, dT0, w1, b1, pdx, dy, part, P);
   VT_CHECK_LAUNCH();

@@ -100,6 +100,11 @@ class VTCNN:
         self.training = bool(is_training)
         check(lib.vt_model_set_training(self._h, int(self.training)))
 
+    def set_concurrency(self, on):
+        """Issue the two independent halves of the backward on two streams (default) or on one
+        (vt_model_set_concurrency); same bytes either way."""
+        check(lib.vt_model_set_concurrency(self._h, int(bool(on))), "vt_model_set_concurrency")
+
     def set_matmul_precision(self, bf16):
         """General-shape models only: route the forward-type products through bf16 operands
         (vt_model_set_matmul_precision); parity drops from 1e-4 to 1e-2."""
@@ -254,6 +259,17 @@ class VTCNN:
             lib.vt_model_profile_read(self._h, k, name, 64, C.byref(ms), C.byref(cnt))
             if cnt.value:
                 out[name.value.decode()] = (ms.value, cnt.value)
+        return out
+
+    def profile_timeline(self):
+        """[(launcher, start_us, end_us)] of every launch timed since profile(), relative to the first."""
+        out = []
+        n = lib.vt_model_profile_timeline(self._h, -1, None, 0, None, None)
+        for k in range(max(n, 0)):
+            name = C.create_string_buffer(64)
+            a, b = C.c_float(), C.c_float()
+            lib.vt_model_profile_timeline(self._h, k, name, 64, C.byref(a), C.byref(b))
+            out.append((name.value.decode(), a.value, b.value))
         return out
 
     def read(self, name):
