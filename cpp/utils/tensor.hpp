@@ -181,6 +181,12 @@ class Tensor {
                        "Tensor::to_device");
     return dev_->ptr;
   }
+  // The device mirror itself (allocated on first use), without copying `data` into it: for buffers
+  // that a kernel fills and a later kernel reads.
+  float *device_buffer() const {
+    if (!dev_ || dev_->count != data.size()) dev_ = std::make_shared<vt_host::DeviceBuffer>(data.size());
+    return dev_->ptr;
+  }
   // Downloads the device mirror back into `data` (synchronises `stream`).
   void from_device(hipStream_t stream = nullptr) {
     if (!dev_) return;

@@ -387,6 +387,24 @@ int vt_gemm_f32(int transA, int transB, int M, int N, int K, float alpha, const 
 int vt_gemm_bf16_mfma(int transA, int transB, int M, int N, int K, float alpha, const float *A, int lda, long strideA,
                       const float *B, int ldb, long strideB, int accumulate, float *C, int ldc, long strideC,
                       const float *bias, int batch, float *workspace, long workspace_floats, vt_stream s);
+/* Tensor::softmax over the last axis (tensor_cpu.hpp:894-944), in place on S [rows, width], and
+ * Tensor::softmax_backward (tensor_cpu.hpp:946-950): da <- a * (da - sum_last(a * da)), in place on da. */
+int vt_softmax_rows(float *S, long rows, int width, vt_stream s);
+int vt_softmax_bwd_rows(const float *a, float *da, long rows, int width, vt_stream s);
+/* SelfAttention (layers/self_attention.hpp; the single-head layer the reference ships beside
+ * MultiHeadAttention; VTCNN itself never instantiates it).
+ * forward (:31-55): key = x.Wk, query = x.Wq (DenseLayer without bias), attn = softmax_last(key.query^T)
+ * (key times query-transposed, unscaled), out = attn.x.  x, out [B,T,D]; wk, wq [D,Dk]; key, query
+ * [B,T,Dk]; attn [B,T,T]: all device fp32, written by the call and kept by the caller for backward.
+ * backward (:57-136): g_wk, g_wq [D,Dk] (overwritten: DenseLayer::backward assigns, dense_layer.hpp:93),
+ * dx [B,T,D] = attn^T.delta + d_key.Wk^T + d_query.Wq^T.  ds [B,T,T], d_key, d_query [B,T,Dk]: scratch
+ * of the caller; workspace (may be NULL) as in vt_gemm_f32. */
+int vt_self_attention_fwd(const float *x, const float *wk, const float *wq, float *key, float *query, float *attn,
+                          float *out, int B, int T, int D, int Dk, vt_stream s);
+int vt_self_attention_bwd(const float *x, const float *wk, const float *wq, const float *key, const float *query,
+                          const float *attn, const float *delta, float *ds, float *d_key, float *d_query, float *g_wk,
+                          float *g_wq, float *dx, float *workspace, long workspace_floats, int B, int T, int D, int Dk,
+                          vt_stream s);
 /* update_weights + SGD::update (utils/optimizer.hpp:22-28) over n floats. */
 int vt_sgd_update(float *w, float *g, int n, float lr, float divisor, int zero_grad, vt_stream s);
 /* Textbook Adam over the arena.  NOT in the reference (utils/optimizer.hpp has SGD only):

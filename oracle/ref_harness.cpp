@@ -419,11 +419,41 @@ static int cmd_images(int argc, char **argv)
   return 0;
 }
 
+// selfattn <out.bundle> <B> <T> <D> <Dk> <seed>: SelfAttention::forward / backward
+// (layers/self_attention.hpp:31-136) on a uniform random input and delta; dumps the two weight
+// matrices, the output, the weight gradients and the input delta.
+static int cmd_selfattn(int argc, char **argv)
+{
+  const int B = std::atoi(argv[3]), T = std::atoi(argv[4]), D = std::atoi(argv[5]), Dk = std::atoi(argv[6]);
+  const unsigned seed = (unsigned)std::atoi(argv[7]);
+  Tensor::set_seed(42);
+  SelfAttention sa(D, Dk);
+  std::mt19937 gen(seed);
+  std::uniform_real_distribution<float> dist(-1.0f, 1.0f);
+  Tensor x({B, T, D}), delta({B, T, D});
+  for (auto &v : x.data)
+    v = dist(gen);
+  for (auto &v : delta.data)
+    v = dist(gen);
+  Tensor out = sa.forward({x})[0];
+  sa.backward(&delta);
+  Bundle b(argv[2]);
+  b.put("x", x);
+  b.put("delta", delta);
+  b.put("key.W", sa.key_linear->weights);
+  b.put("query.W", sa.query_linear->weights);
+  b.put("out", out);
+  b.put("g.key.W", sa.key_linear->grad_weights);
+  b.put("g.query.W", sa.query_linear->grad_weights);
+  b.put("dx", sa.input_deltas);
+  return 0;
+}
+
 int main(int argc, char **argv)
 {
   if (argc < 2)
   {
-    std::fprintf(stderr, "usage: ref_harness step|dp|kat|blood|bench|images ...\n");
+    std::fprintf(stderr, "usage: ref_harness step|dp|kat|blood|bench|images|selfattn ...\n");
     return 2;
   }
   std::string c = argv[1];
@@ -441,6 +471,8 @@ int main(int argc, char **argv)
       return cmd_bench(argc, argv);
     if (c == "images" && argc == 4)
       return cmd_images(argc, argv);
+    if (c == "selfattn" && argc == 8)
+      return cmd_selfattn(argc, argv);
   }
   catch (const std::exception &e)
   {

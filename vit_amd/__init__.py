@@ -6,6 +6,6 @@ Model / Trainer / DataLoader interface on top of it.  There is no CPU fallback: 
 `vit_amd.engine` without the built library raises.
 """
 from . import _lib  # noqa: F401
-from .engine import VTCNN, Dims, DataLoader, Trainer, load_dataset  # noqa: F401
+from .engine import VTCNN, Dims, DataLoader, Trainer, SelfAttention, load_dataset  # noqa: F401
 
-__all__ = ["VTCNN", "Dims", "DataLoader", "Trainer", "load_dataset"]
+__all__ = ["VTCNN", "Dims", "DataLoader", "Trainer", "SelfAttention", "load_dataset"]

@@ -108,6 +108,10 @@ SIGNATURES = {
     "vt_reduce_rows": (i, [p, l, i, i, p, p]),
     "vt_gemm_f32": (i, [i, i, i, i, i, f, p, i, C.c_long, p, i, C.c_long, i, p, i, C.c_long, p, i, p, C.c_long, p]),
     "vt_gemm_bf16_mfma": (i, [i, i, i, i, i, f, p, i, C.c_long, p, i, C.c_long, i, p, i, C.c_long, p, i, p, C.c_long, p]),
+    "vt_softmax_rows": (i, [p, l, i, p]),
+    "vt_softmax_bwd_rows": (i, [p, p, l, i, p]),
+    "vt_self_attention_fwd": (i, [p, p, p, p, p, p, p, i, i, i, i, p]),
+    "vt_self_attention_bwd": (i, [p, p, p, p, p, p, p, p, p, p, p, p, p, p, l, i, i, i, i, p]),
     "vt_sgd_update": (i, [p, p, i, f, f, i, p]),
     "vt_adam_update": (i, [p, p, p, p, i, f, f, f, f, i, f, p]),
     "vt_projector_tokens_bwd": (i, [p] * 8 + [l, p]),

@@ -872,3 +872,56 @@ int gen_backward(GenModel *g, const float *arena, const vt_layout *lo, float *gr
 }
 
 }  // namespace vt
+
+// ---------------------------------------------------------------------------------------------
+// Stand-alone launchers over the same kernels: Tensor::softmax / softmax_backward over the last axis
+// and the reference's single-head SelfAttention layer.
+// ---------------------------------------------------------------------------------------------
+extern "C" int vt_softmax_rows(float *S, long rows, int width, vt_stream s) {
+  if (!S || rows < 1 || width < 1) return VT_EINVAL;
+  return softmax_rows(S, rows, width, (hipStream_t)s);
+}
+
+extern "C" int vt_softmax_bwd_rows(const float *a, float *da, long rows, int width, vt_stream s) {
+  if (!a || !da || rows < 1 || width < 1) return VT_EINVAL;
+  return softmax_bwd_rows(a, da, rows, width, (hipStream_t)s);
+}
+
+// SelfAttention::forward (layers/self_attention.hpp:31-55): key = x.Wk, query = x.Wq (no bias),
+// attn = softmax_last(key . query^T) (key times query-transposed, unscaled), out = attn . x.
+extern "C" int vt_self_attention_fwd(const float *x, const float *wk, const float *wq, float *key, float *query, float *attn,
+                                     float *out, int B, int T, int D, int Dk, vt_stream s) {
+  if (!x || !wk || !wq || !key || !query || !attn || !out || B < 1 || T < 1 || D < 1 || Dk < 1) return VT_EINVAL;
+  const long TT = (long)T * T, TD = (long)T * D, TK = (long)T * Dk;
+  VTG(vt_gemm_f32(0, 0, B * T, Dk, D, 1.f, x, D, 0, wk, Dk, 0, 0, key, Dk, 0, nullptr, 1, nullptr, 0, s));
+  VTG(vt_gemm_f32(0, 0, B * T, Dk, D, 1.f, x, D, 0, wq, Dk, 0, 0, query, Dk, 0, nullptr, 1, nullptr, 0, s));
+  VTG(vt_gemm_f32(0, 1, T, T, Dk, 1.f, key, Dk, TK, query, Dk, TK, 0, attn, T, TT, nullptr, B, nullptr, 0, s));
+  VTG(softmax_rows(attn, (long)B * T, T, (hipStream_t)s));
+  return vt_gemm_f32(0, 0, T, D, T, 1.f, attn, T, TT, x, D, TD, 0, out, D, TD, nullptr, B, nullptr, 0, s);
+}
+
+// SelfAttention::backward (layers/self_attention.hpp:57-136) from the forward's key / query / attn:
+//   d_attn = delta . x^T;  dx = attn^T . delta;  ds = softmax_backward(attn, d_attn)
+//   d_key = ds . query;  d_query = ds^T . key  (= (key^T . ds)^T, :117-119)
+//   gWk = x^T . d_key, gWq = x^T . d_query (DenseLayer::backward, dense_layer.hpp:92-93)
+//   dx += d_key . Wk^T + d_query . Wq^T  (:129-135)
+// ds [B,T,T], d_key and d_query [B*T,Dk] are caller-provided scratch; workspace (may be NULL) lets the two
+// weight-gradient contractions over B*T rows be cut along their long axis.
+extern "C" int vt_self_attention_bwd(const float *x, const float *wk, const float *wq, const float *key, const float *query,
+                                     const float *attn, const float *delta, float *ds, float *d_key, float *d_query,
+                                     float *g_wk, float *g_wq, float *dx, float *workspace, long workspace_floats, int B,
+                                     int T, int D, int Dk, vt_stream s) {
+  if (!x || !wk || !wq || !key || !query || !attn || !delta || !ds || !d_key || !d_query || !g_wk || !g_wq || !dx ||
+      B < 1 || T < 1 || D < 1 || Dk < 1)
+    return VT_EINVAL;
+  const long TT = (long)T * T, TD = (long)T * D, TK = (long)T * Dk;
+  VTG(vt_gemm_f32(0, 1, T, T, D, 1.f, delta, D, TD, x, D, TD, 0, ds, T, TT, nullptr, B, nullptr, 0, s));
+  VTG(vt_gemm_f32(1, 0, T, D, T, 1.f, attn, T, TT, delta, D, TD, 0, dx, D, TD, nullptr, B, nullptr, 0, s));
+  VTG(softmax_bwd_rows(attn, ds, (long)B * T, T, (hipStream_t)s));
+  VTG(vt_gemm_f32(0, 0, T, Dk, T, 1.f, ds, T, TT, query, Dk, TK, 0, d_key, Dk, TK, nullptr, B, nullptr, 0, s));
+  VTG(vt_gemm_f32(1, 0, T, Dk, T, 1.f, ds, T, TT, key, Dk, TK, 0, d_query, Dk, TK, nullptr, B, nullptr, 0, s));
+  VTG(vt_gemm_f32(1, 0, D, Dk, B * T, 1.f, x, D, 0, d_key, Dk, 0, 0, g_wk, Dk, 0, nullptr, 1, workspace, workspace_floats, s));
+  VTG(vt_gemm_f32(1, 0, D, Dk, B * T, 1.f, x, D, 0, d_query, Dk, 0, 0, g_wq, Dk, 0, nullptr, 1, workspace, workspace_floats, s));
+  VTG(vt_gemm_f32(0, 1, B * T, D, Dk, 1.f, d_key, Dk, 0, wk, Dk, 0, 1, dx, D, 0, nullptr, 1, nullptr, 0, s));
+  return vt_gemm_f32(0, 1, B * T, D, Dk, 1.f, d_query, Dk, 0, wq, Dk, 0, 1, dx, D, 0, nullptr, 1, nullptr, 0, s);
+}

@@ -297,6 +297,74 @@ class VTCNN:
 # ---------------------------------------------------------------------------------------------
 # Data path (reference utils/load_dataset.hpp)
 # ---------------------------------------------------------------------------------------------
+class SelfAttention:
+    """Host mirror of the reference's SelfAttention layer (layers/self_attention.hpp): forward(x),
+    backward(delta), get_input_deltas(), update_weights(batch_size), zero_grad().  Weights are the two
+    bias-free DenseLayers' [channels, attn_dim] matrices, Xavier-uniform (dense_layer.hpp:22-23); a fresh
+    layer draws them with numpy, so reference weights come in through set_parameters().  Like the
+    reference layer, update_weights does nothing unless an optimizer was attached to the layer itself
+    (self_attention.hpp:138-145): attached_optimizer=True stands for that."""
+
+    def __init__(self, channels, attn_dim, rng_seed=42, attached_optimizer=False, lr=0.001):
+        self.D, self.Dk, self.lr, self.attached = int(channels), int(attn_dim), float(lr), bool(attached_optimizer)
+        limit = np.float32(math.sqrt(6.0 / (channels + attn_dim)))
+        g = np.random.default_rng(rng_seed)
+        self.wq = torch.from_numpy(g.uniform(-limit, limit, size=(channels, attn_dim)).astype(np.float32)).cuda()
+        self.wk = torch.from_numpy(g.uniform(-limit, limit, size=(channels, attn_dim)).astype(np.float32)).cuda()
+        self.g_wq, self.g_wk = torch.zeros_like(self.wq), torch.zeros_like(self.wk)
+        self._x = None
+
+    def set_parameters(self, key_w, query_w):
+        self.wk = torch.as_tensor(key_w, dtype=torch.float32).contiguous().cuda()
+        self.wq = torch.as_tensor(query_w, dtype=torch.float32).contiguous().cuda()
+        assert tuple(self.wk.shape) == (self.D, self.Dk) and tuple(self.wq.shape) == (self.D, self.Dk)
+
+    def forward(self, x):
+        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 3 and x.shape[2] == self.D
+        B, T, D = x.shape
+        dev = x.device
+        self._x = x
+        self._key = torch.empty((B, T, self.Dk), device=dev)
+        self._query = torch.empty((B, T, self.Dk), device=dev)
+        self._attn = torch.empty((B, T, T), device=dev)
+        out = torch.empty((B, T, D), device=dev)
+        pv = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+        check(lib.vt_self_attention_fwd(pv(x), pv(self.wk), pv(self.wq), pv(self._key), pv(self._query), pv(self._attn),
+                                        pv(out), B, T, D, self.Dk, _stream_handle()), "vt_self_attention_fwd")
+        return out
+
+    def backward(self, delta):
+        if self._x is None:
+            raise RuntimeError("SelfAttention: No hay fuente de delta para backward.")
+        x = self._x
+        B, T, D = x.shape
+        assert delta.is_cuda and delta.dtype == torch.float32 and delta.is_contiguous() and delta.shape == x.shape
+        dev = x.device
+        ds = torch.empty((B, T, T), device=dev)
+        dkey = torch.empty((B, T, self.Dk), device=dev)
+        dquery = torch.empty((B, T, self.Dk), device=dev)
+        self._dx = torch.empty((B, T, D), device=dev)
+        ws = torch.empty(1 << 20, device=dev)
+        pv = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+        check(lib.vt_self_attention_bwd(pv(x), pv(self.wk), pv(self.wq), pv(self._key), pv(self._query), pv(self._attn),
+                                        pv(delta), pv(ds), pv(dkey), pv(dquery), pv(self.g_wk), pv(self.g_wq), pv(self._dx),
+                                        pv(ws), ws.numel(), B, T, D, self.Dk, _stream_handle()), "vt_self_attention_bwd")
+
+    def get_input_deltas(self):
+        return self._dx
+
+    def update_weights(self, batch_size):
+        if not self.attached:
+            return
+        for w, g in ((self.wq, self.g_wq), (self.wk, self.g_wk)):
+            check(lib.vt_sgd_update(C.c_void_p(w.data_ptr()), C.c_void_p(g.data_ptr()), w.numel(), self.lr, float(batch_size),
+                                    0, _stream_handle()), "vt_sgd_update")
+
+    def zero_grad(self):
+        self.g_wq.zero_()
+        self.g_wk.zero_()
+
+
 class Dataset:
     def __init__(self, images, labels, images_u8=None):
         self.images = images  # float32 [S, rows*cols] = u8 / 255.0f
