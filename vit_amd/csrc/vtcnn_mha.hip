@@ -60,6 +60,11 @@ __device__ __forceinline__ void split2(float a, float b, unsigned &hi, unsigned 
   const floatx2 r = {a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u)};
   lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
 }
+__device__ __forceinline__ void split2(floatx2 f, unsigned &hi, unsigned &lo) {
+  hi = __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2));
+  const floatx2 r = f - floatx2{__uint_as_float(hi << 16), __uint_as_float(hi & 0xffff0000u)};
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
+}
 __device__ __forceinline__ bf16x8 as_bf8(uint4 v) { return __builtin_bit_cast(bf16x8, v); }
 __device__ __forceinline__ floatx16 mfma_bf(bf16x8 a, bf16x8 b, floatx16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
@@ -87,7 +92,7 @@ __global__ __launch_bounds__(64 * MR_WAVES) void k_mha_rows(const float *__restr
                                                             float *__restrict__ st, int T, long rows, int groups,
                                                             int nsplit) {
   static_assert(HD == 16 && D == 32 && MR_WAVES == 4, "tile shapes are written for head_dim 16, token channels 32");
-  __shared__ __attribute__((aligned(16))) StageBuf sb[2];
+  __shared__ __attribute__((aligned(16))) StageBuf sb[3];
   __shared__ float sred[MR_WAVES];
   const int itiles = (T + 31) / 32, iblocks = (itiles + MR_WAVES - 1) / MR_WAVES;
   int bi = blockIdx.x;
@@ -126,12 +131,14 @@ __global__ __launch_bounds__(64 * MR_WAVES) void k_mha_rows(const float *__restr
   const int xr = tid >> 3, xc = (tid & 7) * 4, t2 = tid & 127, qr = t2 >> 2, qc = (t2 & 3) * 4;
   const float *__restrict__ gx = tok + gbase * D + xc;
   const float *__restrict__ gq = (tid < 128 ? Qm : Vm) + gbase * D + h * HD + qc;
-  float4 rx, rq;
-  auto gload = [&](int jt) {
+  // two register sets: a tile's global loads are issued two sweep steps before it is needed in LDS
+  // (one step of arithmetic is shorter than a trip to memory)
+  float4 rxa, rqa, rxb, rqb;
+  auto gload = [&](int jt, float4 &rx, float4 &rq) {
     rx = *reinterpret_cast<const float4 *>(gx + (long)min(jt + xr, T - 1) * D);
     rq = *reinterpret_cast<const float4 *>(gq + (long)min(jt + qr, T - 1) * D);
   };
-  auto sstore = [&](int buf) {
+  auto sstore = [&](int buf, const float4 &rx, const float4 &rq) {
     StageBuf &B = sb[buf];
     uint2 hv, lv;
     split2(rq.x, rq.y, hv.x, lv.x);
@@ -146,7 +153,10 @@ __global__ __launch_bounds__(64 * MR_WAVES) void k_mha_rows(const float *__restr
     B.xl[(xc + 0) * XT + xr] = (unsigned short)lv.x; B.xl[(xc + 1) * XT + xr] = (unsigned short)(lv.x >> 16);
     B.xl[(xc + 2) * XT + xr] = (unsigned short)lv.y; B.xl[(xc + 3) * XT + xr] = (unsigned short)(lv.y >> 16);
   };
-  if (ntile > 0) gload(jbeg);
+  if (ntile > 0) {
+    gload(jbeg, rxa, rqa);
+    gload(jbeg + 32 * min(1, ntile - 1), rxb, rqb);
+  }
 
   kn2 += __shfl_xor(kn2, 32);
   // largest |Q_j|^2 of the whole group (identical in every split and row tile)
@@ -162,7 +172,11 @@ __global__ __launch_bounds__(64 * MR_WAVES) void k_mha_rows(const float *__restr
   }
   qn2 = wave_max(qn2);
   if (lane == 0) sred[wave] = qn2;
-  if (ntile > 0) sstore(0);
+  if (ntile > 0) {
+    sstore(0, rxa, rqa);
+    sstore(1, rxb, rqb);
+    gload(jbeg + 32 * min(2, ntile - 1), rxa, rqa);  // stored by sweep step 0
+  }
   __syncthreads();
   qn2 = fmaxf(fmaxf(sred[0], sred[1]), fmaxf(sred[2], sred[3]));
   // e = exp(scale * s - mx) with mx = scale |K_i| max|Q_j| >= every scaled score of row i, evaluated
@@ -173,74 +187,87 @@ __global__ __launch_bounds__(64 * MR_WAVES) void k_mha_rows(const float *__restr
   floatx16 accY, accW;
 #pragma unroll
   for (int v = 0; v < 16; ++v) { accY[v] = 0.f; accW[v] = 0.f; }
-  float ssum = 0.f, tsum = 0.f;
+  floatx2 ssum2 = {0.f, 0.f}, tsum2 = {0.f, 0.f};
+  const floatx2 sc2v = {sc2, sc2}, nmxv = {nmx, nmx};
 
-  for (int k = 0; k < ntile; ++k) {
-    const int jt = jbeg + 32 * k, b = k & 1;
-    gload(jbeg + 32 * min(k + 1, ntile - 1));  // unconditional: the last one re-reads the final tile
-    const StageBuf &B = sb[b];
-    // transposed score and dattn tiles: rows j (this lane: j = c) x columns i, contraction over the 16
-    // head columns = one matrix instruction per partial product
+  // With one j range per row tile a SIMD holds a single wave, so the matrix pipe and the vector pipe
+  // only overlap if independent work of both kinds sits next to each other in that wave's instruction
+  // stream.  The sweep is therefore software-pipelined over three staged tiles: while the vector
+  // pipe turns tile k's scores into softmax numerators, the matrix pipe forms tile k+1's scores, and
+  // the second-stage products of one half tile run beside the vector work of the other half.
+  // Transposed score and dattn tiles of one staged tile: rows j (this lane: j = c) x columns i,
+  // contraction over the 16 head columns = one matrix instruction per partial product.
+  auto scores = [&](const StageBuf &B, floatx16 &aS, floatx16 &aD) {
     const bf16x8 qh = as_bf8(*reinterpret_cast<const uint4 *>(B.qh + c * HD + 8 * hh));
     const bf16x8 ql = as_bf8(*reinterpret_cast<const uint4 *>(B.ql + c * HD + 8 * hh));
     const bf16x8 vh = as_bf8(*reinterpret_cast<const uint4 *>(B.vh + c * HD + 8 * hh));
     const bf16x8 vl = as_bf8(*reinterpret_cast<const uint4 *>(B.vl + c * HD + 8 * hh));
-    floatx16 accS, accD;
 #pragma unroll
-    for (int v = 0; v < 16; ++v) { accS[v] = 0.f; accD[v] = 0.f; }
-    accS = mfma_bf(ql, kbl, accS);  // smallest partial product first
-    accS = mfma_bf(ql, kbh, accS);
-    accS = mfma_bf(qh, kbl, accS);
-    accS = mfma_bf(qh, kbh, accS);
-    accD = mfma_bf(vl, dbh, accD);
-    accD = mfma_bf(vh, dbl, accD);
-    accD = mfma_bf(vh, dbh, accD);
+    for (int v = 0; v < 16; ++v) { aS[v] = 0.f; aD[v] = 0.f; }
+    aS = mfma_bf(ql, kbl, aS);  // smallest partial product first
+    aD = mfma_bf(vl, dbh, aD);
+    aS = mfma_bf(ql, kbh, aS);
+    aD = mfma_bf(vh, dbl, aD);
+    aS = mfma_bf(qh, kbl, aS);
+    aD = mfma_bf(vh, dbh, aD);
+    aS = mfma_bf(qh, kbh, aS);
+  };
+  // one sweep step: tile k's scores are in (aS, aD); tile k+1's go to (nS, nD)
+  // (rxs, rqs): tile k+2, loaded one step ago, goes to LDS at the end of this step; (rxl, rql) receives tile k+3
+  auto step = [&](int k, const floatx16 &aS, const floatx16 &aD, floatx16 &nS, floatx16 &nD, const float4 &rxs,
+                  const float4 &rqs, float4 &rxl, float4 &rql) {
+    const int jt = jbeg + 32 * k;
+    gload(jbeg + 32 * min(k + 3, ntile - 1), rxl, rql);  // unconditional: past the end it re-reads the final tile
+    scores(sb[(k + 1) % 3], nS, nD);           // (past the end: the final tile again, result unused)
+    const StageBuf &B = sb[k % 3];
     // softmax numerators e and e * dattn, then their hi / lo halves as the B operands of the second
     // stage: registers 0..7 of lane half hh are tile rows {4hh..4hh+3, 8+4hh..}, registers 8..15 the
-    // same + 16; the token operand below presents its rows in that same order
-    uint4 eh[2], el[2], fh[2], fl[2];
+    // same + 16; the token operand presents its rows in that same order
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       unsigned ph[4], pl[4], qh4[4], ql4[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        float ev[2], ed[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int v = 8 * half + 2 * q + u;
-          float e = __builtin_amdgcn_exp2f(fmaf(accS[v], sc2, nmx));
-          if (!FULL) e = (jt + acc_row(v, hh) < T) ? e : 0.f;
-          ev[u] = e;
-          ed[u] = e * accD[v];
-          ssum += e;
-          tsum += ed[u];
+        // two adjacent accumulator registers at a time: the multiply-adds, products, sums and the
+        // hi / lo remainders are packed fp32 instructions (two lanes' worth of work per issue slot)
+        const int v = 8 * half + 2 * q;
+        const floatx2 t = floatx2{aS[v], aS[v + 1]} * sc2v + nmxv;
+        floatx2 e = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+        if (!FULL) {
+          e.x = (jt + acc_row(v, hh) < T) ? e.x : 0.f;
+          e.y = (jt + acc_row(v + 1, hh) < T) ? e.y : 0.f;
         }
-        split2(ev[0], ev[1], ph[q], pl[q]);
-        split2(ed[0], ed[1], qh4[q], ql4[q]);
+        const floatx2 ed = e * floatx2{aD[v], aD[v + 1]};
+        ssum2 += e;
+        tsum2 += ed;
+        split2(e, ph[q], pl[q]);
+        split2(ed, qh4[q], ql4[q]);
       }
-      eh[half] = make_uint4(ph[0], ph[1], ph[2], ph[3]);
-      el[half] = make_uint4(pl[0], pl[1], pl[2], pl[3]);
-      fh[half] = make_uint4(qh4[0], qh4[1], qh4[2], qh4[3]);
-      fl[half] = make_uint4(ql4[0], ql4[1], ql4[2], ql4[3]);
-    }
-    // Y^T[d][i] += sum_j X[j][d] e^T[j][i],  W^T[d][i] += sum_j X[j][d] (e*dattn)^T[j][i]: this lane owns
-    // feature d = c; two instructions (16 rows each) per partial product
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      const unsigned short *ph = B.xh + c * XT + 16 * half + 4 * hh, *pl = B.xl + c * XT + 16 * half + 4 * hh;
-      const uint2 h0 = *reinterpret_cast<const uint2 *>(ph), h1 = *reinterpret_cast<const uint2 *>(ph + 8);
-      const uint2 l0 = *reinterpret_cast<const uint2 *>(pl), l1 = *reinterpret_cast<const uint2 *>(pl + 8);
+      const uint4 eh = make_uint4(ph[0], ph[1], ph[2], ph[3]), el = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+      const uint4 fh = make_uint4(qh4[0], qh4[1], qh4[2], qh4[3]), fl = make_uint4(ql4[0], ql4[1], ql4[2], ql4[3]);
+      // Y^T[d][i] += sum_j X[j][d] e^T[j][i],  W^T[d][i] += sum_j X[j][d] (e*dattn)^T[j][i]: this lane owns
+      // feature d = c; one instruction (16 rows) per partial product and half
+      const unsigned short *xph = B.xh + c * XT + 16 * half + 4 * hh, *xpl = B.xl + c * XT + 16 * half + 4 * hh;
+      const uint2 h0 = *reinterpret_cast<const uint2 *>(xph), h1 = *reinterpret_cast<const uint2 *>(xph + 8);
+      const uint2 l0 = *reinterpret_cast<const uint2 *>(xpl), l1 = *reinterpret_cast<const uint2 *>(xpl + 8);
       const bf16x8 xh = as_bf8(make_uint4(h0.x, h0.y, h1.x, h1.y)), xl = as_bf8(make_uint4(l0.x, l0.y, l1.x, l1.y));
-      accY = mfma_bf(xl, as_bf8(eh[half]), accY);
-      accY = mfma_bf(xh, as_bf8(el[half]), accY);
-      accY = mfma_bf(xh, as_bf8(eh[half]), accY);
-      accW = mfma_bf(xl, as_bf8(fh[half]), accW);
-      accW = mfma_bf(xh, as_bf8(fl[half]), accW);
-      accW = mfma_bf(xh, as_bf8(fh[half]), accW);
+      accY = mfma_bf(xl, as_bf8(eh), accY);
+      accW = mfma_bf(xl, as_bf8(fh), accW);
+      accY = mfma_bf(xh, as_bf8(el), accY);
+      accW = mfma_bf(xh, as_bf8(fl), accW);
+      accY = mfma_bf(xh, as_bf8(eh), accY);
+      accW = mfma_bf(xh, as_bf8(fh), accW);
     }
-    sstore(b ^ 1);
+    sstore((k + 2) % 3, rxs, rqs);  // the buffer of tile k-1: every wave left it before the last barrier
     __syncthreads();
+  };
+  floatx16 s0, d0, s1, d1;
+  if (ntile > 0) scores(sb[0], s0, d0);
+  for (int k = 0; k < ntile; k += 2) {
+    step(k, s0, d0, s1, d1, rxa, rqa, rxb, rqb);
+    if (k + 1 < ntile) step(k + 1, s1, d1, s0, d0, rxb, rqb, rxa, rqa);
   }
+  float ssum = ssum2.x + ssum2.y, tsum = tsum2.x + tsum2.y;
   ssum += __shfl_xor(ssum, 32);
   tsum += __shfl_xor(tsum, 32);
   if (ok_i) {
