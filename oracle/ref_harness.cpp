@@ -419,6 +419,48 @@ static int cmd_images(int argc, char **argv)
   return 0;
 }
 
+// traj <out.bundle> <N> <K> <seed> <steps>: `steps` training steps (forward, backward,
+// update_weights(32), zero_grad: utils/trainer.hpp:41-56) on synthetic batches seeded seed, seed+1, ...
+// from the seed-42 model; dumps the loss and arg-max labels of every step and the final weights.
+static int cmd_traj(int argc, char **argv)
+{
+  const int N = std::atoi(argv[3]);
+  Hyper h;
+  hyper_from_env(h);
+  h.num_classes = std::atoi(argv[4]);
+  const unsigned seed = (unsigned)std::atoi(argv[5]);
+  const int steps = std::atoi(argv[6]);
+  const int K = h.num_classes;
+  std::unique_ptr<VTCNN> mp(make_model(h));
+  VTCNN &m = *mp;
+  Bundle b(argv[2]);
+  put_all(b, "p0", m, false);
+  std::vector<float> losses;
+  std::vector<int> labels_all;
+  for (int t = 0; t < steps; ++t)
+  {
+    std::vector<float> xs;
+    std::vector<int> ys;
+    synth_batch(N, h.image_channels, h.input_dim * h.input_dim, K, seed + (unsigned)t, xs, ys);
+    Tensor X({N, h.image_channels, h.input_dim, h.input_dim}, xs);
+    std::vector<float> yf(ys.begin(), ys.end());
+    Tensor yoh = Tensor::one_hot(Tensor({N, 1}, yf), K);
+    b.put("traj.x" + std::to_string(t), X);
+    b.puti("traj.y" + std::to_string(t), ys);
+    Tensor preds = m.forward(X);
+    losses.push_back(Tensor::compute_loss(preds, yoh));
+    for (int a : Tensor::argmax_batch(preds))
+      labels_all.push_back(a);
+    m.backward(yoh);
+    m.update_weights(32.0f);
+    m.zero_grad();
+  }
+  b.putf("traj.loss", losses);
+  b.puti("traj.argmax", labels_all, {steps, N});
+  put_all(b, "pT", m, false);
+  return 0;
+}
+
 // selfattn <out.bundle> <B> <T> <D> <Dk> <seed>: SelfAttention::forward / backward
 // (layers/self_attention.hpp:31-136) on a uniform random input and delta; dumps the two weight
 // matrices, the output, the weight gradients and the input delta.
@@ -453,7 +495,7 @@ int main(int argc, char **argv)
 {
   if (argc < 2)
   {
-    std::fprintf(stderr, "usage: ref_harness step|dp|kat|blood|bench|images|selfattn ...\n");
+    std::fprintf(stderr, "usage: ref_harness step|dp|kat|blood|bench|images|traj|selfattn ...\n");
     return 2;
   }
   std::string c = argv[1];
@@ -471,6 +513,8 @@ int main(int argc, char **argv)
       return cmd_bench(argc, argv);
     if (c == "images" && argc == 4)
       return cmd_images(argc, argv);
+    if (c == "traj" && argc == 7)
+      return cmd_traj(argc, argv);
     if (c == "selfattn" && argc == 8)
       return cmd_selfattn(argc, argv);
   }

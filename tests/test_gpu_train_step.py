@@ -98,6 +98,42 @@ def test_train_step_vs_reference(fx, n, k):
     assert np.array_equal(am.cpu().numpy(), g["eval.argmax"])
 
 
+def test_twelve_step_trajectory_vs_reference():
+    """Twelve consecutive training steps from the seed-42 initialisation on the batches the real
+    reference was given (fixture from `ref_harness traj`): per-step loss within 1e-4, every arg-max
+    label identical, and the weight CHANGE over the run (the weights themselves barely move at
+    lr = 0.001) within 1e-2 of the reference's change per tensor.  That bound is the fixture's own
+    uncertainty: the float64 build of the CPU restatement (exact arithmetic, same batches) ends 1.7e-3
+    (conv.W) to 4.7e-3 (proj.linear3.W) of the change away from the reference's fp32 result, and this
+    path lands at the same distances (1.6e-3, 5.6e-3): twelve steps amplify the reference's rounding."""
+    import torch
+    from vit_amd import VTCNN, Dims
+    g = load_golden("traj_n32_k8_t12.npz")
+    m = VTCNN(Dims(num_classes=8), max_batch=32, seed=42)
+    p0 = m.get_arena().copy()
+    for t in range(12):
+        x = torch.from_numpy(g["traj.x_u8"][t].astype(np.float32) / np.float32(255.0)).cuda()
+        y = torch.from_numpy(g["traj.y"][t]).cuda()
+        m.forward(x)
+        loss, am = m.metrics(y)
+        assert abs(float(loss) / 32.0 - float(g["traj.loss"][t])) < TOL * abs(float(g["traj.loss"][t])), t
+        assert np.array_equal(am.cpu().numpy(), g["traj.argmax"][t]), t
+        m.backward(y)
+        m.update_weights(32.0)
+    pT = m.get_arena()
+    bad = []
+    for name, (off, size, shape, kind) in m.layout.tensors.items():
+        ref = g["pT." + name].ravel().astype(np.float64)
+        if kind == 1:
+            assert np.array_equal(pT[off:off + size], p0[off:off + size]), name  # frozen tokenizer
+            continue
+        moved = np.abs(ref - p0[off:off + size]).max()
+        err = np.abs(pT[off:off + size] - ref).max()
+        if moved > 0 and not err <= 1e-2 * moved + 2e-6 * np.abs(ref).max():
+            bad.append((name, err, moved))
+    assert not bad, bad
+
+
 def _routing_from_gpu(m, n):
     """Max-pool slots and the effective ReLU mask the HIP path used in its last backward."""
     slots = m.read("fwd.pool_idx").view(np.uint8)[:n * 3136].copy()

@@ -106,3 +106,23 @@ def test_blood_checkpoint_labels():
         o.forward(arena, imgs[order[s:s + 32]], training=False)
         pred.extend(o.argmax().tolist())
     assert np.array_equal(np.array(pred), g["pred"])
+
+
+def test_twelve_step_trajectory_matches_reference():
+    """Twelve consecutive training steps from the seed-42 model on the reference's own batches
+    (tools/make_golden.py, `ref_harness traj`): the restatement follows the real reference step after
+    step -- per-step loss, every predicted label, and the weights it ends on."""
+    g = load_golden("traj_n32_k8_t12.npz")
+    dims = make_dims(num_classes=8)
+    o = Oracle(dims, 32)
+    arena = o.layout.pack(load_golden("step_n2_k8_full.npz"), "p0.")
+    for t in range(12):
+        x = g["traj.x_u8"][t].astype(np.float32) / np.float32(255.0)
+        o.forward(arena, x, training=True)
+        assert abs(o.loss(g["traj.y"][t]) - float(g["traj.loss"][t])) < 1e-5 * abs(float(g["traj.loss"][t])), t
+        assert np.array_equal(o.argmax(), g["traj.argmax"][t]), t
+        grads = o.backward(arena, g["traj.y"][t])
+        o.sgd(arena, grads, 0.001, 32.0)
+    for name, (off, size, shape, kind) in o.layout.tensors.items():
+        e = rel_err(arena[off:off + size], g["pT." + name])
+        assert e < 2e-6, (name, e)

@@ -39,11 +39,30 @@ def sha256(path):
     return h.hexdigest()
 
 
+def make_traj(p):
+    # twelve consecutive training steps at the reference batch size, K=8: per-step loss and labels,
+    # final weights (inputs kept as the u8 pixel values they were drawn as)
+    run("traj", p, 32, 8, 500, 12)
+    b = read_bundle(p)
+    t = {"traj.loss": b["traj.loss"], "traj.argmax": b["traj.argmax"],
+         "traj.x_u8": np.stack([np.rint(b["traj.x%d" % k] * 255.0).astype(np.uint8) for k in range(12)]),
+         "traj.y": np.stack([b["traj.y%d" % k] for k in range(12)]).astype(np.int32)}
+    assert all(np.array_equal(t["traj.x_u8"][k].astype(np.float32) / np.float32(255.0), b["traj.x%d" % k]) for k in range(12))
+    t.update({k: v for k, v in b.items() if k.startswith("pT.")})
+    np.savez_compressed(os.path.join(GOLD, "traj_n32_k8_t12.npz"), **t)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
+    ap.add_argument("--only", choices=("traj",), default=None, help="regenerate just this fixture")
     a = ap.parse_args()
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "REF=" + a.ref])
+    if a.only == "traj":
+        tmp = tempfile.mkdtemp()
+        make_traj(os.path.join(tmp, "a.bundle"))
+        shutil.rmtree(tmp)
+        return
     os.makedirs(GOLD, exist_ok=True)
     tmp = tempfile.mkdtemp()
     manifest = {"harness_flags": "-O2 -ffp-contract=off -fopenmp, OMP_NUM_THREADS=1", "files": {}}
@@ -57,6 +76,7 @@ def main():
     b = read_bundle(p)
     b = {k: v for k, v in b.items() if not (k.startswith("p2.") and "running" not in k)}
     np.savez(os.path.join(GOLD, "step_n32_k10.npz"), **b)
+    make_traj(p)
     # a batch that is not a multiple of anything convenient, K=8
     run("step", p, 5, 8, 7, 0)
     b = read_bundle(p)
