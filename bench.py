@@ -267,6 +267,26 @@ def main():
     torch.cuda.synchronize()
     pair_us = float(np.median([e0.elapsed_time(e1) for e0, e1 in pairs])) * 1e3
 
+    # yardstick: what a plain copy with the kernels' own access pattern (one contiguous region per
+    # workgroup) reaches on this device once the footprint is beyond the 256 MB Infinity Cache
+    copy_gbs = None
+    if rank == 0 and a.mode == "train" and not generic:
+        import ctypes as C
+        from vit_amd._lib import lib as _lib
+        blocks, floats = 4096, 50 * 256
+        src = torch.rand(blocks * floats, device="cuda")
+        dst = torch.empty_like(src)
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for rep in range(2):  # first round warms up
+            e0.record()
+            for _ in range(5):
+                _lib.vt_probe_copy(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), blocks, floats, 0, st)
+            e1.record()
+            torch.cuda.synchronize()
+        copy_gbs = 5 * 2.0 * blocks * floats * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del src, dst
+
     if rank == 0:
         value = a.steps * B * world / dt
         k_ms, k_cnt = prof.get(dominant, (0.0, 0))
@@ -306,6 +326,7 @@ def main():
                        "grad_allreduce_floats": int(m.layout.n_trainable) if world > 1 else 0},
             "roofline": roof,
             "whole_step_hbm_frac": round(value / world * total_bytes / (HBM_PEAK_GBS * 1e9), 4),
+            "measured_copy_gbs": None if copy_gbs is None else round(copy_gbs, 1),
             "algorithmic_bytes_per_image": total_bytes,
             "launcher_us": {k: round(1e3 * v, 2) for k, v in sorted(per_launch_ms.items(), key=lambda kv: -kv[1])},
         }

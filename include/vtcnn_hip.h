@@ -405,6 +405,12 @@ int vt_self_attention_bwd(const float *x, const float *wk, const float *wq, cons
                           const float *attn, const float *delta, float *ds, float *d_key, float *d_query, float *g_wk,
                           float *g_wq, float *dx, float *workspace, long workspace_floats, int B, int T, int D, int Dk,
                           vt_stream s);
+/* Measurement aid, no counterpart in the reference: copies blocks * floats_per_block floats (a multiple
+ * of 4) from src to dst with `blocks` workgroups.  mode 0: workgroup b streams its own contiguous region,
+ * the access pattern of the one-workgroup-per-image kernels; mode 1: the same bytes in 4 KB chunks dealt
+ * round-robin, so that the chunks in flight are neighbours in memory.  bench.py reports both rates beside
+ * the kernels' achieved bandwidth. */
+int vt_probe_copy(const float *src, float *dst, int blocks, long floats_per_block, int mode, vt_stream s);
 /* update_weights + SGD::update (utils/optimizer.hpp:22-28) over n floats. */
 int vt_sgd_update(float *w, float *g, int n, float lr, float divisor, int zero_grad, vt_stream s);
 /* Textbook Adam over the arena.  NOT in the reference (utils/optimizer.hpp has SGD only):

@@ -215,6 +215,26 @@ __global__ __launch_bounds__(TPB) void k_dense_bwd_rows(const float *__restrict_
   }
 }
 
+// Bandwidth yardstick with the access pattern of the per-image kernels: `blocks` workgroups, each
+// streaming its own contiguous region of `floats_per_block` floats (mode 0: one region per workgroup,
+// what a one-workgroup-per-image kernel does; mode 1: the same bytes, but trip k of workgroup b moves
+// the 4 KB chunk k*blocks + b, so that the chunks in flight at any moment are neighbours in memory).
+__global__ __launch_bounds__(TPB) void k_probe_copy(const float4 *__restrict__ src, float4 *__restrict__ dst,
+                                                    long vec_per_block, int mode) {
+  const long nb = gridDim.x, b = blockIdx.x;
+  if (mode == 0) {
+    const float4 *s = src + b * vec_per_block;
+    float4 *d = dst + b * vec_per_block;
+    for (long i = threadIdx.x; i < vec_per_block; i += TPB) d[i] = s[i];
+  } else {
+    const long trips = (vec_per_block + TPB - 1) / TPB, total = nb * vec_per_block;
+    for (long k = 0; k < trips; ++k) {
+      const long i = (k * nb + b) * TPB + threadIdx.x;
+      if (i < total) dst[i] = src[i];
+    }
+  }
+}
+
 }  // namespace vt
 
 // ---------------------------------------------------------------------------------------------
@@ -261,6 +281,14 @@ extern "C" int vt_bn_bwd_finalize(const float *part, int nblocks, int C, long ro
   if (C < 1 || C > 1024 || nblocks < 1 || rows_total < 1) return VT_EUNSUPPORTED;
   hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(C), dim3(FIN_T), 0, (hipStream_t)s, part, nblocks, C, rows_total, gamma,
                      stat, in_row0, ggamma, gbeta, coef);
+  VT_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int vt_probe_copy(const float *src, float *dst, int blocks, long floats_per_block, int mode, vt_stream s) {
+  if (!src || !dst || blocks < 1 || floats_per_block < 4 || (floats_per_block & 3) || mode < 0 || mode > 1) return VT_EINVAL;
+  hipLaunchKernelGGL(k_probe_copy, dim3(blocks), dim3(TPB), 0, (hipStream_t)s, reinterpret_cast<const float4 *>(src),
+                     reinterpret_cast<float4 *>(dst), floats_per_block / 4, mode);
   VT_CHECK_LAUNCH();
   return 0;
 }
