@@ -411,6 +411,16 @@ int vt_self_attention_bwd(const float *x, const float *wk, const float *wq, cons
  * round-robin, so that the chunks in flight are neighbours in memory.  bench.py reports both rates beside
  * the kernels' achieved bandwidth. */
 int vt_probe_copy(const float *src, float *dst, int blocks, long floats_per_block, int mode, vt_stream s);
+/* MultiHeadAttention::forward (layers/multi_head_attention.hpp:64-107) as a stand-alone launcher.
+ * x [B,T,D]; wqkv: for each head its [D,hd] query, key and value matrices in that order (the arena order
+ * mha.q0 | mha.k0 | mha.v0 | mha.q1 ...), wo [D,D]; heads [B,T,D] receives the head outputs side by side
+ * (head h in columns h*hd ..), out [B,T,D] the layer output: with reference_compat != 0 exactly zero, as
+ * in the reference, whose Tensor::concat returns an unfilled tensor (utils/tensor/tensor_cpu.hpp:218-256)
+ * in front of a bias-free projection; with 0 the projection of the concatenated heads.
+ * scratch >= 3*B*T*hd + B*T*T floats.  (The training step itself never launches this: with a zero
+ * output the forward attention is dead code there, and its backward recomputes what it needs.) */
+int vt_mha_fwd(const float *x, const float *wqkv, const float *wo, float *heads, float *out, float *scratch,
+               long scratch_floats, int B, int T, int D, int nheads, int reference_compat, vt_stream s);
 /* update_weights + SGD::update (utils/optimizer.hpp:22-28) over n floats. */
 int vt_sgd_update(float *w, float *g, int n, float lr, float divisor, int zero_grad, vt_stream s);
 /* Textbook Adam over the arena.  NOT in the reference (utils/optimizer.hpp has SGD only):

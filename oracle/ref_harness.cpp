@@ -461,6 +461,49 @@ static int cmd_traj(int argc, char **argv)
   return 0;
 }
 
+// mha <out.bundle> <B> <T> <D> <heads> <seed>: MultiHeadAttention::forward
+// (layers/multi_head_attention.hpp:64-107) on a uniform random input.  Dumps the layer's own output
+// (zero: Tensor::concat leaves its result unfilled) and, evaluated with the same reference Tensor and
+// DenseLayer operations the layer runs (:79-92), every head's output, plus what the output projection
+// gives for their channel-wise concatenation (the reading the layer's comments intend).
+static int cmd_mha(int argc, char **argv)
+{
+  const int B = std::atoi(argv[3]), T = std::atoi(argv[4]), D = std::atoi(argv[5]), H = std::atoi(argv[6]);
+  const unsigned seed = (unsigned)std::atoi(argv[7]);
+  Tensor::set_seed(42);
+  MultiHeadAttention mha(D, D, H);
+  const int hd = D / H;
+  std::mt19937 gen(seed);
+  std::uniform_real_distribution<float> dist(-1.0f, 1.0f);
+  Tensor x({B, T, D});
+  for (auto &v : x.data)
+    v = dist(gen);
+  Bundle b(argv[2]);
+  b.put("x", x);
+  b.put("out", mha.forward({x})[0]);
+  Tensor x_flat = x.reshape({B * T, D});
+  Tensor cat({B, T, D});
+  for (int h = 0; h < H; ++h)
+  {
+    put_dense(b, "q" + std::to_string(h), mha.query_linears[h], false);
+    put_dense(b, "k" + std::to_string(h), mha.key_linears[h], false);
+    put_dense(b, "v" + std::to_string(h), mha.value_linears[h], false);
+    Tensor query = mha.query_linears[h]->forward({x_flat})[0].reshape({B, T, hd});
+    Tensor key = mha.key_linears[h]->forward({x_flat})[0].reshape({B, T, hd});
+    Tensor value = mha.value_linears[h]->forward({x_flat})[0].reshape({B, T, hd});
+    Tensor scores = key.matmul(query.transpose({0, 2, 1}));
+    scores = scores * (1.0f / std::sqrt(static_cast<float>(hd)));
+    Tensor head_out = scores.softmax(2).matmul(value);
+    b.put("head" + std::to_string(h), head_out);
+    for (int r = 0; r < B * T; ++r)
+      for (int e = 0; e < hd; ++e)
+        cat.data[(size_t)r * D + h * hd + e] = head_out.data[(size_t)r * hd + e];
+  }
+  put_dense(b, "o", mha.output_linear, false);
+  b.put("out_concat", mha.output_linear->forward({cat.reshape({B * T, D})})[0].reshape({B, T, D}));
+  return 0;
+}
+
 // selfattn <out.bundle> <B> <T> <D> <Dk> <seed>: SelfAttention::forward / backward
 // (layers/self_attention.hpp:31-136) on a uniform random input and delta; dumps the two weight
 // matrices, the output, the weight gradients and the input delta.
@@ -495,7 +538,7 @@ int main(int argc, char **argv)
 {
   if (argc < 2)
   {
-    std::fprintf(stderr, "usage: ref_harness step|dp|kat|blood|bench|images|traj|selfattn ...\n");
+    std::fprintf(stderr, "usage: ref_harness step|dp|kat|blood|bench|images|traj|mha|selfattn ...\n");
     return 2;
   }
   std::string c = argv[1];
@@ -513,6 +556,8 @@ int main(int argc, char **argv)
       return cmd_bench(argc, argv);
     if (c == "images" && argc == 4)
       return cmd_images(argc, argv);
+    if (c == "mha" && argc == 8)
+      return cmd_mha(argc, argv);
     if (c == "traj" && argc == 7)
       return cmd_traj(argc, argv);
     if (c == "selfattn" && argc == 8)

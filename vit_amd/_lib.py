@@ -112,6 +112,7 @@ SIGNATURES = {
     "vt_softmax_bwd_rows": (i, [p, p, l, i, p]),
     "vt_self_attention_fwd": (i, [p, p, p, p, p, p, p, i, i, i, i, p]),
     "vt_self_attention_bwd": (i, [p, p, p, p, p, p, p, p, p, p, p, p, p, p, l, i, i, i, i, p]),
+    "vt_mha_fwd": (i, [p, p, p, p, p, p, l, i, i, i, i, i, p]),
     "vt_probe_copy": (i, [p, p, i, l, i, p]),
     "vt_sgd_update": (i, [p, p, i, f, f, i, p]),
     "vt_adam_update": (i, [p, p, p, p, i, f, f, f, f, i, f, p]),

@@ -925,3 +925,33 @@ extern "C" int vt_self_attention_bwd(const float *x, const float *wk, const floa
   VTG(vt_gemm_f32(0, 1, B * T, D, Dk, 1.f, d_key, Dk, 0, wk, Dk, 0, 1, dx, D, 0, nullptr, 1, nullptr, 0, s));
   return vt_gemm_f32(0, 1, B * T, D, Dk, 1.f, d_query, Dk, 0, wq, Dk, 0, 1, dx, D, 0, nullptr, 1, nullptr, 0, s);
 }
+
+// MultiHeadAttention::forward (layers/multi_head_attention.hpp:64-107): per head q, k, v = x.W (no bias),
+// attn = softmax_last(k.q^T / sqrt(hd)) (key times query-transposed, :89-91), head = attn.v; the heads
+// are laid side by side in `heads` [B,T,D].  The reference then runs Tensor::concat, which returns its
+// result unfilled (utils/tensor/tensor_cpu.hpp:218-256), so the bias-free output projection yields exactly
+// zero: reference_compat != 0 reproduces that (out = 0); 0 applies the projection to the concatenated
+// heads, which is what the layer's comments describe.
+extern "C" int vt_mha_fwd(const float *x, const float *wqkv, const float *wo, float *heads, float *out, float *scratch,
+                          long scratch_floats, int B, int T, int D, int nheads, int reference_compat, vt_stream s) {
+  if (!x || !wqkv || !wo || !heads || !out || !scratch || B < 1 || T < 1 || D < 1 || nheads < 1 || D % nheads != 0)
+    return VT_EINVAL;
+  const int hd = D / nheads;
+  const long BT = (long)B * T, TT = (long)T * T, TH = (long)T * hd;
+  if (scratch_floats < 3 * BT * hd + B * TT) return VT_EINVAL;
+  float *q = scratch, *k = q + BT * hd, *v = k + BT * hd, *sc = v + BT * hd;
+  for (int h = 0; h < nheads; ++h) {
+    const float *w = wqkv + (size_t)h * 3 * D * hd;
+    VTG(vt_gemm_f32(0, 0, (int)BT, hd, D, 1.f, x, D, 0, w, hd, 0, 0, q, hd, 0, nullptr, 1, nullptr, 0, s));
+    VTG(vt_gemm_f32(0, 0, (int)BT, hd, D, 1.f, x, D, 0, w + (size_t)D * hd, hd, 0, 0, k, hd, 0, nullptr, 1, nullptr, 0, s));
+    VTG(vt_gemm_f32(0, 0, (int)BT, hd, D, 1.f, x, D, 0, w + (size_t)2 * D * hd, hd, 0, 0, v, hd, 0, nullptr, 1, nullptr, 0, s));
+    VTG(vt_gemm_f32(0, 1, T, T, hd, 1.0f / sqrtf((float)hd), k, hd, TH, q, hd, TH, 0, sc, T, TT, nullptr, B, nullptr, 0, s));
+    VTG(softmax_rows(sc, BT, T, (hipStream_t)s));
+    VTG(vt_gemm_f32(0, 0, T, hd, T, 1.f, sc, T, TT, v, hd, TH, 0, heads + (size_t)h * hd, D, (long)T * D, nullptr, B, nullptr, 0, s));
+  }
+  if (reference_compat) {
+    HIPCHK_G(hipMemsetAsync(out, 0, (size_t)BT * D * sizeof(float), (hipStream_t)s));
+    return 0;
+  }
+  return vt_gemm_f32(0, 0, (int)BT, D, D, 1.f, heads, D, 0, wo, D, 0, 0, out, D, 0, nullptr, 1, nullptr, 0, s);
+}
