@@ -370,41 +370,32 @@ __global__ __launch_bounds__(TPB) void k_proj_bwd(const float *__restrict__ du, 
 // and the NCHW->[N,P,C] transpose (model/vit_cnn.hpp:127-134).  One workgroup per image.
 //   S = x.W1 + b1;  A = softmax over the P pixels per token;  T0 = A^T.x;  t = T0.W2 + b2
 // S is produced in N layout (lane = token, registers = pixels), so the softmax over pixels reduces
-// inside the lane first and crosses lanes once per workgroup.  Two sweeps over the image's pixels
-// (25 KB, L2-resident), S recomputed in the second one (2 MFMAs per tile are cheaper than 52
-// registers per lane, which would halve the occupancy):
-//   sweep 1: per-token maximum;   sweep 2: e = exp(S - max), sum e, and T0~ = e^T.x accumulated
-//   in one D tile per wave; T0 = T0~ / sum at the end.
+// inside the lane first and crosses lanes once per workgroup.  The image is read once: a wave fetches
+// all of its tiles together, keeps their score tiles in registers (52 per lane, the kernel stays
+// under 128) and the normalised pixels in LDS;
+//   pass 1: scores and the per-token maximum;   pass 2: e = exp(S - max), sum e, and T0~ = e^T.x
+//   accumulated in D tiles per wave; T0 = T0~ / sum at the end.
+// (The kernel is bound by its vector instructions, not by bytes: recomputing S and re-reading x in a
+// second sweep cost 40 % more of them.)
 // tok_stat[n] = (max_l[L], sum_l[L]) lets the backward pass rebuild A in a single sweep; tokA is
 // written only when non-null (debug / tests), by a third sweep.
 // ---------------------------------------------------------------------------------------------
-template <int NT>  // tiles handled together (their loads are issued before the first is used)
-__device__ __forceinline__ void tok_scores(const float *__restrict__ xin, int t0, int ntiles, int P, int j, const BnPair &bn,
-                                           const float (&bw)[2], float bias, f4 (&sc)[NT]) {
-  float2 raw[NT];
-#pragma unroll
-  for (int u = 0; u < NT; ++u) raw[u] = *reinterpret_cast<const float2 *>(xin + (size_t)min((t0 + NW * u) * 16 + j, P - 1) * C1);
-#pragma unroll
-  for (int u = 0; u < NT; ++u) {
-    const bool ok = t0 + NW * u < ntiles && (t0 + NW * u) * 16 + j < P;
-    const float x0 = ok ? bn.apply(raw[u].x, 0) : 0.f, x1 = ok ? bn.apply(raw[u].y, 1) : 0.f;
-    sc[u] = f4{bias, bias, bias, bias};
-    sc[u] = mfma16(x0, bw[0], sc[u]);
-    sc[u] = mfma16(x1, bw[1], sc[u]);
-  }
-}
-
-__global__ __launch_bounds__(TPB) void k_tokenizer_fwd(const float *__restrict__ conv, const float *__restrict__ st,
+template <bool WITH_MAP>  // also write the attention map tokA (tests); its stores cost registers the step cannot spare
+__global__ __launch_bounds__(TPB, 4) void k_tokenizer_fwd(const float *__restrict__ conv, const float *__restrict__ st,
                                                        const float *__restrict__ g, const float *__restrict__ b,
                                                        const float *__restrict__ W1, const float *__restrict__ b1,
                                                        const float *__restrict__ W2, const float *__restrict__ b2,
                                                        float *__restrict__ tokA, float *__restrict__ tok_stat,
                                                        float *__restrict__ tok, float *__restrict__ part_n1, int P) {
-  constexpr int NT = 4;
   __shared__ float redm[NW][L], reds[NW][L];
   __shared__ float sT[NW][256];
   __shared__ float sT0[L * C1];
   __shared__ float st_[L * D];
+  // normalised pixels of the whole image, [pixel][TKX] with a pad column (the second product reads
+  // them with the pixel in the registers, four rows apart per lane group: stride 9 keeps those reads
+  // and the 16 lanes' writes on distinct banks)
+  constexpr int TKX = C1 + 1;
+  __shared__ float sx[16 * NW * TK_MAXT * TKX];
   const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, gq = lane >> 4;
   const int ntiles = (P + 15) >> 4;
   float bw[2];
@@ -414,48 +405,63 @@ __global__ __launch_bounds__(TPB) void k_tokenizer_fwd(const float *__restrict__
   BnPair bn;
   bn.init(st, g, b, gq);
   const float *__restrict__ xin = conv + (size_t)n * P * C1 + 2 * gq;
-  // sweep 1: maximum over the pixels, per token (lane j)
+  // One pass over the image: every tile of the wave (t = wave + NW*u) is fetched at once, normalised,
+  // left in LDS for the second product, and its score tile S = x.W1 + b1 stays in registers
+  // (N layout: lane = token j, registers = pixels 4g+v), so nothing is recomputed or re-read.
+  float2 raw[TK_MAXT];
+#pragma unroll
+  for (int u = 0; u < TK_MAXT; ++u)
+    raw[u] = *reinterpret_cast<const float2 *>(xin + (size_t)min((wave + NW * u) * 16 + j, P - 1) * C1);
+  f4 sc[TK_MAXT];
   float cm = -INFINITY;
-  for (int t0 = wave; t0 < ntiles; t0 += NW * NT) {
-    f4 sc[NT];
-    tok_scores<NT>(xin, t0, ntiles, P, j, bn, bw, bias, sc);
 #pragma unroll
-    for (int u = 0; u < NT; ++u)
+  for (int u = 0; u < TK_MAXT; ++u) {
+    const int t = wave + NW * u;
+    const bool ok = t < ntiles && t * 16 + j < P;
+    const float x0 = ok ? bn.apply(raw[u].x, 0) : 0.f, x1 = ok ? bn.apply(raw[u].y, 1) : 0.f;
+    sx[(t * 16 + j) * TKX + 2 * gq] = x0;
+    sx[(t * 16 + j) * TKX + 2 * gq + 1] = x1;
+    sc[u] = f4{bias, bias, bias, bias};
+    sc[u] = mfma16(x0, bw[0], sc[u]);
+    sc[u] = mfma16(x1, bw[1], sc[u]);
+    // rows past the image leave the softmax here: exp(-inf - max) = 0, and the second pass needs no masks
 #pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const bool valid = t0 + NW * u < ntiles && (t0 + NW * u) * 16 + 4 * gq + v < P;
-        cm = valid ? fmaxf(cm, sc[u][v]) : cm;
-      }
+    for (int v = 0; v < 4; ++v) {
+      const bool valid = t < ntiles && t * 16 + 4 * gq + v < P;
+      sc[u][v] = valid ? sc[u][v] : -INFINITY;
+      cm = fmaxf(cm, sc[u][v]);
+    }
+    __builtin_amdgcn_sched_barrier(0);  // one tile at a time: see the note in the second pass
   }
+  // maximum over the pixels, per token (lane j)
   cm = gmax(cm);
   if (gq == 0) redm[wave][j] = cm;
   __syncthreads();
   cm = fmaxf(fmaxf(redm[0][j], redm[1][j]), fmaxf(redm[2][j], redm[3][j]));
-  // sweep 2: e = exp(S - max), its sum, and T0~[l][c] = sum_p e[p][l] x[p][c] (D[token][channel])
+  // e = exp(S - max), its sum, and T0~[l][c] = sum_p e[p][l] x[p][c] (D[token][channel]); two
+  // accumulators so that consecutive matrix instructions do not wait for each other
   const int ch = j & (C1 - 1);
-  const float nmean = st[ch], ninv = st[C1 + ch], ngam = g[ch], nbet = b[ch];
-  const float *__restrict__ cb = conv + (size_t)n * P * C1;
   float cs = 0.f;
-  f4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (int t0 = wave; t0 < ntiles; t0 += NW * NT) {
-    float xr[NT][4];
+  f4 acc = {0.f, 0.f, 0.f, 0.f}, acc1 = acc;
 #pragma unroll
-    for (int u = 0; u < NT; ++u)
-#pragma unroll
-      for (int v = 0; v < 4; ++v) xr[u][v] = cb[(size_t)min((t0 + NW * u) * 16 + 4 * gq + v, P - 1) * C1 + ch];
-    f4 sc[NT];
-    tok_scores<NT>(xin, t0, ntiles, P, j, bn, bw, bias, sc);
-#pragma unroll
-    for (int u = 0; u < NT; ++u)
+  for (int u = 0; u < TK_MAXT; ++u) {
+    const int t = wave + NW * u;
+    if (t < ntiles) {  // wave-uniform
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
-        const bool valid = t0 + NW * u < ntiles && (t0 + NW * u) * 16 + 4 * gq + v < P;
-        const float e = valid ? __expf(sc[u][v] - cm) : 0.f;
-        const float xn = (valid && j < C1) ? ((xr[u][v] - nmean) * ninv) * ngam + nbet : 0.f;
+        const float e = __expf(sc[u][v] - cm);
+        const float xn = j < C1 ? sx[(t * 16 + 4 * gq + v) * TKX + ch] : 0.f;  // rows past P hold zeros
         cs += e;
-        acc = mfma16(e, xn, acc);
+        if (v & 1) acc1 = mfma16(e, xn, acc1);
+        else acc = mfma16(e, xn, acc);
       }
+    }
+    // keep the instruction scheduler from hoisting every tile's LDS reads to the top of the pass
+    // (52 more live registers would halve the occupancy)
+    if ((u & 1) == 1) __builtin_amdgcn_sched_barrier(0);
   }
+#pragma unroll
+  for (int v = 0; v < 4; ++v) acc[v] += acc1[v];
   cs = gsum(cs);
   if (gq == 0) reds[wave][j] = cs;
 #pragma unroll
@@ -471,19 +477,15 @@ __global__ __launch_bounds__(TPB) void k_tokenizer_fwd(const float *__restrict__
     const float tot = (reds[0][l] + reds[1][l]) + (reds[2][l] + reds[3][l]);
     if (c < C1) sT0[l * C1 + c] = ((sT[0][tid] + sT[1][tid]) + (sT[2][tid] + sT[3][tid])) * (1.0f / tot);
   }
-  if (tokA != nullptr) {  // debug sweep: the attention map itself
+  if (WITH_MAP) {  // debug output: the attention map itself
     const float rcs = 1.0f / cs;
-    for (int t0 = wave; t0 < ntiles; t0 += NW * NT) {
-      f4 sc[NT];
-      tok_scores<NT>(xin, t0, ntiles, P, j, bn, bw, bias, sc);
 #pragma unroll
-      for (int u = 0; u < NT; ++u)
+    for (int u = 0; u < TK_MAXT; ++u)
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          const int pr = (t0 + NW * u) * 16 + 4 * gq + v;
-          if (t0 + NW * u < ntiles && pr < P) tokA[((size_t)n * P + pr) * L + j] = __expf(sc[u][v] - cm) * rcs;
-        }
-    }
+      for (int v = 0; v < 4; ++v) {
+        const int t = wave + NW * u, pr = t * 16 + 4 * gq + v;
+        if (t < ntiles && pr < P) tokA[((size_t)n * P + pr) * L + j] = __expf(sc[u][v] - cm) * rcs;
+      }
   }
   __syncthreads();
   // t = T0 . W2 + b2  (linear2, tokenizer.hpp:42-44)
@@ -797,9 +799,13 @@ extern "C" int vt_projector_bwd(const float *du, const float *pn_coef, const flo
 extern "C" int vt_tokenizer_fwd(const float *conv_out, const float *bn_stat, const float *bn_gamma, const float *bn_beta,
                                 const float *w1, const float *b1, const float *w2, const float *b2, float *tok_A,
                                 float *tok_stat, float *tokens, float *part_n1, int N, int P, vt_stream s) {
-  if (N < 1 || P < 1 || !tok_stat) return VT_EUNSUPPORTED;
-  hipLaunchKernelGGL(k_tokenizer_fwd, dim3(N), dim3(TPB), 0, (hipStream_t)s, conv_out, bn_stat, bn_gamma, bn_beta, w1,
-                     b1, w2, b2, tok_A, tok_stat, tokens, part_n1, P);
+  if (N < 1 || P < 1 || P > 16 * NW * TK_MAXT || !tok_stat) return VT_EUNSUPPORTED;
+  if (tok_A != nullptr)
+    hipLaunchKernelGGL(k_tokenizer_fwd<true>, dim3(N), dim3(TPB), 0, (hipStream_t)s, conv_out, bn_stat, bn_gamma, bn_beta,
+                       w1, b1, w2, b2, tok_A, tok_stat, tokens, part_n1, P);
+  else
+    hipLaunchKernelGGL(k_tokenizer_fwd<false>, dim3(N), dim3(TPB), 0, (hipStream_t)s, conv_out, bn_stat, bn_gamma, bn_beta,
+                       w1, b1, w2, b2, tok_A, tok_stat, tokens, part_n1, P);
   VT_CHECK_LAUNCH();
   return 0;
 }
