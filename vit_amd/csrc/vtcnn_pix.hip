@@ -643,6 +643,19 @@ __global__ __launch_bounds__(TPB) void k_conv_wgrad(const float *__restrict__ X,
   for (int ci = 0; ci < CW_MAXCI; ++ci) acc[ci] = f4{0.f, 0.f, 0.f, 0.f};
   const float *__restrict__ dyb = dy + (size_t)n * P * C1 + (j < C1 ? j : 0);
   const float *__restrict__ xb = X + (size_t)n * Ci * P;
+  // W4: the zero-padded image ((H+2) x (W+2) per channel) is staged in LDS once, so that a shifted
+  // image value is one LDS read with no clamps or border masks (the launcher checks that it fits)
+  extern __shared__ float xt[];
+  const int TW = W + 2, plane = (H + 2) * TW;
+  if (W4) {
+    for (int i = tid; i < Ci * plane; i += TPB) {
+      const int ci = i / plane, r = i - ci * plane, hh = r / TW - 1, ww = r - (hh + 1) * TW - 1;
+      const bool in = hh >= 0 && hh < H && ww >= 0 && ww < W;
+      const float v = xb[(size_t)ci * P + (in ? hh * W + ww : 0)];
+      xt[i] = in ? v : 0.f;
+    }
+    __syncthreads();
+  }
   for (int t = wave; t < ntiles; t += NW) {
     float dv[4];
     if (W4) {
@@ -651,26 +664,23 @@ __global__ __launch_bounds__(TPB) void k_conv_wgrad(const float *__restrict__ X,
       int h = (int)(((float)p4 + 0.5f) * invW);
       h -= (h * W > p4) ? 1 : 0;
       h += ((h + 1) * W <= p4) ? 1 : 0;
-      const int w0 = p4 - h * W, hr = h + kh, wc = w0 + kw;
-      const bool rowok = valid && j < 9 && hr >= 0 && hr < H;
+      const int w0 = p4 - h * W;
       const int pc = valid ? p4 : 0;
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         const float d = dyb[(size_t)(pc + v) * C1];
         dv[v] = (valid && j < C1) ? d * c0 + c1 : 0.f;
       }
-      // clamped, unconditional image loads; the mask is applied to the value
-      const int hc = min(max(hr, 0), H - 1);
+      // lanes j < 9: tap (kh, kw) of the padded tile; lane 9: the ones row (bias gradient); lanes past
+      // it contribute rows that are never read.  Pixels past the image have a zero delta.
+      const int toff = valid ? (h + kh + 1) * TW + w0 + kw + 1 : TW + 1;
 #pragma unroll
       for (int ci = 0; ci < CW_MAXCI; ++ci) {
         if (ci < Ci) {
-          const float *__restrict__ xr = xb + (size_t)ci * P + hc * W;
+          const float *__restrict__ xr = xt + ci * plane + (j < 9 ? toff : TW + 1);
 #pragma unroll
           for (int v = 0; v < 4; ++v) {
-            const int wv = wc + v;
-            float xv = xr[min(max(wv, 0), W - 1)];
-            xv = (rowok && wv >= 0 && wv < W) ? xv : 0.f;
-            if (j == 9) xv = 1.f;  // invalid pixels have a zero delta, so the ones row needs no mask
+            const float xv = j == 9 ? 1.f : xr[v];
             acc[ci] = mfma16(xv, dv[v], acc[ci]);
           }
         }
@@ -825,8 +835,9 @@ extern "C" int vt_conv3x3_wgrad(const float *x, const float *dy, const float *bn
                                 int H, int W, vt_stream s) {
   if (N < 1 || Ci < 1 || Ci > CW_MAXCI || H < 1 || W < 1) return VT_EUNSUPPORTED;
   const int ld = C1 * Ci * 9 + C1;
-  if (W % 4 == 0)
-    hipLaunchKernelGGL(k_conv_wgrad<true>, dim3(N), dim3(TPB), 0, (hipStream_t)s, x, dy, bn_coef, gslab, Ci, H, W, ld);
+  const size_t lds = (size_t)Ci * (H + 2) * (W + 2) * sizeof(float);
+  if (W % 4 == 0 && lds <= 32 * 1024)
+    hipLaunchKernelGGL(k_conv_wgrad<true>, dim3(N), dim3(TPB), lds, (hipStream_t)s, x, dy, bn_coef, gslab, Ci, H, W, ld);
   else
     hipLaunchKernelGGL(k_conv_wgrad<false>, dim3(N), dim3(TPB), 0, (hipStream_t)s, x, dy, bn_coef, gslab, Ci, H, W, ld);
   VT_CHECK_LAUNCH();
