@@ -85,7 +85,7 @@ int vt_model_set_training(vt_model *m, int training);
  * of the headline shape run fused fp32 kernels and accept only 0.  No counterpart in the reference. */
 int vt_model_set_matmul_precision(vt_model *m, int bf16);
 /* Launch order of the headline-shape backward.  on != 0 (the default): once the projector's deltas
- * exist, the tokenizer / BatchNorm2D / convolution backward (and the fc weight gradient before it)
+ * exist, the tokenizer / BatchNorm2D / convolution backward (and the fc weight gradient after it)
  * are issued on a stream of the model's own, beside the transformer and attention backward on the
  * caller's stream, and joined before the gradient reduction; the two chains share no buffer
  * (layers/visual_transformer.hpp:153-173: tokenizer.backward2 takes the projector's deltas, not the

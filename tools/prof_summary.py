@@ -40,7 +40,9 @@ def main():
     print("%-34s %6s %10s %7s  %s" % ("kernel", "calls", "avg_us", "share", "launch"))
     for n, calls, t, avg, geo in rows:
         print("%-34s %6d %10.2f %6.1f%%  %s" % (short(n), calls, avg, 100 * t / tot, geo))
-    print("sum of kernel time per step: %.1f us (%d steps)" % (tot / steps, steps))
+    # kernels launched fewer times than there are steps (set-up fills, the copy yardstick) are not part of a step
+    step_tot = sum(r[2] for r in rows if r[1] >= steps)
+    print("sum of kernel time per step: %.1f us (%d steps; kernels with at least one launch per step)" % (step_tot / steps, steps))
 
 
 if __name__ == "__main__":

@@ -38,7 +38,7 @@ struct vt_model {
   // and the tokenizer/BatchNorm2D/conv pixels); the second one is issued on this stream between a
   // fork event and a join event so that latency-bound row kernels overlap HBM-bound pixel kernels.
   hipStream_t side = nullptr;
-  hipEvent_t ev_head = nullptr, ev_rows = nullptr, ev_join = nullptr;
+  hipEvent_t ev_rows = nullptr, ev_join = nullptr;
   bool concurrent = true, side_open = false;
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec = nullptr;
@@ -191,7 +191,6 @@ extern "C" int vt_model_create(const vt_dims *dims, int max_batch, int device, f
   rc |= dalloc(m, &m->coef_bn, 2 * C1, "coef.bn");
   rc |= dalloc(m, &m->loss_buf, 4);
   if (rc == 0 && (hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking) != hipSuccess ||
-                  hipEventCreateWithFlags(&m->ev_head, hipEventDisableTiming) != hipSuccess ||
                   hipEventCreateWithFlags(&m->ev_rows, hipEventDisableTiming) != hipSuccess ||
                   hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming) != hipSuccess))
     rc = VT_ENOMEM;
@@ -213,7 +212,7 @@ extern "C" int vt_model_destroy(vt_model *m) {
   if (m->graph) (void)hipGraphDestroy(m->graph);
   if (m->gstream) (void)hipStreamDestroy(m->gstream);
   if (m->side) (void)hipStreamDestroy(m->side);
-  for (hipEvent_t e : {m->ev_head, m->ev_rows, m->ev_join})
+  for (hipEvent_t e : {m->ev_rows, m->ev_join})
     if (e) (void)hipEventDestroy(e);
   for (void *p : m->allocs) (void)hipFree(p);
   for (hipEvent_t e : m->prof_ev) (void)hipEventDestroy(e);
@@ -821,20 +820,14 @@ static int backward_main(vt_model *m, const int *d_labels, vt_stream s) {
   const long NL = (long)n * L;
   const int nrb = (int)((NL + RB - 1) / RB);
   hipStream_t hs = (hipStream_t)s;
-  // The side chain: fc weight gradient (needs only the head's delta), later the tokenizer / BatchNorm2D /
-  // conv backward (needs the projector's input delta and transformer_bwd_a's token delta).  Its
+  // The side chain: the tokenizer / BatchNorm2D / conv backward (needs the projector's input delta and
+  // transformer_bwd_a's token delta), then the fc weight gradient (needs only the head's delta).  Its
   // launchers write buffers nothing on the caller's stream touches before join_side().
   const bool fork = m->concurrent && m->side != nullptr;
   const vt_stream t = fork ? (vt_stream)m->side : s;
   // head: softmax/fc/pool/relu backward + projector BatchNorm1D backward sums
   STEP("head_bwd", vt_head_bwd(m->last_probs, d_labels, m->P_("fc.W"), m->pool_idx, m->z, m->stat_pn, m->P_("proj.norm.gamma"),
                     m->P_("proj.norm.beta"), m->dlogits, m->du, m->part, n, H, K, s));
-  if (fork) {
-    HIPCHK(hipEventRecord(m->ev_head, hs));
-    HIPCHK(hipStreamWaitEvent(m->side, m->ev_head, 0));
-    m->side_open = true;
-  }
-  STEP_ON("fc_wgrad", t, vt_fc_wgrad(m->pooled, m->dlogits, m->G_("fc.W"), m->G_("fc.b"), m->sc_fc, n, Q, K, t));
   STEP("bn_bwd_finalize", vt_bn_bwd_finalize(m->part, n, C2, (long)n * P, m->P_("proj.norm.gamma"), m->stat_pn, m->z,
                            m->G_("proj.norm.gamma"), m->G_("proj.norm.beta"), m->coef_pn, s));
   // projector
@@ -849,6 +842,7 @@ static int backward_main(vt_model *m, const int *d_labels, vt_stream s) {
   if (fork) {
     HIPCHK(hipEventRecord(m->ev_rows, hs));
     HIPCHK(hipStreamWaitEvent(m->side, m->ev_rows, 0));
+    m->side_open = true;
   }
   // tokenizer.backward2(projector token delta, projector input delta) + BatchNorm2D + conv, with
   // partial sums of their own (norm2's are still waiting in m->part for their finalize)
@@ -858,6 +852,8 @@ static int backward_main(vt_model *m, const int *d_labels, vt_stream s) {
                            m->G_("bn.gamma"), m->G_("bn.beta"), m->coef_bn, t));
   STEP_ON("conv3x3_wgrad", t, vt_conv3x3_wgrad(m->last_images, m->dy, m->coef_bn, m->gslab_conv, n, Ci, H, H, t));
   VTCHK(vt_reduce_rows(m->gslab_conv, n, C1 * Ci * 9 + C1, C1 * Ci * 9 + C1, m->G_("conv.W"), s));  // queued
+  // the fc weight gradient only needs the head's delta: it rides at the end of the shorter chain
+  STEP_ON("fc_wgrad", t, vt_fc_wgrad(m->pooled, m->dlogits, m->G_("fc.W"), m->G_("fc.b"), m->sc_fc, n, Q, K, t));
   // feed-forward half of the transformer layer
   STEP("bn_bwd_finalize", vt_bn_bwd_finalize(m->part, nrb, D, NL, m->P_("norm2.gamma"), m->stat_n2, m->s2, m->G_("norm2.gamma"),
                            m->G_("norm2.beta"), m->coef_n2, s));
