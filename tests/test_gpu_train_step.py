@@ -143,6 +143,18 @@ def _routing_from_gpu(m, n):
 
 @pytest.mark.parametrize("n,k", [(64, 8), (200, 10), (1024, 8)])
 def test_train_step_vs_oracle_larger_batch(n, k):
+    _step_vs_f64_oracle(n, k, 1, 28)
+
+
+@pytest.mark.parametrize("n,k,ci,h", [(33, 5, 3, 28), (40, 8, 1, 14), (16, 16, 4, 14), (7, 2, 2, 28), (1, 8, 1, 28), (3, 10, 1, 14)])
+def test_train_step_other_inputs_on_the_fused_kernels(n, k, ci, h):
+    """The fused kernels also serve the reference's hyper-parameters with colour inputs (up to four
+    image channels) and 14x14 images (pool kernel 1: every pixel its own window), up to sixteen classes:
+    same two-part check against the float64 restatement as for the larger batches."""
+    _step_vs_f64_oracle(n, k, ci, h)
+
+
+def _step_vs_f64_oracle(n, k, ci, h):
     """Batches beyond the committed reference fixtures, up to the benchmark's 1024.
 
     Checker: the oracle (pinned bit-exactly to the reference at N=2/5/32) in its double-precision
@@ -161,16 +173,16 @@ def test_train_step_vs_oracle_larger_batch(n, k):
     from vit_amd import VTCNN, Dims
     from oracle.pyoracle import Oracle, make_dims
     rng = np.random.default_rng(n)
-    x = (rng.integers(0, 256, size=(n, 1, 28, 28)).astype(np.float32) / np.float32(255.0))
+    x = (rng.integers(0, 256, size=(n, ci, h, h)).astype(np.float32) / np.float32(255.0))
     y = rng.integers(0, k, size=n).astype(np.int32)
-    m = VTCNN(Dims(num_classes=k), max_batch=n, seed=42)
+    m = VTCNN(Dims(num_classes=k, image_channels=ci, input_dim=h), max_batch=n, seed=42)
     arena32 = m.get_arena().copy()
     pg = m.forward(torch.from_numpy(x).cuda()).cpu().numpy()
     m.backward(torch.from_numpy(y).cuda())
     gg = m.get_grads()
     slots, mask = _routing_from_gpu(m, n)
     # part 1: forward floats and discrete decisions vs exact math (fp64 oracle, its own decisions)
-    o = Oracle(make_dims(num_classes=k), n, f64=True)
+    o = Oracle(make_dims(num_classes=k, image_channels=ci, input_dim=h), n, f64=True)
     arena64 = arena32.astype(np.float64)
     p64 = o.forward(arena64.copy(), x, training=True)
     assert rel_err(pg, p64) < TOL

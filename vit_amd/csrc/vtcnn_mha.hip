@@ -300,7 +300,7 @@ __device__ __forceinline__ f4 mfma16(float a, float b, f4 c) { return __builtin_
 __global__ __launch_bounds__(TPB) void k_mha_wgrad(const float *__restrict__ yz, const float *__restrict__ st,
                                                    const float *__restrict__ qkv, const float *__restrict__ dc,
                                                    const float *__restrict__ tok, const float *__restrict__ Wqkv,
-                                                   float *__restrict__ slab, long rows, int nsplit) {
+                                                   float *__restrict__ slab, long rows, int nsplit, int single_key) {
   __shared__ float sbuf[NW * 256];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4, h = blockIdx.y;
   const long row0 = ((long)blockIdx.x * NW + wave) * 16;
@@ -355,7 +355,9 @@ __global__ __launch_bounds__(TPB) void k_mha_wgrad(const float *__restrict__ yz,
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
       yn[t][v] = y[v] * inv4[v];
-      zn[t][v] = w[v] * inv4[v] - dot4[v] * yn[t][v];
+      // a group of one row attends only to itself: its softmax is exactly 1 and softmax_backward
+      // exactly 0 (tensor_cpu.hpp:946-950), which the difference of two rounded terms would miss
+      zn[t][v] = single_key ? 0.f : w[v] * inv4[v] - dot4[v] * yn[t][v];
     }
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
@@ -367,7 +369,7 @@ __global__ __launch_bounds__(TPB) void k_mha_wgrad(const float *__restrict__ yz,
           w1 += yz[o + (size_t)D * rows];
         }
       y1 *= invj;
-      zt[t][v] = w1 * invj - dotj * y1;
+      zt[t][v] = single_key ? 0.f : w1 * invj - dotj * y1;
     }
   }
   // dK[row][e] = sum_d Z[d][row] Wq[d][e]  (rows in registers)
@@ -457,7 +459,7 @@ extern "C" int vt_mha_bwd_wgrad(const float *qkv, const float *dc, const float *
   float *st = yz + (size_t)HEADS * ns * 2 * D * rows;
   float *slab = st + (size_t)HEADS * ns * 2 * rows;
   hipLaunchKernelGGL(k_mha_wgrad, dim3(nrb, HEADS), dim3(TPB), 0, (hipStream_t)s, yz, st, qkv, dc, tok, wqkv, slab, rows,
-                     ns);
+                     ns, N == 1 ? 1 : 0);
   VT_CHECK_LAUNCH();
   for (int h = 0; h < HEADS; ++h) {
     const int rc = reduce_rows(slab + (size_t)h * nrb * MH_STRIDE, nrb, MH_STRIDE, MH_STRIDE,
