@@ -355,6 +355,32 @@ def test_two_stream_backward_is_bit_identical_to_one_stream(n):
         assert np.array_equal(wa, c.get_arena()), t
 
 
+def test_batch_size_may_change_from_step_to_step():
+    """One model (max_batch 96) stepping through batches of 96, 5, 33, 1, 64, 96 images (the short last
+    batch of an epoch, then full ones again) computes, at every step, exactly what a model created for that
+    batch size computes from the same weights: nothing in the workspace survives from a larger batch."""
+    import torch
+    from vit_amd import VTCNN, Dims
+    rng = np.random.default_rng(5)
+    a = VTCNN(Dims(num_classes=8), max_batch=96, seed=42)
+    for t, n in enumerate([96, 5, 33, 1, 64, 96]):
+        x = torch.from_numpy(rng.integers(0, 256, size=(n, 1, 28, 28)).astype(np.float32) / np.float32(255.0)).cuda()
+        y = torch.from_numpy(rng.integers(0, 8, size=n).astype(np.int32)).cuda()
+        b = VTCNN(Dims(num_classes=8), max_batch=n, seed=None)
+        b.set_arena(a.get_arena())
+        pa = a.forward(x).cpu().numpy().copy()
+        pb = b.forward(x).cpu().numpy()
+        assert np.array_equal(pa, pb), (t, n)
+        a.backward(y); b.backward(y)
+        assert np.array_equal(a.get_grads(), b.get_grads()), (t, n)
+        a.update_weights(32.0); b.update_weights(32.0)
+        assert np.array_equal(a.get_arena(), b.get_arena()), (t, n)
+        # evaluation in between, as Trainer::evaluate does after an epoch
+        a.set_training(False); b.set_training(False)
+        assert np.array_equal(a.forward(x).cpu().numpy(), b.forward(x).cpu().numpy()), (t, n)
+        a.set_training(True)
+
+
 def _overlapped_steps(a, b, dp, xs, ys, n, first, count):
     for t in range(3):
         a.forward(xs[t]); a.backward(ys[t]); a.update_weights(float(n))
