@@ -103,18 +103,18 @@ def measured_traffic(launcher, batch, classes):
 def cpu_baseline(batch, classes):
     """Reference CPU path timed on this box's host cores (rank 0, N=1 only): the real reference
     compiled from its own headers (oracle/_ref/ref_harness_o3, built in the build container) when
-    present, else the oracle port.  Bounded sample: ONE training step of one mini-batch."""
+    present, else the oracle port.  Bounded sample: three training steps of one mini-batch (about 12 s)."""
     cores = min(16, os.cpu_count() or 1)
     exe = os.path.join(ROOT, "oracle", "_ref", "ref_harness_o3")
     if os.access(exe, os.X_OK):
         try:
             env = dict(os.environ, OMP_NUM_THREADS=str(cores))
-            out = subprocess.run([exe, "bench", str(batch), str(classes), "1", "0"], env=env, capture_output=True,
+            out = subprocess.run([exe, "bench", str(batch), str(classes), "3", "0"], env=env, capture_output=True,
                                  text=True, timeout=300)
             r = json.loads(out.stdout.strip().splitlines()[-1])
             return {"value": round(r["images_per_sec"], 2), "unit": "images/sec", "cores": int(r["threads"]),
                     "kind": "reference",
-                    "sample": "1 training step of one %d-image mini-batch, reference headers compiled -O3 "
+                    "sample": "3 training steps of one %d-image mini-batch, reference headers compiled -O3 "
                               "-march=x86-64-v3 -fopenmp" % batch}
         except Exception as e:  # fall through to the port
             sys.stderr.write("reference harness failed (%s); timing the oracle port instead\n" % e)

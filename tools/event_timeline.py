@@ -1,7 +1,7 @@
 """Event timeline of one training step without a profiler attached: start / end of every launcher
 from the library's own HIP events (vt_model_profile_timeline), for both launch orders of the backward.
 
-    python tools/event_timeline.py [batch]
+    PYTHONPATH=. python tools/event_timeline.py [batch]
 """
 import sys
 
