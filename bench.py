@@ -112,10 +112,17 @@ def cpu_baseline(batch, classes):
             out = subprocess.run([exe, "bench", str(batch), str(classes), "3", "0"], env=env, capture_output=True,
                                  text=True, timeout=300)
             r = json.loads(out.stdout.strip().splitlines()[-1])
-            return {"value": round(r["images_per_sec"], 2), "unit": "images/sec", "cores": int(r["threads"]),
-                    "kind": "reference",
-                    "sample": "3 training steps of one %d-image mini-batch, reference headers compiled -O3 "
-                              "-march=x86-64-v3 -fopenmp" % batch}
+            res = {"value": round(r["images_per_sec"], 2), "unit": "images/sec", "cores": int(r["threads"]),
+                   "kind": "reference",
+                   "sample": "3 training steps of one %d-image mini-batch, reference headers compiled -O3 "
+                             "-march=x86-64-v3 -fopenmp" % batch}
+            # the same binary on one core, at the reference's own batch size (a 1024-image step would take a minute)
+            one = subprocess.run([exe, "bench", "32", str(classes), "3", "0"], env=dict(os.environ, OMP_NUM_THREADS="1"),
+                                 capture_output=True, text=True, timeout=300)
+            r1 = json.loads(one.stdout.strip().splitlines()[-1])
+            res["one_core"] = {"value": round(r1["images_per_sec"], 2), "unit": "images/sec", "cores": 1,
+                               "sample": "3 training steps of one 32-image mini-batch"}
+            return res
         except Exception as e:  # fall through to the port
             sys.stderr.write("reference harness failed (%s); timing the oracle port instead\n" % e)
     from oracle.pyoracle import Oracle, make_dims
