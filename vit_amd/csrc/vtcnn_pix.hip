@@ -52,6 +52,20 @@ __device__ __forceinline__ Split8 split8(const float (&x)[8]) {
   split_pair(x[6], x[7], h.w, l.w);
   return Split8{__builtin_bit_cast(bf16x8_t, h), __builtin_bit_cast(bf16x8_t, l)};
 }
+struct Split4 {  // four values: packed bf16 hi and lo halves (two 32-bit words each)
+  uint2 hi, lo;
+};
+__device__ __forceinline__ Split4 split4(const f4 &x) {
+  Split4 r;
+  split_pair(x[0], x[1], r.hi.x, r.lo.x);
+  split_pair(x[2], x[3], r.hi.y, r.lo.y);
+  return r;
+}
+// operand of a 32-deep product from two groups of four slots (either may be all zero)
+__device__ __forceinline__ Split8 join8(const Split4 &a, const Split4 &b) {
+  return Split8{__builtin_bit_cast(bf16x8_t, make_uint4(a.hi.x, a.hi.y, b.hi.x, b.hi.y)),
+                __builtin_bit_cast(bf16x8_t, make_uint4(a.lo.x, a.lo.y, b.lo.x, b.lo.y))};
+}
 __device__ __forceinline__ f4 mfma32_split(const Split8 &a, const Split8 &b, f4 c) {
   c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.lo, b.hi, c, 0, 0, 0);  // smallest partial products first
   c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.hi, b.lo, c, 0, 0, 0);
@@ -287,6 +301,10 @@ __global__ __launch_bounds__(TPB) void k_proj_bwd(const float *__restrict__ du, 
     cf0[v] = coef[4 * gq + v];
     cf1[v] = coef[C2 + 4 * gq + v];
   }
+  // constant operands of the two split products: slots 0..3 = c2 4g..4g+3, slots 4..7 = tokens 4g..4g+3
+  const Split4 zero4 = {make_uint2(0u, 0u), make_uint2(0u, 0u)};
+  const Split8 wda = join8(split4(f4{av[0], av[1], av[2], av[3]}), zero4);
+  const Split8 wdx = join8(split4(f4{awd[0], awd[1], awd[2], awd[3]}), split4(f4{amt[0], amt[1], amt[2], amt[3]}));
   BnPair bn;
   bn.init(st, g, b, gq);
   f4 accG = {0.f, 0.f, 0.f, 0.f}, accW = accG, accV = accG;
@@ -315,18 +333,15 @@ __global__ __launch_bounds__(TPB) void k_proj_bwd(const float *__restrict__ du, 
     const float rsum = __builtin_amdgcn_rcpf(gsum((a[0] + a[1]) + (a[2] + a[3])));
 #pragma unroll
     for (int v = 0; v < 4; ++v) a[v] = a[v] * rsum;
-    f4 da = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int v = 0; v < 4; ++v) da = mfma16(av[v], dz[v], da);
+    // da = v . dz (16 deep) and, below, dx = Wd . dz + Mq . ds (32 deep) as bf16 hi/lo partial products:
+    // 6 matrix instructions of 16 cycles instead of 12 of 32; dz is split once for both
+    const Split4 sdz = split4(dz);
+    f4 da = mfma32_split(wda, join8(sdz, zero4), f4{0.f, 0.f, 0.f, 0.f});
     const float dot = gsum((da[0] * a[0] + da[1] * a[1]) + (da[2] * a[2] + da[3] * a[3]));
     f4 ds;
 #pragma unroll
     for (int v = 0; v < 4; ++v) ds[v] = a[v] * (da[v] - dot);
-    f4 dx = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int v = 0; v < 4; ++v) dx = mfma16(awd[v], dz[v], dx);
-#pragma unroll
-    for (int v = 0; v < 4; ++v) dx = mfma16(amt[v], ds[v], dx);
+    const f4 dx = mfma32_split(wdx, join8(sdz, split4(ds)), f4{0.f, 0.f, 0.f, 0.f});
     if (ok && gq < 2) *reinterpret_cast<f4 *>(pdx + ((size_t)n * P + p) * C1 + 4 * gq) = dx;
     // T -> N through the wave's LDS patch
     *reinterpret_cast<float2 *>(pt + j * PB_RS + PB_X + 2 * gq) = make_float2(x0, x1);
