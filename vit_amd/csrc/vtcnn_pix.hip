@@ -182,8 +182,6 @@ __global__ __launch_bounds__(TPB) void k_proj_fwd(const float *__restrict__ conv
   for (int i = 0; i < TK_MAXT; ++i)
     raws[i] = *reinterpret_cast<const float2 *>(xin + (size_t)min((wave + NW * i) * 16 + j, P - 1) * C1);
   settle(amq);
-  settle(awd);
-  settle(av);
   settle(pv);
   settle(cinit);
   bn.settle_all();
@@ -192,6 +190,8 @@ __global__ __launch_bounds__(TPB) void k_proj_fwd(const float *__restrict__ conv
     settle(raws[i].x);
     settle(raws[i].y);
   }
+  // constant operand of the split product below (formed after every load of the prologue is under way)
+  const Split8 wz = join8(split4(f4{awd[0], awd[1], 0.f, 0.f}), split4(f4{av[0], av[1], av[2], av[3]}));
 #pragma unroll
   for (int i = 0; i < TK_MAXT; ++i) {
     const int t = wave + NW * i;
@@ -210,11 +210,13 @@ __global__ __launch_bounds__(TPB) void k_proj_fwd(const float *__restrict__ conv
     const float rsum = __builtin_amdgcn_rcpf(gsum((a[0] + a[1]) + (a[2] + a[3])));
 #pragma unroll
     for (int v = 0; v < 4; ++v) a[v] = a[v] * rsum;
-    f4 zc = cinit;
-    zc = mfma16(awd[0], x0, zc);
-    zc = mfma16(awd[1], x1, zc);
-#pragma unroll
-    for (int v = 0; v < 4; ++v) zc = mfma16(av[v], a[v], zc);
+    // z = bd + Wd . x + v . a: one 24-deep contraction (slots 0..1 = channels 2g, 2g+1, slots 4..7 = tokens
+    // 4g..4g+3) as bf16 hi/lo partial products, 3 matrix instructions of 16 cycles instead of 6 of 32
+    Split4 sx;
+    split_pair(x0, x1, sx.hi.x, sx.lo.x);
+    sx.hi.y = 0u;
+    sx.lo.y = 0u;
+    const f4 zc = mfma32_split(wz, join8(sx, split4(a)), cinit);
     if (ok) {
       if (projA) *reinterpret_cast<f4 *>(projA + ((size_t)n * P + p) * L + 4 * gq) = a;
       *reinterpret_cast<f4 *>(z + ((size_t)n * P + p) * C2 + 4 * gq) = zc;
