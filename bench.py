@@ -146,8 +146,8 @@ def cpu_baseline(batch, classes):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=1024, help="images per mini-batch per GPU")
     ap.add_argument("--classes", type=int, default=8)
     ap.add_argument("--shape", choices=tuple(SHAPES), default="blood",
