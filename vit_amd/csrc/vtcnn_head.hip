@@ -181,6 +181,14 @@ __global__ __launch_bounds__(TPB) void k_head_bwd(const float *__restrict__ prob
   const unsigned char *__restrict__ pix = pool_idx + (size_t)n * Q;
   // phase 1: fc input delta of every pooling window (one window per thread trip), kept in LDS;
   // the weight rows of HB windows are loaded together
+  // the first pixel record of this thread is requested now: its trip to HBM runs under phase 1, which
+  // only touches the (cached) fc weights
+  float4 zpre[C2 / 4];
+  {
+    const float4 *src0 = reinterpret_cast<const float4 *>(z + ((size_t)n * P + min(tid, P - 1)) * C2);
+#pragma unroll
+    for (int q = 0; q < C2 / 4; ++q) zpre[q] = src0[q];
+  }
   extern __shared__ float sdf[];  // Q floats
   for (int f0 = tid; f0 < Q; f0 += HB * TPB) {
     float w[HB][K];
@@ -209,7 +217,7 @@ __global__ __launch_bounds__(TPB) void k_head_bwd(const float *__restrict__ prob
       // bytes, two fc rows) is loaded unconditionally, so all loads of a pixel are independent.
 #pragma unroll
       for (int q = 0; q < C2 / 4; ++q) {
-        const float4 v4 = src[q];
+        const float4 v4 = p == tid ? zpre[q] : src[q];
         const float zv[4] = {v4.x, v4.y, v4.z, v4.w};
         const int f0 = ch * 196 + (h >> 1) * 14 + (w >> 1);
         const unsigned short sl2 = *reinterpret_cast<const unsigned short *>(pix + f0);
