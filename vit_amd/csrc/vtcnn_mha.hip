@@ -301,7 +301,7 @@ __global__ __launch_bounds__(TPB) void k_mha_wgrad(const float *__restrict__ yz,
                                                    const float *__restrict__ qkv, const float *__restrict__ dc,
                                                    const float *__restrict__ tok, const float *__restrict__ Wqkv,
                                                    float *__restrict__ slab, long rows, int nsplit, int single_key) {
-  __shared__ float sbuf[NW * 256];
+  __shared__ float sbuf[6][NW * 256];  // the six gradient tiles of the four waves, summed in one phase
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4, h = blockIdx.y;
   const long row0 = ((long)blockIdx.x * NW + wave) * 16;
   const int nv = (int)max(0L, min(16L, rows - row0));
@@ -345,12 +345,18 @@ __global__ __launch_bounds__(TPB) void k_mha_wgrad(const float *__restrict__ yz,
     for (int sp = 0; sp < nsplit; ++sp) {
       const float *yb = yz + ((((size_t)h * nsplit + sp) * 2 + 0) * D + (j + 16 * t)) * rows + row0 + 4 * g;
       const float *wb = yb + (size_t)D * rows;
+      if (4 * g + 3 < nv) {  // the four rows of this lane group are consecutive floats, 16-byte aligned
+        const f4 y4 = *reinterpret_cast<const f4 *>(yb), w4 = *reinterpret_cast<const f4 *>(wb);
+        y += y4;
+        w += w4;
+      } else {
 #pragma unroll
-      for (int v = 0; v < 4; ++v)
-        if (4 * g + v < nv) {
-          y[v] += yb[v];
-          w[v] += wb[v];
-        }
+        for (int v = 0; v < 4; ++v)
+          if (4 * g + v < nv) {
+            y[v] += yb[v];
+            w[v] += wb[v];
+          }
+      }
     }
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
@@ -403,14 +409,18 @@ __global__ __launch_bounds__(TPB) void k_mha_wgrad(const float *__restrict__ yz,
     }
     const f4 acc[3] = {gq, gk, gv};
 #pragma unroll
-    for (int m = 0; m < 3; ++m) {
-      __syncthreads();
+    for (int m = 0; m < 3; ++m)
 #pragma unroll
-      for (int v = 0; v < 4; ++v) sbuf[wave * 256 + (4 * g + v) * 16 + j] = acc[m][v];
-      __syncthreads();
-      row[m * D * HD + (16 * t) * HD + tid] = (sbuf[tid] + sbuf[256 + tid]) + (sbuf[512 + tid] + sbuf[768 + tid]);
-    }
+      for (int v = 0; v < 4; ++v) sbuf[3 * t + m][wave * 256 + (4 * g + v) * 16 + j] = acc[m][v];
   }
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      const float *b = sbuf[3 * t + m];
+      row[m * D * HD + (16 * t) * HD + tid] = (b[tid] + b[256 + tid]) + (b[512 + tid] + b[768 + tid]);
+    }
 }
 
 }  // namespace vt
