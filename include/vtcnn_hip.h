@@ -340,6 +340,13 @@ int vt_projector_tokens_bwd(const float *o, const float *dv, const float *dk, co
  *     (layers/multi_head_attention.hpp:131-135) and the per-head q,k,v recomputation (:144-152). */
 int vt_transformer_bwd_a(const float *o, const float *pdt, const float *s2, const float *n2_stat,
                          const float *tok_w2, float *part, float *dT0, long rows, vt_stream s);
+/* vt_projector_tokens_bwd and vt_transformer_bwd_a as one launch (projector_layer.hpp:186-202, then
+ * transformer_layer.hpp:142-161 and tokenizer.hpp:73-75): step a only reads the token delta of its own
+ * rows, so nothing device-wide sits between the two.  Same outputs, bit for bit. */
+int vt_projector_tokens_bwd_transformer_a(const float *o, const float *dv, const float *dk, const float *wv,
+                                          const float *wk, float *pdt, float *g_wk_wv_bv, float *scratch,
+                                          const float *s2, const float *n2_stat, const float *tok_w2, float *part,
+                                          float *dT0, long rows, vt_stream s);
 int vt_transformer_bwd_b(const float *o, const float *pdt, const float *n2_coef, const float *hdn, const float *a,
                          const float *tok, const float *n1_stat, const float *w1, const float *w2, float *ds2,
                          float *da, float *g_ffn, float *scratch, float *part, long rows, vt_stream s);

@@ -118,6 +118,7 @@ SIGNATURES = {
     "vt_adam_update": (i, [p, p, p, p, i, f, f, f, f, i, f, p]),
     "vt_projector_tokens_bwd": (i, [p] * 8 + [l, p]),
     "vt_transformer_bwd_a": (i, [p] * 7 + [l, p]),
+    "vt_projector_tokens_bwd_transformer_a": (i, [p] * 13 + [l, p]),
     "vt_transformer_bwd_b": (i, [p] * 14 + [l, p]),
     "vt_transformer_bwd_c": (i, [p] * 8 + [l, p]),
     "vt_mha_bwd": (i, [p] * 6 + [i, i, p]),

@@ -835,10 +835,11 @@ static int backward_main(vt_model *m, const int *d_labels, vt_stream s) {
                          m->P_("proj.linear1.W"), m->P_("proj.downsample.W"), m->pdx, m->dv, m->dk, m->gslab, n, P, s));
   VTCHK(vt_reduce_rows(m->gslab, n, C1 * D, 400, m->G_("proj.linear1.W"), s));  // queued
   VTCHK(vt_reduce_rows(m->gslab + C1 * D, n, C1 * C2 + C2, 400, m->G_("proj.downsample.W"), s));
-  STEP("projector_tokens_bwd", vt_projector_tokens_bwd(m->o, m->dv, m->dk, m->P_("proj.linear3.W"), m->P_("proj.linear2.W"), m->pdt,
-                                m->G_("proj.linear2.W"), m->sc_pt, NL, s));
-  // transformer (targets = projector token delta, same bytes: visual_transformer.hpp:153-157)
-  STEP("transformer_bwd_a", vt_transformer_bwd_a(m->o, m->pdt, m->s2, m->stat_n2, m->P_("tok.linear2.W"), m->part, m->dT0, NL, s));
+  // projector token side + transformer step a (targets = projector token delta, same bytes:
+  // visual_transformer.hpp:153-157) in one launch
+  STEP("projector_tokens_bwd", vt_projector_tokens_bwd_transformer_a(m->o, m->dv, m->dk, m->P_("proj.linear3.W"), m->P_("proj.linear2.W"),
+                                m->pdt, m->G_("proj.linear2.W"), m->sc_pt, m->s2, m->stat_n2, m->P_("tok.linear2.W"), m->part,
+                                m->dT0, NL, s));
   if (fork) {
     HIPCHK(hipEventRecord(m->ev_rows, hs));
     HIPCHK(hipStreamWaitEvent(m->side, m->ev_rows, 0));

@@ -305,18 +305,18 @@ __global__ __launch_bounds__(TPB) void k_proj_tokens_fwd(const float *__restrict
 // Per-workgroup partials: gWk[D*D] | gWv[D*C2] | gbv[C2]  (PT_STRIDE floats), summed afterwards.
 // ---------------------------------------------------------------------------------------------
 constexpr int PT_STRIDE = D * D + D * C2 + C2;  // 1552
-__global__ __launch_bounds__(TPB) void k_projtok_bwd(const float *__restrict__ o, const float *__restrict__ dv,
-                                                     const float *__restrict__ dk, const float *__restrict__ Wv,
-                                                     const float *__restrict__ Wk, float *__restrict__ pdt,
-                                                     float *__restrict__ scratch, long rows) {
-  __shared__ float sbuf[NW * 256];
+// sbuf: NW * 256 floats of LDS.  `out` returns this wave's tile of the token delta (T layout).
+__device__ __forceinline__ void projtok_bwd_body(const float *__restrict__ o, const float *__restrict__ dv,
+                                                 const float *__restrict__ dk, const float *__restrict__ Wv,
+                                                 const float *__restrict__ Wk, float *__restrict__ pdt,
+                                                 float *__restrict__ scratch, long rows, float *sbuf, TTile<2> &out) {
   const Lane ln;
   const int wave = threadIdx.x >> 6;
   const long row0 = ((long)blockIdx.x * NW + wave) * 16;
   const int nv = (int)max(0L, min(16L, rows - row0));
   // token delta, T layout
   TTile<1> dvt;
-  TTile<2> dkt, out;
+  TTile<2> dkt;
   dvt.load(dv, row0, nv, C2, 0, ln);
   dkt.load(dk, row0, nv, D, 0, ln);
 #pragma unroll
@@ -351,6 +351,14 @@ __global__ __launch_bounds__(TPB) void k_projtok_bwd(const float *__restrict__ o
     if (threadIdx.x < C2) row[D * D + D * C2 + threadIdx.x] = (sbuf[threadIdx.x] + sbuf[16 + threadIdx.x]) + (sbuf[32 + threadIdx.x] + sbuf[48 + threadIdx.x]);
   }
 }
+__global__ __launch_bounds__(TPB) void k_projtok_bwd(const float *__restrict__ o, const float *__restrict__ dv,
+                                                     const float *__restrict__ dk, const float *__restrict__ Wv,
+                                                     const float *__restrict__ Wk, float *__restrict__ pdt,
+                                                     float *__restrict__ scratch, long rows) {
+  __shared__ float sbuf[NW * 256];
+  TTile<2> out;
+  projtok_bwd_body(o, dv, dk, Wv, Wk, pdt, scratch, rows, sbuf, out);
+}
 
 // ---------------------------------------------------------------------------------------------
 // TransformerLayer::backward, step A (reference layers/transformer_layer.hpp:142-161):
@@ -359,11 +367,11 @@ __global__ __launch_bounds__(TPB) void k_projtok_bwd(const float *__restrict__ o
 // Also the tokenizer's linear2 input delta dT0 = token_delta . W2tok^T (tokenizer.hpp:73-75), which
 // reads the same rows.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(TPB) void k_tr_bwd_a(const float *__restrict__ o, const float *__restrict__ pdt,
-                                                  const float *__restrict__ s2, const float *__restrict__ st2,
-                                                  const float *__restrict__ W2tok, float *__restrict__ part,
-                                                  float *__restrict__ dT0, long rows) {
-  __shared__ float sred[NW][2 * D];
+// pt: this wave's tile of the projector token delta (T layout).  sred: NW x 2D floats of LDS.
+__device__ __forceinline__ void tr_bwd_a_body(const float *__restrict__ o, const TTile<2> &pt,
+                                              const float *__restrict__ s2, const float *__restrict__ st2,
+                                              const float *__restrict__ W2tok, float *__restrict__ part,
+                                              float *__restrict__ dT0, long rows, float (*sred)[2 * D]) {
   const Lane ln;
   const int wave = threadIdx.x >> 6;
   const long row0 = ((long)blockIdx.x * NW + wave) * 16;
@@ -371,9 +379,8 @@ __global__ __launch_bounds__(TPB) void k_tr_bwd_a(const float *__restrict__ o, c
   f4 mean[2], inv[2];
   load_fvec<2>(st2, mean, ln);
   load_fvec<2>(st2 + D, inv, ln);
-  TTile<2> ot, pt, xt;
+  TTile<2> ot, xt;
   ot.load(o, row0, nv, D, 0, ln);
-  pt.load(pdt, row0, nv, D, 0, ln);
   xt.load(s2, row0, nv, D, 0, ln);
   const bool ok = ln.j < nv;
 #pragma unroll
@@ -400,6 +407,32 @@ __global__ __launch_bounds__(TPB) void k_tr_bwd_a(const float *__restrict__ o, c
     const int f = threadIdx.x;
     part[(size_t)blockIdx.x * 2 * D + f] = (sred[0][f] + sred[1][f]) + (sred[2][f] + sred[3][f]);
   }
+}
+__global__ __launch_bounds__(TPB) void k_tr_bwd_a(const float *__restrict__ o, const float *__restrict__ pdt,
+                                                  const float *__restrict__ s2, const float *__restrict__ st2,
+                                                  const float *__restrict__ W2tok, float *__restrict__ part,
+                                                  float *__restrict__ dT0, long rows) {
+  __shared__ float sred[NW][2 * D];
+  const Lane ln;
+  const long row0 = ((long)blockIdx.x * NW + (threadIdx.x >> 6)) * 16;
+  TTile<2> pt;
+  pt.load(pdt, row0, (int)max(0L, min(16L, rows - row0)), D, 0, ln);
+  tr_bwd_a_body(o, pt, s2, st2, W2tok, part, dT0, rows, sred);
+}
+// Both of the above in one launch: step A only needs the token delta of its own rows, which the
+// projector's token-side backward has just formed in registers, so no device-wide ordering sits
+// between them.  Same arithmetic in the same order: bit-identical to the two separate launches.
+__global__ __launch_bounds__(TPB) void k_projtok_bwd_tr_a(const float *__restrict__ o, const float *__restrict__ dv,
+                                                          const float *__restrict__ dk, const float *__restrict__ Wv,
+                                                          const float *__restrict__ Wk, float *__restrict__ pdt,
+                                                          float *__restrict__ scratch, const float *__restrict__ s2,
+                                                          const float *__restrict__ st2, const float *__restrict__ W2tok,
+                                                          float *__restrict__ part, float *__restrict__ dT0, long rows) {
+  __shared__ float sbuf[NW * 256];
+  __shared__ float sred[NW][2 * D];
+  TTile<2> pt;
+  projtok_bwd_body(o, dv, dk, Wv, Wk, pdt, scratch, rows, sbuf, pt);
+  tr_bwd_a_body(o, pt, s2, st2, W2tok, part, dT0, rows, sred);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -630,6 +663,19 @@ extern "C" int vt_transformer_bwd_a(const float *o, const float *pdt, const floa
   hipLaunchKernelGGL(k_tr_bwd_a, dim3(nb), dim3(TPB), 0, (hipStream_t)s, o, pdt, s2, n2_stat, tok_w2, part, dT0, rows);
   VT_CHECK_LAUNCH();
   return 0;
+}
+
+// vt_projector_tokens_bwd followed by vt_transformer_bwd_a as one launch (same results, bit for bit).
+extern "C" int vt_projector_tokens_bwd_transformer_a(const float *o, const float *dv, const float *dk, const float *wv,
+                                                     const float *wk, float *pdt, float *g_wk_wv_bv, float *scratch,
+                                                     const float *s2, const float *n2_stat, const float *tok_w2,
+                                                     float *part, float *dT0, long rows, vt_stream s) {
+  if (rows < 1) return VT_EINVAL;
+  const int nb = (int)((rows + RB - 1) / RB);
+  hipLaunchKernelGGL(k_projtok_bwd_tr_a, dim3(nb), dim3(TPB), 0, (hipStream_t)s, o, dv, dk, wv, wk, pdt, scratch, s2,
+                     n2_stat, tok_w2, part, dT0, rows);
+  VT_CHECK_LAUNCH();
+  return reduce_rows(scratch, nb, PT_STRIDE, PT_STRIDE, g_wk_wv_bv, (hipStream_t)s);
 }
 
 // g_ffn: gradient block [gW1 | gb1 | gW2 | gb2] (2112 floats, arena order); scratch >= nb*2112.
