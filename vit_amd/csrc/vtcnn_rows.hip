@@ -112,17 +112,20 @@ __device__ __forceinline__ f4 mm_rows(f4 a_n, f4 b_n, f4 acc) {
   return acc;
 }
 
-// Sums a D tile (rows i = 4g+v, columns j) held by each of the NW waves and writes the workgroup
-// total to dst[i*ld + j] for i < ni, j < nj.  sbuf: NW*256 floats of LDS.  Ends with a barrier.
-__device__ __forceinline__ void block_tile_out(f4 acc, float *sbuf, float *__restrict__ dst, int ld, int ni, int nj) {
-  const int tid = threadIdx.x, wave = tid >> 6;
+// Cross-wave sums of D tiles (rows i = 4g+v, columns j), one LDS phase for all of a kernel's tiles:
+// every wave stages its copy of tile `slot`, ONE workgroup barrier follows, then tile_flush writes
+// the workgroup totals ((w0 + w1) + (w2 + w3)) to dst[i*ld + j].  sbuf: slots x TILE_SLOT floats.
+constexpr int TILE_SLOT = NW * 256;
+__device__ __forceinline__ void tile_stage(f4 acc, float *sbuf, int slot) {
   const Lane ln;
-  __syncthreads();
+  float *b = sbuf + slot * TILE_SLOT + (threadIdx.x >> 6) * 256;
 #pragma unroll
-  for (int v = 0; v < 4; ++v) sbuf[wave * 256 + (4 * ln.g + v) * 16 + ln.j] = acc[v];
-  __syncthreads();
-  const int i = tid >> 4, jj = tid & 15;
-  if (i < ni && jj < nj) dst[i * ld + jj] = (sbuf[tid] + sbuf[256 + tid]) + (sbuf[512 + tid] + sbuf[768 + tid]);
+  for (int v = 0; v < 4; ++v) b[(4 * ln.g + v) * 16 + ln.j] = acc[v];
+}
+__device__ __forceinline__ void tile_flush(const float *sbuf, int slot, float *__restrict__ dst, int ld) {
+  const int tid = threadIdx.x;
+  const float *b = sbuf + slot * TILE_SLOT;
+  dst[(tid >> 4) * ld + (tid & 15)] = (b[tid] + b[256 + tid]) + (b[512 + tid] + b[768 + tid]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -305,7 +308,8 @@ __global__ __launch_bounds__(TPB) void k_proj_tokens_fwd(const float *__restrict
 // Per-workgroup partials: gWk[D*D] | gWv[D*C2] | gbv[C2]  (PT_STRIDE floats), summed afterwards.
 // ---------------------------------------------------------------------------------------------
 constexpr int PT_STRIDE = D * D + D * C2 + C2;  // 1552
-// sbuf: NW * 256 floats of LDS.  `out` returns this wave's tile of the token delta (T layout).
+constexpr int PT_SLOTS = 6 + 1;                  // staged tiles + one slot holding the bias sums
+// sbuf: PT_SLOTS * TILE_SLOT floats of LDS.  `out` returns this wave's tile of the token delta (T layout).
 __device__ __forceinline__ void projtok_bwd_body(const float *__restrict__ o, const float *__restrict__ dv,
                                                  const float *__restrict__ dk, const float *__restrict__ Wv,
                                                  const float *__restrict__ Wk, float *__restrict__ pdt,
@@ -336,26 +340,30 @@ __device__ __forceinline__ void projtok_bwd_body(const float *__restrict__ o, co
   }
   const f4 dvn = load_n(dv, row0, nv, C2, ln.j, ln);
   float *row = scratch + (size_t)blockIdx.x * PT_STRIDE;
+  // slots 0..3: gWk tiles, 4..5: gWv tiles, 6: the bias sums of the four waves
 #pragma unroll
   for (int ti = 0; ti < 2; ++ti) {
 #pragma unroll
-    for (int te = 0; te < 2; ++te)
-      block_tile_out(mm_rows(on[ti], dkn[te], f4zero()), sbuf, row + (16 * ti) * D + 16 * te, D, 16, 16);
-    block_tile_out(mm_rows(on[ti], dvn, f4zero()), sbuf, row + D * D + (16 * ti) * C2, C2, 16, 16);
+    for (int te = 0; te < 2; ++te) tile_stage(mm_rows(on[ti], dkn[te], f4zero()), sbuf, 2 * ti + te);
+    tile_stage(mm_rows(on[ti], dvn, f4zero()), sbuf, 4 + ti);
   }
-  {
-    const float s = gsum((dvn[0] + dvn[1]) + (dvn[2] + dvn[3]));  // lane j: sum over the tile's rows of dv[.][j]
-    __syncthreads();
-    if (ln.g == 0) sbuf[wave * 16 + ln.j] = s;
-    __syncthreads();
-    if (threadIdx.x < C2) row[D * D + D * C2 + threadIdx.x] = (sbuf[threadIdx.x] + sbuf[16 + threadIdx.x]) + (sbuf[32 + threadIdx.x] + sbuf[48 + threadIdx.x]);
+  const float sbv = gsum((dvn[0] + dvn[1]) + (dvn[2] + dvn[3]));  // lane j: sum over the tile's rows of dv[.][j]
+  float *bs = sbuf + 6 * TILE_SLOT;
+  if (ln.g == 0) bs[wave * 16 + ln.j] = sbv;
+  __syncthreads();
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti) {
+#pragma unroll
+    for (int te = 0; te < 2; ++te) tile_flush(sbuf, 2 * ti + te, row + (16 * ti) * D + 16 * te, D);
+    tile_flush(sbuf, 4 + ti, row + D * D + (16 * ti) * C2, C2);
   }
+  if (threadIdx.x < C2) row[D * D + D * C2 + threadIdx.x] = (bs[threadIdx.x] + bs[16 + threadIdx.x]) + (bs[32 + threadIdx.x] + bs[48 + threadIdx.x]);
 }
 __global__ __launch_bounds__(TPB) void k_projtok_bwd(const float *__restrict__ o, const float *__restrict__ dv,
                                                      const float *__restrict__ dk, const float *__restrict__ Wv,
                                                      const float *__restrict__ Wk, float *__restrict__ pdt,
                                                      float *__restrict__ scratch, long rows) {
-  __shared__ float sbuf[NW * 256];
+  __shared__ float sbuf[PT_SLOTS * TILE_SLOT];
   TTile<2> out;
   projtok_bwd_body(o, dv, dk, Wv, Wk, pdt, scratch, rows, sbuf, out);
 }
@@ -428,7 +436,7 @@ __global__ __launch_bounds__(TPB) void k_projtok_bwd_tr_a(const float *__restric
                                                           float *__restrict__ scratch, const float *__restrict__ s2,
                                                           const float *__restrict__ st2, const float *__restrict__ W2tok,
                                                           float *__restrict__ part, float *__restrict__ dT0, long rows) {
-  __shared__ float sbuf[NW * 256];
+  __shared__ float sbuf[PT_SLOTS * TILE_SLOT];
   __shared__ float sred[NW][2 * D];
   TTile<2> pt;
   projtok_bwd_body(o, dv, dk, Wv, Wk, pdt, scratch, rows, sbuf, pt);
@@ -452,7 +460,7 @@ __global__ __launch_bounds__(TPB) void k_tr_bwd_b(const float *__restrict__ o, c
                                                   const float *__restrict__ W2, float *__restrict__ ds2_out,
                                                   float *__restrict__ da_out, float *__restrict__ scratch,
                                                   float *__restrict__ part, long rows) {
-  __shared__ float sbuf[NW * 256];
+  __shared__ float sbuf[9 * TILE_SLOT];
   __shared__ float sred[NW][2 * D];
   const Lane ln;
   const int wave = threadIdx.x >> 6;
@@ -523,36 +531,38 @@ __global__ __launch_bounds__(TPB) void k_tr_bwd_b(const float *__restrict__ o, c
     }
   }
   float *row = scratch + (size_t)blockIdx.x * FF_STRIDE;
+  // slots 0..3: gW1 = a^T dh, 4..7: gW2 = relu(hdn)^T ds2, 8: the bias sums of the four waves
 #pragma unroll
   for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
     for (int te = 0; te < 2; ++te) {
-      block_tile_out(mm_rows(an[ti], dhn[te], f4zero()), sbuf, row + (16 * ti) * D + 16 * te, D, 16, 16);               // gW1 = a^T dh
-      block_tile_out(mm_rows(rn[ti], dsn[te], f4zero()), sbuf, row + D * D + D + (16 * ti) * D + 16 * te, D, 16, 16);   // gW2 = relu(hdn)^T ds2
+      tile_stage(mm_rows(an[ti], dhn[te], f4zero()), sbuf, 2 * ti + te);
+      tile_stage(mm_rows(rn[ti], dsn[te], f4zero()), sbuf, 4 + 2 * ti + te);
     }
-  {
-    float sb1[2], sb2[2];
+  float *bs = sbuf + 8 * TILE_SLOT;
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      sb1[t] = gsum((dhn[t][0] + dhn[t][1]) + (dhn[t][2] + dhn[t][3]));  // gb1[j+16t] over the tile's rows
-      sb2[t] = gsum((dsn[t][0] + dsn[t][1]) + (dsn[t][2] + dsn[t][3]));  // gb2
-    }
-    __syncthreads();
+  for (int t = 0; t < 2; ++t) {
+    const float sb1 = gsum((dhn[t][0] + dhn[t][1]) + (dhn[t][2] + dhn[t][3]));  // gb1[j+16t] over the tile's rows
+    const float sb2 = gsum((dsn[t][0] + dsn[t][1]) + (dsn[t][2] + dsn[t][3]));  // gb2
     if (ln.g == 0) {
+      bs[wave * 64 + 16 * t + ln.j] = sb1;
+      bs[wave * 64 + 32 + 16 * t + ln.j] = sb2;
+    }
+  }
+  __syncthreads();
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        sbuf[wave * 64 + 16 * t + ln.j] = sb1[t];
-        sbuf[wave * 64 + 32 + 16 * t + ln.j] = sb2[t];
-      }
+  for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+    for (int te = 0; te < 2; ++te) {
+      tile_flush(sbuf, 2 * ti + te, row + (16 * ti) * D + 16 * te, D);
+      tile_flush(sbuf, 4 + 2 * ti + te, row + D * D + D + (16 * ti) * D + 16 * te, D);
     }
-    __syncthreads();
-    if (threadIdx.x < 2 * D) {
-      const int f = threadIdx.x;
-      const float s = (sbuf[f] + sbuf[64 + f]) + (sbuf[128 + f] + sbuf[192 + f]);
-      if (f < D) row[D * D + f] = s;
-      else row[2 * D * D + D + (f - D)] = s;
-      part[(size_t)blockIdx.x * 2 * D + f] = (sred[0][f] + sred[1][f]) + (sred[2][f] + sred[3][f]);
-    }
+  if (threadIdx.x < 2 * D) {
+    const int f = threadIdx.x;
+    const float sm = (bs[f] + bs[64 + f]) + (bs[128 + f] + bs[192 + f]);
+    if (f < D) row[D * D + f] = sm;
+    else row[2 * D * D + D + (f - D)] = sm;
+    part[(size_t)blockIdx.x * 2 * D + f] = (sred[0][f] + sred[1][f]) + (sred[2][f] + sred[3][f]);
   }
 }
 
