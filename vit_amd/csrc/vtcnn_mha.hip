@@ -95,7 +95,10 @@ __global__ __launch_bounds__(64 * MR_WAVES) void k_mha_rows(const float *__restr
   __shared__ __attribute__((aligned(16))) StageBuf sb[3];
   __shared__ float sred[MR_WAVES];
   const int itiles = (T + 31) / 32, iblocks = (itiles + MR_WAVES - 1) / MR_WAVES;
+  // Workgroups go to the eight XCDs round-robin, each XCD with an L2 of its own: the row tiles of one
+  // (head, group) sweep the same j tiles, so they are given indices that land on one XCD.
   int bi = blockIdx.x;
+  if ((gridDim.x & 7) == 0) bi = (bi & 7) * (gridDim.x >> 3) + (bi >> 3);
   const int sp = bi % nsplit; bi /= nsplit;
   const int ib = bi % iblocks; bi /= iblocks;
   const int bgrp = bi % groups, h = bi / groups;
