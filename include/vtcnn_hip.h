@@ -415,8 +415,9 @@ int vt_self_attention_bwd(const float *x, const float *wk, const float *wq, cons
 /* Measurement aid, no counterpart in the reference: copies blocks * floats_per_block floats (a multiple
  * of 4) from src to dst with `blocks` workgroups.  mode 0: workgroup b streams its own contiguous region,
  * the access pattern of the one-workgroup-per-image kernels; mode 1: the same bytes in 4 KB chunks dealt
- * round-robin, so that the chunks in flight are neighbours in memory.  bench.py reports both rates beside
- * the kernels' achieved bandwidth. */
+ * round-robin, so that the chunks in flight are neighbours in memory; modes 2 and 3: mode 0 with
+ * nontemporal loads and stores / nontemporal stores only.  bench.py reports the mode 0 rate beside the
+ * kernels' achieved bandwidth. */
 int vt_probe_copy(const float *src, float *dst, int blocks, long floats_per_block, int mode, vt_stream s);
 /* MultiHeadAttention::forward (layers/multi_head_attention.hpp:64-107) as a stand-alone launcher.
  * x [B,T,D]; wqkv: for each head its [D,hd] query, key and value matrices in that order (the arena order

@@ -6,7 +6,7 @@ import pytest
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
 def test_probe_copy_copies(mode):
     import torch
     from vit_amd._lib import check, lib
@@ -18,6 +18,7 @@ def test_probe_copy_copies(mode):
     assert torch.equal(src, dst)
     assert lib.vt_probe_copy(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), blocks, 6, mode, st) != 0  # not a multiple of 4
     assert lib.vt_probe_copy(None, C.c_void_p(dst.data_ptr()), blocks, floats, mode, st) != 0
+    assert lib.vt_probe_copy(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), blocks, floats, 4, st) != 0  # no such mode
 
 
 @pytest.mark.gpu

@@ -1,5 +1,6 @@
 """Device copy bandwidth with the access pattern of the per-image kernels (vt_probe_copy): one
-contiguous region per workgroup against round-robin 4 KB chunks, for a few region sizes.
+contiguous region per workgroup against round-robin 4 KB chunks, and against nontemporal accesses, for a
+few region sizes.
 
     PYTHONPATH=. python tools/probe_bandwidth.py
 """
@@ -35,3 +36,4 @@ if __name__ == "__main__":
             r1, t1 = rate(blocks, floats, 1)
             print("blocks %5d x %3d KB: per-workgroup regions %6.0f GB/s (%.1f us)   round-robin chunks %6.0f GB/s (%.1f us)"
                   % (blocks, kb, r0, t0, r1, t1))
+            print("   nontemporal load+store %6.0f GB/s, store only %6.0f GB/s" % (rate(blocks, floats, 2)[0], rate(blocks, floats, 3)[0]))

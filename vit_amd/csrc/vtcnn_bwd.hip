@@ -218,7 +218,8 @@ __global__ __launch_bounds__(TPB) void k_dense_bwd_rows(const float *__restrict_
 // Bandwidth yardstick with the access pattern of the per-image kernels: `blocks` workgroups, each
 // streaming its own contiguous region of `floats_per_block` floats (mode 0: one region per workgroup,
 // what a one-workgroup-per-image kernel does; mode 1: the same bytes, but trip k of workgroup b moves
-// the 4 KB chunk k*blocks + b, so that the chunks in flight at any moment are neighbours in memory).
+// the 4 KB chunk k*blocks + b, so that the chunks in flight at any moment are neighbours in memory;
+// modes 2, 3: mode 0 with nontemporal loads and stores / nontemporal stores only).
 __global__ __launch_bounds__(TPB) void k_probe_copy(const float4 *__restrict__ src, float4 *__restrict__ dst,
                                                     long vec_per_block, int mode) {
   const long nb = gridDim.x, b = blockIdx.x;
@@ -226,6 +227,14 @@ __global__ __launch_bounds__(TPB) void k_probe_copy(const float4 *__restrict__ s
     const float4 *s = src + b * vec_per_block;
     float4 *d = dst + b * vec_per_block;
     for (long i = threadIdx.x; i < vec_per_block; i += TPB) d[i] = s[i];
+  } else if (mode >= 2) {
+    typedef float fv4 __attribute__((ext_vector_type(4)));
+    const fv4 *s = reinterpret_cast<const fv4 *>(src) + b * vec_per_block;
+    fv4 *d = reinterpret_cast<fv4 *>(dst) + b * vec_per_block;
+    for (long i = threadIdx.x; i < vec_per_block; i += TPB) {
+      const fv4 v = mode == 2 ? __builtin_nontemporal_load(s + i) : s[i];
+      __builtin_nontemporal_store(v, d + i);
+    }
   } else {
     const long trips = (vec_per_block + TPB - 1) / TPB, total = nb * vec_per_block;
     for (long k = 0; k < trips; ++k) {
@@ -286,7 +295,7 @@ extern "C" int vt_bn_bwd_finalize(const float *part, int nblocks, int C, long ro
 }
 
 extern "C" int vt_probe_copy(const float *src, float *dst, int blocks, long floats_per_block, int mode, vt_stream s) {
-  if (!src || !dst || blocks < 1 || floats_per_block < 4 || (floats_per_block & 3) || mode < 0 || mode > 1) return VT_EINVAL;
+  if (!src || !dst || blocks < 1 || floats_per_block < 4 || (floats_per_block & 3) || mode < 0 || mode > 3) return VT_EINVAL;
   hipLaunchKernelGGL(k_probe_copy, dim3(blocks), dim3(TPB), 0, (hipStream_t)s, reinterpret_cast<const float4 *>(src),
                      reinterpret_cast<float4 *>(dst), floats_per_block / 4, mode);
   VT_CHECK_LAUNCH();
