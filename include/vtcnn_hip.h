@@ -35,6 +35,7 @@ extern "C" {
 #define VT_ENOMEM (-3)
 #define VT_EIO (-4)
 #define VT_EFORMAT (-5)
+#define VT_ELIMIT (-6) /* size beyond the fixed capacity of an allocation-free entry point */
 
 typedef void *vt_stream; /* hipStream_t */
 typedef struct vt_model vt_model;
@@ -314,6 +315,17 @@ int vt_head_bwd(const float *probs, const int *labels, const float *wfc, const u
 /* fc DenseLayer::backward weight/bias gradients (dense_layer.hpp:92-96): gW = pooled^T . d_logits. */
 int vt_fc_wgrad(const float *pooled, const float *d_logits, float *gw, float *gb, float *scratch, int N, int Q, int K,
                 vt_stream s);
+/* vt_fc_wgrad without the scratch argument and without any allocation.  No counterpart in the
+ * reference: it is for callers that cannot allocate device memory (code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc).  The partial slab lives in a fixed device
+ * array inside the library (3.06 MiB, held by every GPU the library has run this call on until the
+ * process ends), which bounds the size: ceil(N/128) * (Q*K + K) <= 16 * (3136*16 + 16) floats
+ * (N <= 2048 at the reference's Q = 3136 for any K <= 16), else VT_ELIMIT.  Same kernels and the
+ * same bytes in gw / gb as vt_fc_wgrad.  The first call on a device looks up that device's array
+ * address (make it outside a stream capture); calls that overlap on one GPU share the array and
+ * race: serialise them on one stream. */
+int vt_fc_wgrad_static(const float *pooled, const float *d_logits, float *gw, float *gb, int N, int Q, int K,
+                       vt_stream s);
 /* BatchNorm backward reduction step (batch_normalization_layer.hpp:187-199, 316-326): from the
  * partial sums produces grad gamma/beta and coef[2][C] = (scale, shift) such that
  * delta_in = delta * scale + shift, including the reference's row-0 variance term. */

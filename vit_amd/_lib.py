@@ -100,6 +100,7 @@ SIGNATURES = {
     "vt_eval_accumulate_grouped": (i, [p, p, i, i, i, i, p, p, p, p, p]),
     "vt_head_bwd": (i, [p] * 11 + [i, i, i, p]),
     "vt_fc_wgrad": (i, [p] * 5 + [i, i, i, p]),
+    "vt_fc_wgrad_static": (i, [p] * 4 + [i, i, i, p]),
     "vt_bn_bwd_finalize": (i, [p, i, i, l, p, p, p, p, p, p, p]),
     "vt_projector_bwd": (i, [p] * 13 + [i, i, p]),
     "vt_dense_bwd_rows": (i, [p, p, p, p, p, p, i, p, l, i, i, i, p]),

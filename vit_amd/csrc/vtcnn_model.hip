@@ -84,6 +84,7 @@ extern "C" const char *vt_error_string(int code) {
     case VT_ENOMEM: return "out of memory";
     case VT_EIO: return "file i/o error";
     case VT_EFORMAT: return "checkpoint / file format mismatch";
+    case VT_ELIMIT: return "size exceeds the fixed scratch capacity of the allocation-free entry point";
     default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
   }
 }

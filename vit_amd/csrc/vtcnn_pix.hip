@@ -915,3 +915,46 @@ extern "C" int vt_fc_wgrad(const float *pooled, const float *d_logits, float *gw
   }
   return 0;
 }
+
+
+// ---------------------------------------------------------------------------------------------
+// vt_fc_wgrad for callers that cannot allocate (code under HIP graph capture, tight serving loops,
+// harnesses that forbid hipMalloc): the per-chunk partial slab that vt_fc_wgrad takes as its
+// `scratch` argument lives in a file-scope device array instead.  Every GPU the library runs on holds
+// its own copy of the array at its own address until the process ends; the address is looked up once
+// per device (first call on that device, with that device current) and only that pointer is ever
+// handed to kernels.  k_fc_wgrad writes every slab entry the reduction reads (all Q*K + K columns of
+// each of the ceil(N/128) rows), so the previous call's contents never have to be cleared.  Calls that
+// overlap on one GPU (two streams, two threads) share the array and race.
+// ---------------------------------------------------------------------------------------------
+constexpr int FCW_STATIC_MAX_FLOATS = 16 * (3136 * KMAX + KMAX);  // 2048 images of the reference's Q = 3136, 16 classes: 3.06 MiB
+static __device__ __align__(256) float fcw_static_scratch[FCW_STATIC_MAX_FLOATS];
+constexpr int FCW_MAX_DEVICES = 64;
+static float *g_fcw_scratch_ptr[FCW_MAX_DEVICES];  // per device: address of that device's copy, 0 = not looked up yet
+
+extern "C" int vt_fc_wgrad_static(const float *pooled, const float *d_logits, float *gw, float *gb, int N, int Q, int K,
+                                  vt_stream s) {
+  if (!pooled || !d_logits || !gw || !gb) return VT_EINVAL;
+  if (N < 1 || Q < 1 || K < 1 || K > KMAX) return VT_EUNSUPPORTED;
+  const long ns = (N + FCW_CH - 1) / FCW_CH, ld = (long)Q * K + K;
+  if (ns * ld > (long)FCW_STATIC_MAX_FLOATS) return VT_ELIMIT;
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= FCW_MAX_DEVICES) return VT_EINVAL;
+  float *scratch = __atomic_load_n(&g_fcw_scratch_ptr[dev], __ATOMIC_ACQUIRE);
+  if (!scratch) {  // set-up, once per device: two racing threads look up the same address
+    void *ptr = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(fcw_static_scratch));
+    if (e != hipSuccess) return (int)e;
+    if (!ptr) return VT_EINVAL;
+    scratch = static_cast<float *>(ptr);
+    __atomic_store_n(&g_fcw_scratch_ptr[dev], scratch, __ATOMIC_RELEASE);
+  }
+  const int tiles = (Q + 15) / 16 + 1;
+  hipLaunchKernelGGL(k_fc_wgrad, dim3((tiles + NW - 1) / NW, (int)ns), dim3(TPB), 0, (hipStream_t)s, pooled, d_logits,
+                     scratch, N, Q, K, (int)ld);
+  VT_CHECK_LAUNCH();
+  // the same two column reductions as vt_fc_wgrad (kernel launches only)
+  int rc = reduce_rows(scratch, ns, Q * K, (int)ld, gw, (hipStream_t)s);
+  if (rc) return rc;
+  return reduce_rows(scratch + (size_t)Q * K, ns, K, (int)ld, gb, (hipStream_t)s);
+}
