@@ -91,31 +91,47 @@ def measured_traffic(launcher, batch, classes):
     (profiles/r01_hbm_traffic_b1024_k8.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
     runs of this same command, 2*FETCH_SIZE + WRITE_SIZE as the gfx950 notes prescribe).  Only
     valid for the configuration it was measured on; None otherwise."""
+    t = measured_traffic_table(batch, classes)
+    k = LAUNCHER_KERNEL.get(launcher)
+    return t.get(k) if (t and k) else None
+
+
+TRAFFIC_FILES = ("r02_hbm_traffic_b1024_k8.json", "r01_hbm_traffic_b1024_k8.json")  # newest first
+STEP_LAUNCHES = {"k_bn_stats_finalize": 4, "k_bn_bwd_finalize": 4}  # launches per step where it is not one
+
+
+def measured_traffic_table(batch, classes):
+    """kernel -> HBM bytes per launch from the committed PMC passes; None off the measured configuration."""
     if batch != 1024 or classes != 8:
         return None
-    try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic_b1024_k8.json")))
-        return int(t["kernels"][LAUNCHER_KERNEL[launcher]]["traffic_bytes"])
-    except (OSError, KeyError, ValueError):
-        return None
+    for fn in TRAFFIC_FILES:
+        try:
+            t = json.load(open(os.path.join(ROOT, "profiles", fn)))
+            return {k: int(v["traffic_bytes"]) for k, v in t["kernels"].items()}
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
 
 
 def cpu_baseline(batch, classes):
     """Reference CPU path timed on this box's host cores (rank 0, N=1 only): the real reference
     compiled from its own headers (oracle/_ref/ref_harness_o3, built in the build container) when
-    present, else the oracle port.  Bounded sample: three training steps of one mini-batch (about 12 s)."""
-    cores = min(16, os.cpu_count() or 1)
+    present, else the oracle port.  Bounded sample: five training steps of one mini-batch after one
+    warm-up step (about 25 s at 1024 images on 16 threads).  `cores` is the number of threads used (the
+    box's CPU share for one GPU is 16 cores); `host_cpu_count` is what the machine reports."""
+    host_cpus = os.cpu_count() or 1
+    cores = min(16, host_cpus)
     exe = os.path.join(ROOT, "oracle", "_ref", "ref_harness_o3")
     if os.access(exe, os.X_OK):
         try:
             env = dict(os.environ, OMP_NUM_THREADS=str(cores))
-            out = subprocess.run([exe, "bench", str(batch), str(classes), "3", "0"], env=env, capture_output=True,
+            out = subprocess.run([exe, "bench", str(batch), str(classes), "5", "1"], env=env, capture_output=True,
                                  text=True, timeout=300)
             r = json.loads(out.stdout.strip().splitlines()[-1])
             res = {"value": round(r["images_per_sec"], 2), "unit": "images/sec", "cores": int(r["threads"]),
-                   "kind": "reference",
-                   "sample": "3 training steps of one %d-image mini-batch, reference headers compiled -O3 "
-                             "-march=x86-64-v3 -fopenmp" % batch}
+                   "host_cpu_count": host_cpus, "kind": "reference",
+                   "sample": "5 training steps (after 1 warm-up) of one %d-image mini-batch, reference headers "
+                             "compiled -O3 -march=x86-64-v3 -fopenmp, OMP_NUM_THREADS=%d" % (batch, cores)}
             # the same binary on one core, at the reference's own batch size (a 1024-image step would take a minute)
             one = subprocess.run([exe, "bench", "32", str(classes), "3", "0"], env=dict(os.environ, OMP_NUM_THREADS="1"),
                                  capture_output=True, text=True, timeout=300)
@@ -139,7 +155,7 @@ def cpu_baseline(batch, classes):
     g = o.backward(arena, y)
     o.sgd(arena, g)
     dt = time.time() - t0
-    return {"value": round(n / dt, 2), "unit": "images/sec", "cores": cores, "kind": "port",
+    return {"value": round(n / dt, 2), "unit": "images/sec", "cores": cores, "host_cpu_count": host_cpus, "kind": "port",
             "sample": "1 training step of one %d-image mini-batch, CPU restatement (oracle/vtcnn_oracle.c)" % n}
 
 
@@ -167,6 +183,10 @@ def main():
                     help="rehearsal on one GPU: a one-rank RCCL group whose all-reduces are really launched")
     ap.add_argument("--concurrent", type=int, default=1,
                     help="0: issue the whole backward on one stream (default: two independent chains on two streams)")
+    ap.add_argument("--defer-attention", type=int, default=0,
+                    help="1: the attention block's backward and weight update run on a stream of their own "
+                         "beside the next step's forward, which never reads those weights (same bytes; "
+                         "vt_model_set_deferred_attention); only without a gradient exchange (one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel", default=None, help="launcher to time with HIP events (default: the slowest)")
     a = ap.parse_args()
@@ -193,6 +213,9 @@ def main():
     if a.bf16:
         m.set_matmul_precision(True)
     m.set_concurrency(bool(a.concurrent))
+    deferred = bool(a.defer_attention) and world == 1 and not generic and not a.exchange_alone and a.mode == "train"
+    if deferred:
+        m.set_deferred_attention(True)
     nb = 4  # resident mini-batches cycled through
     rng = np.random.default_rng(123 + rank)
     xs = torch.from_numpy(rng.integers(0, 256, size=(nb, B, dims.image_channels, dims.input_dim, dims.input_dim), dtype=np.uint8).astype(np.float32) / np.float32(255.0)).cuda()
@@ -247,8 +270,13 @@ def main():
     per_launch_ms = {k: v[0] / v[1] for k, v in breakdown.items()}
     tbl, total_bytes = algorithmic_bytes_per_image(dims, a.mode == "predict", generic)
     candidates = {k: v for k, v in breakdown.items() if k in tbl or k == "mha_bwd_rows"}
-    dominant = a.kernel or (max(candidates, key=lambda k: candidates[k][0]) if candidates else "projector_bwd")
-    m.profile(dominant)
+    # fixed choice (not "the slowest this run": two launchers tie within a microsecond): the launcher that the
+    # byte model charges with the most bytes, which is also one of the two longest in the committed kernel traces
+    dominant = a.kernel or ("generic_backward" if generic else ("head_fwd" if a.mode == "predict" else "projector_bwd"))
+    del candidates
+    # timed with HIP events on one step in eight: the two queue markers of an event pair stall the launch
+    # stream for about 4.4 us each time, which would otherwise be part of every measured step
+    m.profile(dominant + "/8")
 
     sync()
     t0 = time.perf_counter()
@@ -296,43 +324,82 @@ def main():
 
     if rank == 0:
         value = a.steps * B * world / dt
+        step_s = dt / a.steps
+        traffic_tbl = measured_traffic_table(B, a.classes) if (a.mode == "train" and not generic) else None
+        # per-launcher table from the warm-up breakdown (HIP events around every launcher; an event pair adds
+        # `pair_us` to each interval): HBM form for the launchers the byte model charges, matrix form for
+        # the attention backward, whose work is O(batch^2) and outside the byte model
+        ktable = {}
+        for name, ms in per_launch_ms.items():
+            us = ms * 1e3
+            row = {"us": round(us, 2)}
+            if name in tbl:
+                gbs = tbl[name] * B / (us * 1e-6) / 1e9
+                row.update({"bound": "hbm", "algorithmic_bytes_per_launch": tbl[name] * B, "gbs": round(gbs, 1),
+                            "frac": round(gbs / HBM_PEAK_GBS, 4)})
+            elif name == "mha_bwd_rows":
+                fl = attention_bwd_flops(dims, B)
+                tf = fl / (us * 1e-6) / 1e12
+                row.update({"bound": "mfma", "algorithmic_flops_per_launch": fl, "tflops": round(tf, 2),
+                            "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4), "peak": MFMA_BF16_PEAK_TFLOPS,
+                            "frac_of_f32_matrix_peak": round(tf / MFMA_F32_PEAK_TFLOPS, 4),
+                            "executed_bf16_flops_per_launch": int(fl * MHA_EXECUTED_PER_ALGORITHMIC)})
+            if traffic_tbl and LAUNCHER_KERNEL.get(name) in traffic_tbl:
+                row["traffic"] = traffic_tbl[LAUNCHER_KERNEL[name]]
+            ktable[name] = row
+        # the one launcher timed with HIP events over the measured steps
         k_ms, k_cnt = prof.get(dominant, (0.0, 0))
         avg_s = (k_ms / k_cnt) * 1e-3 if k_cnt else float("nan")
-        achieved = tbl.get(dominant, 0) * B / avg_s / 1e9 if k_cnt else None
-        if dominant == "mha_bwd_rows":  # compute bound on the matrix cores, not an HBM kernel
+        if dominant == "mha_bwd_rows":  # compute bound on the matrix cores: algorithmic FLOPs over time
             fl = attention_bwd_flops(dims, B)
-            ach = fl * MHA_EXECUTED_PER_ALGORITHMIC / avg_s / 1e12 if k_cnt else None
-            roof = {"bound": "mfma", "kernel": dominant, "achieved": None if ach is None else round(ach, 2),
-                    "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": None if ach is None else round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
-                    "traffic": measured_traffic(dominant, B, a.classes),
-                    "algorithmic_flops_per_launch": fl,
-                    "executed_bf16_flops_per_launch": int(fl * MHA_EXECUTED_PER_ALGORITHMIC),
-                    "fp32_equivalent_tflops": None if not k_cnt else round(fl / avg_s / 1e12, 2),
-                    "avg_launch_us": None if not k_cnt else round(avg_s * 1e6, 2), "launches_timed": k_cnt,
-                    "event_pair_overhead_us": round(pair_us, 2)}
+            ach = fl / avg_s / 1e12 if k_cnt else None
+            dom = {"bound": "mfma", "kernel": dominant, "achieved": None if ach is None else round(ach, 2),
+                   "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                   "frac": None if ach is None else round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
+                   "traffic": measured_traffic(dominant, B, a.classes), "algorithmic_flops_per_launch": fl,
+                   "executed_bf16_flops_per_launch": int(fl * MHA_EXECUTED_PER_ALGORITHMIC)}
         else:
-            roof = {"bound": "hbm", "kernel": dominant, "achieved": None if achieved is None else round(achieved, 1),
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 4),
-                    "traffic": measured_traffic(dominant, B, a.classes),
-                    "algorithmic_bytes_per_launch": tbl.get(dominant, 0) * B,
-                    "avg_launch_us": None if not k_cnt else round(avg_s * 1e6, 2), "launches_timed": k_cnt,
-                    "event_pair_overhead_us": round(pair_us, 2)}
+            ach = tbl.get(dominant, 0) * B / avg_s / 1e9 if k_cnt else None
+            dom = {"bound": "hbm", "kernel": dominant, "achieved": None if ach is None else round(ach, 1),
+                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None if ach is None else round(ach / HBM_PEAK_GBS, 4),
+                   "traffic": measured_traffic(dominant, B, a.classes),
+                   "algorithmic_bytes_per_launch": tbl.get(dominant, 0) * B}
+        dom.update({"avg_launch_us": None if not k_cnt else round(avg_s * 1e6, 2), "launches_timed": k_cnt, "timed_every_nth_step": 8,
+                    "event_pair_overhead_us": round(pair_us, 2),
+                    "chosen": "fixed: the launcher with the most algorithmic bytes" if not a.kernel else "--kernel"})
+        # headline roofline: HBM is the bounding roofline of this shape (every contraction is 8 to 32 deep), so
+        # the figure is the whole step: algorithmic bytes of one step over the measured time of one step
+        # (all launches of the step; `ms_per_step` of this same line)
+        step_gbs = total_bytes * B / step_s / 1e9
+        roof = {"bound": "hbm", "kernel": "whole step (every launch of forward + backward + update)",
+                "achieved": round(step_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(step_gbs / HBM_PEAK_GBS, 4),
+                "traffic": None if not traffic_tbl else int(sum(v * STEP_LAUNCHES.get(k, 1) for k, v in traffic_tbl.items()
+                                                                if k != "k_probe_copy")),
+                "algorithmic_bytes_per_launch": total_bytes * B, "avg_launch_us": round(step_s * 1e6, 2),
+                "launches_timed": a.steps,
+                "definition": "algorithmic layer-boundary bytes per image x images per step / measured step time; "
+                              "per-launcher figures in `kernels`, the event-timed dominant launcher in `dominant_kernel`",
+                "dominant_kernel": dom, "kernels": ktable}
         res = {
             "metric": ("train" if a.mode == "train" else "predict") + " images/sec (whole node) VTCNN " + {"blood": "BloodMNIST"}.get(a.shape, a.shape), "value": round(value, 1), "unit": "images/sec",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if a.bf16 else "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if a.bf16 else "f32",
+            "emulation": None if (a.bf16 or generic) else "fp32 storage and accumulation; the 16- and 32-deep contractions "
+                         "(projector value/downsample and delta products, tokenizer input delta, all attention-backward products) "
+                         "run as bf16x3 hi/lo split products with fp32 accumulate (about 2^-17 relative per product), "
+                         "the narrow ones on exact fp32 MFMA",
+            "data": "synthetic",
             "config": {"workload": ("VTCNN train step (forward+backward+SGD)" if a.mode == "train" else
                                     "VTCNN predict step (eval-mode forward)") + ", %s shape %dx%dx%d, %d classes, "
                                    "mini-batch %d per GPU, fp32, seed-42 reference init" % (
                                        {"blood": "BloodMNIST"}.get(a.shape, a.shape), dims.image_channels, dims.input_dim,
                                        dims.input_dim, a.classes, B),
-                       "hip_graph": bool(use_graph), "two_stream_backward": bool(a.concurrent) and not generic, "statistics_group": a.group if a.mode == "predict" else 0, "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world,
+                       "hip_graph": bool(use_graph), "two_stream_backward": bool(a.concurrent) and not generic, "deferred_attention_backward": deferred, "statistics_group": a.group if a.mode == "predict" else 0, "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world,
                        "exchange_overlapped": bool(dp.overlap and a.mode == "train" and not use_graph),
                        "grad_allreduce_floats": int(m.layout.n_trainable) if world > 1 else 0},
             "roofline": roof,
-            "whole_step_hbm_frac": round(value / world * total_bytes / (HBM_PEAK_GBS * 1e9), 4),
+            "whole_step_hbm_frac": round(value / world * total_bytes / (HBM_PEAK_GBS * 1e9), 4),  # algorithmic bytes, not measured
             "measured_copy_gbs": None if copy_gbs is None else round(copy_gbs, 1),
             "algorithmic_bytes_per_image": total_bytes,
             "launcher_us": {k: round(1e3 * v, 2) for k, v in sorted(per_launch_ms.items(), key=lambda kv: -kv[1])},

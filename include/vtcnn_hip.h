@@ -94,6 +94,19 @@ int vt_model_set_matmul_precision(vt_model *m, int bf16);
  * caller's stream.  General-shape models ignore it.  No counterpart in the reference. */
 int vt_model_set_concurrency(vt_model *m, int on);
 
+/* Deferred attention backward (headline shape; no counterpart in the reference).  on != 0: vt_model_backward
+ * issues the attention block's backward (MultiHeadAttention::backward's q/k/v weight gradients,
+ * layers/multi_head_attention.hpp:109-181) on a stream of the model's own instead of the caller's, and
+ * vt_model_sgd_step updates those weights on that stream right behind it; both then run beside the rest of
+ * the step and the NEXT step's forward, which never reads the attention weights (the layer's output is
+ * discarded by the zero concat, multi_head_attention.hpp:100).  The token matrix is double-buffered for
+ * this.  The next vt_model_backward, vt_model_adam_step, every host copy of the arenas (get / set / save /
+ * load / read) and graph capture wait for the deferred work first, so results are the same bytes as
+ * with on == 0; a caller that reads the gradient or weight arena on the device itself (a collective)
+ * calls vt_model_attention_join first, which makes stream s wait for it. */
+int vt_model_set_deferred_attention(vt_model *m, int on);
+int vt_model_attention_join(vt_model *m, vt_stream s);
+
 /* VTCNN::forward (model/vit_cnn.hpp:103-213).  d_images: device [n, Ci, H, W] fp32.
  * d_probs: device [n, K] softmax output, written in place by the head kernel and read again by the
  * backward pass and vt_model_metrics, so it must stay untouched until those have run (NULL: the
@@ -154,7 +167,8 @@ int vt_model_metrics(vt_model *m, const int *d_labels, float *d_loss_sum, int *d
 
 /* Per-launcher timing with HIP events recorded on the caller's stream around the launchers that
  * vt_model_forward / backward / sgd_step issue.  filter: NULL or "" = off, "*" = every launcher,
- * otherwise one launcher name without the vt_ prefix (e.g. "projector_bwd").
+ * otherwise one launcher name without the vt_ prefix (e.g. "projector_bwd"), optionally followed by
+ * "/n" to time only every n-th of its launches (an event pair costs the stream about 4 microseconds).
  * vt_model_profile_read synchronises the device, returns the number of distinct names seen and,
  * for 0 <= idx < that number, the name, the summed milliseconds and the launch count since the
  * last vt_model_profile call.  No counterpart in the reference (it has no profiler hooks). */

@@ -355,6 +355,49 @@ def test_two_stream_backward_is_bit_identical_to_one_stream(n):
         assert np.array_equal(wa, c.get_arena()), t
 
 
+@pytest.mark.parametrize("n", [32, 256])
+def test_deferred_attention_backward_is_bit_identical(n):
+    """vt_model_set_deferred_attention: the attention block's backward and its weight update trail on the
+    model's own stream into the next forward.  Weights after every step, the gradients read between
+    backward and update, an eval forward in between and varying batch sizes all give exactly the bytes of
+    the in-order step (a token buffer overwritten too early, a missed join or an update landing late
+    would show from the second step on)."""
+    import torch
+    from vit_amd import VTCNN, Dims
+    rng = np.random.default_rng(7 * n)
+    sizes = [n, n, n // 2, n, n]
+    xs = [torch.from_numpy(rng.integers(0, 256, size=(k, 1, 28, 28)).astype(np.float32) / np.float32(255.0)).cuda() for k in sizes]
+    ys = [torch.from_numpy(rng.integers(0, 8, size=k).astype(np.int32)).cuda() for k in sizes]
+    a, b = (VTCNN(Dims(num_classes=8), max_batch=n, seed=42) for _ in range(2))
+    b.set_deferred_attention(True)
+    first, count = a.attention_range()
+    for t in range(len(sizes)):
+        pa = a.forward(xs[t]).clone(); a.backward(ys[t])
+        pb = b.forward(xs[t]).clone(); b.backward(ys[t])
+        assert torch.equal(pa, pb), t
+        if t == 1:  # gradients read while the deferred block is in flight: complete and identical
+            ga, gb = a.get_grads(), b.get_grads()
+            assert np.abs(ga[first:first + count]).max() > 0
+            assert np.array_equal(ga, gb), t
+        a.update_weights(float(n)); b.update_weights(float(n))
+        if t == 2:  # two forwards in a row (evaluation) while the update is still trailing
+            for m in (a, b):
+                m.set_training(False)
+            ea = a.forward(xs[0]).clone(); a.forward(xs[1])
+            eb = b.forward(xs[0]).clone(); b.forward(xs[1])
+            assert torch.equal(ea, eb)
+            for m in (a, b):
+                m.set_training(True)
+        if t != 3:  # step 3 -> 4 runs without any host read in between
+            assert np.array_equal(a.get_arena(), b.get_arena()), t
+    assert np.array_equal(a.get_arena(), b.get_arena())
+    assert np.array_equal(a.get_grads(), b.get_grads())
+    b.set_deferred_attention(False)
+    a.forward(xs[0]); a.backward(ys[0]); a.update_weights(float(n))
+    b.forward(xs[0]); b.backward(ys[0]); b.update_weights(float(n))
+    assert np.array_equal(a.get_arena(), b.get_arena())
+
+
 def test_batch_size_may_change_from_step_to_step():
     """One model (max_batch 96) stepping through batches of 96, 5, 33, 1, 64, 96 images (the short last
     batch of an epoch, then full ones again) computes, at every step, exactly what a model created for that

@@ -53,6 +53,8 @@ SIGNATURES = {
     "vt_model_set_matmul_precision": (i, [p, i]),
     "vt_model_set_training": (i, [p, i]),
     "vt_model_set_concurrency": (i, [p, i]),
+    "vt_model_set_deferred_attention": (i, [p, i]),
+    "vt_model_attention_join": (i, [p, p]),
     "vt_model_keep_internals": (i, [p, i]),
     "vt_model_forward": (i, [p, p, i, p, p]),
     "vt_model_forward_grouped": (i, [p, p, i, i, p, p]),

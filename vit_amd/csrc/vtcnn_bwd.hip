@@ -91,6 +91,14 @@ __global__ __launch_bounds__(FIN_T) void k_bn_bwd_finalize(const float *__restri
                                                            float *__restrict__ gbeta, float *__restrict__ coef) {
   __shared__ double sh[2][FIN_T / 64];
   const int tid = threadIdx.x, c = blockIdx.x;
+  // operands of the closing arithmetic, requested before the partial loads so that their round trip is hidden
+  float gm = 0.f, mean = 0.f, inv = 0.f, x0 = 0.f;
+  if (tid == 0) {
+    gm = gamma[c];
+    mean = stat[c];
+    inv = stat[C + c];
+    x0 = in_row0[c];
+  }
   double s1 = 0.0, s2 = 0.0;
   for (int b0 = tid; b0 < nb; b0 += 8 * FIN_T) {
     float a[8], q[8];
@@ -125,13 +133,12 @@ __global__ __launch_bounds__(FIN_T) void k_bn_bwd_finalize(const float *__restri
       t2 += sh[1][k];
     }
     const float S1 = (float)t1, S2 = (float)t2;
-    const float gm = gamma[c], mean = stat[c], inv = stat[C + c];
     const float R = (float)rows_total;
     ggamma[c] = S2;
     gbeta[c] = S1;
     const float dvar = -0.5f * gm * inv * inv * S2;
     const float dmean = -gm * inv * S1;
-    const float k1 = ((dvar * 2.0f) * (1.0f / R)) * (in_row0[c] - mean);
+    const float k1 = ((dvar * 2.0f) * (1.0f / R)) * (x0 - mean);
     const float k2 = dmean * (1.0f / R);
     coef[c] = gm * inv;
     coef[C + c] = k1 + k2;
@@ -140,10 +147,12 @@ __global__ __launch_bounds__(FIN_T) void k_bn_bwd_finalize(const float *__restri
 
 // update_weights + SGD::update (reference e.g. layers/dense_layer.hpp:102-112,
 // utils/optimizer.hpp:22-28):  g <- g * (1/divisor);  w <- w - g * lr.  Two roundings, as there.
+// Floats [hole_first, hole_first + hole_count) are left untouched (weights and gradients): the model's
+// deferred attention update owns that range while its gradients are still being computed.
 __global__ __launch_bounds__(TPB) void k_sgd(float *__restrict__ w, float *__restrict__ gr, int n, float lr,
-                                             float inv_div, int zero_grad) {
+                                             float inv_div, int zero_grad, int hole_first, int hole_count) {
   const int i = blockIdx.x * TPB + threadIdx.x;
-  if (i < n) {
+  if (i < n && (unsigned)(i - hole_first) >= (unsigned)hole_count) {
     const float gs = __fmul_rn(gr[i], inv_div);
     w[i] = __fsub_rn(w[i], __fmul_rn(gs, lr));
     if (zero_grad) gr[i] = 0.f;
@@ -305,7 +314,15 @@ extern "C" int vt_probe_copy(const float *src, float *dst, int blocks, long floa
 extern "C" int vt_sgd_update(float *w, float *g, int n, float lr, float divisor, int zero_grad, vt_stream s) {
   if (n < 1 || divisor == 0.f) return VT_EINVAL;
   hipLaunchKernelGGL(k_sgd, dim3((n + TPB - 1) / TPB), dim3(TPB), 0, (hipStream_t)s, w, g, n, lr, 1.0f / divisor,
-                     zero_grad);
+                     zero_grad, 0, 0);
+  VT_CHECK_LAUNCH();
+  return 0;
+}
+
+int vt::sgd_update_hole(float *w, float *g, int n, float lr, float divisor, int hole_first, int hole_count, hipStream_t s) {
+  if (n < 1 || divisor == 0.f || hole_first < 0 || hole_count < 0) return VT_EINVAL;
+  hipLaunchKernelGGL(k_sgd, dim3((n + TPB - 1) / TPB), dim3(TPB), 0, s, w, g, n, lr, 1.0f / divisor, 1, hole_first,
+                     hole_count);
   VT_CHECK_LAUNCH();
   return 0;
 }

@@ -56,6 +56,27 @@ __device__ __forceinline__ void block_sum(float (&v)[NV], float *red) {
   }
 }
 
+// The same for a workgroup of NWV waves (kernels that run more than TPB threads per image).
+template <int NV, int NWV>
+__device__ __forceinline__ void block_sum_w(float (&v)[NV], float *red) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = wave_sum(v[i]);
+  __syncthreads();
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) red[wave * NV + i] = v[i];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < NWV; ++w) s += red[w * NV + i];
+    v[i] = s;
+  }
+}
+
 template <int NV>
 __device__ __forceinline__ void block_max(float (&v)[NV], float *red) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -147,6 +168,8 @@ int reduce_rows(const float *slab, long rows, int cols, int ld, float *out, hipS
 void reduce_batch_begin(ReduceBatch *b);         // b must outlive the matching flush / abandon
 int reduce_batch_flush(hipStream_t s);           // launches the queued jobs and closes the batch
 void reduce_batch_abandon();                     // closes the batch without launching
+// vt_sgd_update (gradients cleared) that leaves floats [hole_first, hole_first + hole_count) untouched
+int sgd_update_hole(float *w, float *g, int n, float lr, float divisor, int hole_first, int hole_count, hipStream_t s);
 
 }  // namespace vt
 

@@ -145,6 +145,13 @@ __global__ __launch_bounds__(FIN_T) void k_bn_stats_finalize(const float *__rest
   part += (size_t)bfirst * 2 * C;
   const long last_cnt = rows_here - (long)(nb - 1) * rows_per_block;
   const double rc = 1.0 / (double)rows_per_block, rc_last = 1.0 / (double)last_cnt;
+  // the running buffers are only needed by the very last instruction: requested now, their round trip runs
+  // under the partial loads instead of after the reduction
+  float rm_old = 0.f, rv_old = 0.f;
+  if (tid == 0 && batch_mv == nullptr) {
+    rm_old = run_mean[c];
+    rv_old = run_var[c];
+  }
   double S = 0.0, Q = 0.0, U = 0.0;
   for (int b0 = tid; b0 < nb; b0 += 8 * FIN_T) {
     float sv[8], qv[8];
@@ -194,8 +201,8 @@ __global__ __launch_bounds__(FIN_T) void k_bn_stats_finalize(const float *__rest
       batch_mv[(size_t)grp * 2 * C + c] = mean;
       batch_mv[(size_t)grp * 2 * C + C + c] = var;
     } else {
-      run_mean[c] = mean * BN_MOM + run_mean[c] * (1 - BN_MOM);
-      run_var[c] = var * BN_MOM + run_var[c] * (1 - BN_MOM);
+      run_mean[c] = mean * BN_MOM + rm_old * (1 - BN_MOM);
+      run_var[c] = var * BN_MOM + rv_old * (1 - BN_MOM);
     }
   }
 }

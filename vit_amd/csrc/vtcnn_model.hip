@@ -40,6 +40,15 @@ struct vt_model {
   hipStream_t side = nullptr;
   hipEvent_t ev_rows = nullptr, ev_join = nullptr;
   bool concurrent = true, side_open = false;
+  // Deferred attention backward (vt_model_set_deferred_attention): the attention block's backward and the
+  // update of its weights run on attn_stream beside the NEXT step's forward, which never reads those
+  // weights.  tokbuf[2]: the token matrix is double-buffered so that the next forward can write its tokens
+  // while the attention backward still reads this step's.
+  hipStream_t attn_stream = nullptr;
+  hipEvent_t ev_attn_go = nullptr, ev_attn_done = nullptr;
+  bool defer_attn = false, attn_inflight = false, attn_update_pending = false, capturing = false;
+  float *tokbuf[2] = {nullptr, nullptr};
+  int tok_parity = 0, attn_tok_parity = 0;
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec = nullptr;
   bool keep_internals = false;  // also store the two attention maps (test aid)
@@ -62,6 +71,7 @@ struct vt_model {
   float *loss_buf;
   // optional per-launcher timing with HIP events on the caller's stream
   std::string prof_filter;  // "" = off, "*" = every launcher, else one launcher name
+  int prof_period = 1, prof_seen = 0;  // time every prof_period-th matching launch only
   std::vector<hipEvent_t> prof_ev;
   std::vector<int> prof_name;  // name index per event pair
   std::vector<std::string> prof_names;
@@ -90,6 +100,30 @@ extern "C" const char *vt_error_string(int code) {
 }
 extern "C" int vt_version(void) { return 1; }
 
+// Makes the model's device current for the lifetime of the object and restores the caller's afterwards.
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = true;
+  explicit DeviceGuard(int device) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != device) ok = hipSetDevice(device) == hipSuccess;
+  }
+  ~DeviceGuard() {
+    int now = -1;
+    if (prev >= 0 && hipGetDevice(&now) == hipSuccess && now != prev) (void)hipSetDevice(prev);
+  }
+};
+
+// Host copies of the arenas wait for every stream of the device first: the step may have been issued on
+// non-blocking streams (the caller's, the model's side streams, a deferred attention update), which a
+// blocking copy on the null stream does not order against.
+static int quiesce(vt_model *m) {
+  HIPCHK(hipDeviceSynchronize());
+  m->attn_inflight = false;
+  m->attn_update_pending = false;
+  return 0;
+}
+
 static int dalloc(vt_model *m, float **p, size_t floats, const char *name = nullptr) {
   void *q = nullptr;
   if (hipMalloc(&q, std::max<size_t>(floats, 4) * sizeof(float)) != hipSuccess) return VT_ENOMEM;
@@ -107,7 +141,8 @@ extern "C" int vt_model_create(const vt_dims *dims, int max_batch, int device, f
   const bool headline = dims->vt_channels == C2 && dims->tokens == L && dims->token_channels == D && dims->heads == HEADS &&
                         dims->input_dim * dims->input_dim <= PPT * TPB && dims->num_classes <= KMAX &&
                         dims->image_channels <= 4;
-  HIPCHK(hipSetDevice(device));
+  DeviceGuard dg(device);
+  if (!dg.ok) return VT_EINVAL;
   vt_model *m = new vt_model();
   m->d = *dims;
   m->lo = lo;
@@ -142,6 +177,7 @@ extern "C" int vt_model_create(const vt_dims *dims, int max_batch, int device, f
   rc |= dalloc(m, &m->conv, N * P * C1, "fwd.conv_out");
   rc |= dalloc(m, &m->tokstat, N * 2 * L, "fwd.tok_stat");
   rc |= dalloc(m, &m->tok, NL * D, "fwd.tok_out");
+  m->tokbuf[0] = m->tok;
   rc |= dalloc(m, &m->a, NL * D, "fwd.tr_a");
   rc |= dalloc(m, &m->hdn, NL * D, "fwd.tr_hdn");
   rc |= dalloc(m, &m->s2, NL * D, "fwd.tr_s2");
@@ -207,13 +243,14 @@ extern "C" int vt_model_create(const vt_dims *dims, int max_batch, int device, f
 
 extern "C" int vt_model_destroy(vt_model *m) {
   if (!m) return 0;
-  (void)hipSetDevice(m->device);
+  DeviceGuard dg(m->device);
   (void)hipDeviceSynchronize();
   if (m->graph_exec) (void)hipGraphExecDestroy(m->graph_exec);
   if (m->graph) (void)hipGraphDestroy(m->graph);
   if (m->gstream) (void)hipStreamDestroy(m->gstream);
   if (m->side) (void)hipStreamDestroy(m->side);
-  for (hipEvent_t e : {m->ev_rows, m->ev_join})
+  if (m->attn_stream) (void)hipStreamDestroy(m->attn_stream);
+  for (hipEvent_t e : {m->ev_rows, m->ev_join, m->ev_attn_go, m->ev_attn_done})
     if (e) (void)hipEventDestroy(e);
   for (void *p : m->allocs) (void)hipFree(p);
   for (hipEvent_t e : m->prof_ev) (void)hipEventDestroy(e);
@@ -233,19 +270,25 @@ extern "C" float *vt_model_grads_ptr(vt_model *m) { return m ? m->grads : nullpt
 
 extern "C" int vt_model_set_arena(vt_model *m, const float *host) {
   if (!m || !host) return VT_EINVAL;
-  HIPCHK(hipSetDevice(m->device));
+  DeviceGuard dg(m->device);
+  if (!dg.ok) return VT_EINVAL;
+  VTCHK(quiesce(m));
   HIPCHK(hipMemcpy(m->arena, host, m->lo.n_total * sizeof(float), hipMemcpyHostToDevice));
   return 0;
 }
 extern "C" int vt_model_get_arena(vt_model *m, float *host) {
   if (!m || !host) return VT_EINVAL;
-  HIPCHK(hipSetDevice(m->device));
+  DeviceGuard dg(m->device);
+  if (!dg.ok) return VT_EINVAL;
+  VTCHK(quiesce(m));
   HIPCHK(hipMemcpy(host, m->arena, m->lo.n_total * sizeof(float), hipMemcpyDeviceToHost));
   return 0;
 }
 extern "C" int vt_model_get_grads(vt_model *m, float *host) {
   if (!m || !host) return VT_EINVAL;
-  HIPCHK(hipSetDevice(m->device));
+  DeviceGuard dg(m->device);
+  if (!dg.ok) return VT_EINVAL;
+  VTCHK(quiesce(m));
   HIPCHK(hipMemcpy(host, m->grads, m->lo.n_trainable * sizeof(float), hipMemcpyDeviceToHost));
   return 0;
 }
@@ -610,6 +653,7 @@ constexpr size_t kMaxProfPairs = 16384;
 // Records a start event; returns the pair slot or -1 when this launcher is not being timed.
 int prof_begin(vt_model *m, const char *name, hipStream_t hs) {
   if (m->prof_filter.empty() || (m->prof_filter != "*" && m->prof_filter != name)) return -1;
+  if (m->prof_period > 1 && (m->prof_seen++ % m->prof_period) != 0) return -1;
   if (m->prof_used >= kMaxProfPairs) return -1;
   if (m->prof_ev.size() < 2 * (m->prof_used + 1)) {
     hipEvent_t a, b;
@@ -647,6 +691,13 @@ void prof_end(vt_model *m, int slot, hipStream_t hs) {
 extern "C" int vt_model_profile(vt_model *m, const char *filter) {
   if (!m) return VT_EINVAL;
   m->prof_filter = filter ? filter : "";
+  m->prof_period = 1;
+  m->prof_seen = 0;
+  const size_t slash = m->prof_filter.find('/');
+  if (slash != std::string::npos) {  // "name/period"
+    m->prof_period = std::max(1, std::atoi(m->prof_filter.c_str() + slash + 1));
+    m->prof_filter.resize(slash);
+  }
   m->prof_used = 0;
   return 0;
 }
@@ -727,6 +778,36 @@ extern "C" int vt_model_set_training(vt_model *m, int training) {
   return 0;
 }
 
+// Makes stream s wait for a deferred attention backward (and the update of its weights) still in flight.
+static int attention_join(vt_model *m, hipStream_t s) {
+  if (!m->attn_inflight) return 0;
+  HIPCHK(hipStreamWaitEvent(s, m->ev_attn_done, 0));
+  m->attn_inflight = false;
+  m->attn_update_pending = false;
+  return 0;
+}
+
+extern "C" int vt_model_set_deferred_attention(vt_model *m, int on) {
+  if (!m) return VT_EINVAL;
+  if (m->gen) return on ? VT_EUNSUPPORTED : 0;
+  DeviceGuard dg(m->device);
+  if (!dg.ok) return VT_EINVAL;
+  VTCHK(quiesce(m));
+  if (on && !m->attn_stream) {
+    if (dalloc(m, &m->tokbuf[1], (size_t)m->maxN * L * D) != 0) return VT_ENOMEM;
+    HIPCHK(hipStreamCreateWithFlags(&m->attn_stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&m->ev_attn_go, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&m->ev_attn_done, hipEventDisableTiming));
+  }
+  m->defer_attn = on != 0;
+  return 0;
+}
+
+extern "C" int vt_model_attention_join(vt_model *m, vt_stream s) {
+  if (!m) return VT_EINVAL;
+  return attention_join(m, (hipStream_t)s);
+}
+
 // group = 0: the n images are one mini-batch.  group > 0 (eval mode only): the n images are
 // consecutive mini-batches of `group` images (the last may be short), each with its own
 // BatchNorm1D statistics, processed by the same launches: what Trainer::evaluate_test computes
@@ -743,6 +824,15 @@ static int forward_impl(vt_model *m, const float *d_images, int n, int group, fl
     return 0;
   }
   if (group >= n) group = 0;
+  if (m->defer_attn && !m->capturing && m->tokbuf[1]) {
+    // the deferred attention backward of the previous step may still be reading its token matrix: this
+    // forward writes the other one (and waits only if that one, too, is still being read)
+    const int next = m->tok_parity ^ 1;
+    if (m->attn_inflight && m->attn_tok_parity == next) VTCHK(attention_join(m, (hipStream_t)s));
+    m->tok_parity = next;
+    m->tok = m->tokbuf[next];
+    m->named["fwd.tok_out"].first = m->tok;
+  }
   const int H = m->d.input_dim, P = m->P, Ci = m->d.image_channels, K = m->K;
   const long NL = (long)n * L;
   const int nrb = (int)((NL + RB - 1) / RB);
@@ -899,17 +989,33 @@ static bool backward_ready(const vt_model *m) { return m && m->lastN >= 1 && m->
 
 extern "C" int vt_model_backward(vt_model *m, const int *d_labels, vt_stream s) {
   if (!backward_ready(m) || !d_labels) return VT_EINVAL;
+  // the previous step's deferred attention read buffers this backward is about to overwrite
+  VTCHK(attention_join(m, (hipStream_t)s));
+  const bool defer = m->defer_attn && !m->gen && !m->capturing && m->attn_stream != nullptr;
   BatchScope batch(m);
   VTCHK(backward_main(m, d_labels, s));
-  VTCHK(backward_attention(m, nullptr, s));
+  if (defer) HIPCHK(hipEventRecord(m->ev_attn_go, (hipStream_t)s));  // everything the attention block reads exists
+  else VTCHK(backward_attention(m, nullptr, s));
   VTCHK(join_side(m, s));
   if (batch.on) STEP("reduce_rows", reduce_batch_flush((hipStream_t)s));
   m->attention_pending = false;
+  if (defer) {
+    // the attention block on its own stream: it overlaps the rest of this step and the next forward
+    HIPCHK(hipStreamWaitEvent(m->attn_stream, m->ev_attn_go, 0));
+    BatchScope abatch(m);
+    VTCHK(backward_attention(m, nullptr, (vt_stream)m->attn_stream));
+    if (abatch.on) STEP_ON("reduce_rows", m->attn_stream, reduce_batch_flush(m->attn_stream));
+    HIPCHK(hipEventRecord(m->ev_attn_done, m->attn_stream));
+    m->attn_inflight = true;
+    m->attn_update_pending = true;
+    m->attn_tok_parity = m->tok_parity;
+  }
   return 0;
 }
 
 extern "C" int vt_model_backward_main(vt_model *m, const int *d_labels, vt_stream s) {
   if (!backward_ready(m) || !d_labels) return VT_EINVAL;
+  VTCHK(attention_join(m, (hipStream_t)s));
   BatchScope batch(m);
   VTCHK(backward_main(m, d_labels, s));
   VTCHK(join_side(m, s));
@@ -937,12 +1043,24 @@ extern "C" int vt_model_attention_range(const vt_model *m, int *first, int *coun
 
 extern "C" int vt_model_sgd_step(vt_model *m, float lr, float divisor, vt_stream s) {
   if (!m) return VT_EINVAL;
+  if (m->attn_inflight && m->attn_update_pending) {
+    // the attention gradients are still being computed on the model's attention stream: everything else is
+    // updated here, their range there, right behind the kernels that produce it
+    int first = 0, count = 0;
+    VTCHK(vt_model_attention_range(m, &first, &count));
+    STEP("sgd_update", sgd_update_hole(m->arena, m->grads, m->lo.n_trainable, lr, divisor, first, count, (hipStream_t)s));
+    STEP_ON("sgd_update", m->attn_stream, vt_sgd_update(m->arena + first, m->grads + first, count, lr, divisor, 1, (vt_stream)m->attn_stream));
+    HIPCHK(hipEventRecord(m->ev_attn_done, m->attn_stream));
+    m->attn_update_pending = false;
+    return 0;
+  }
   STEP("sgd_update", vt_sgd_update(m->arena, m->grads, m->lo.n_trainable, lr, divisor, 1, s));
   return 0;
 }
 
 extern "C" int vt_model_adam_step(vt_model *m, float lr, float beta1, float beta2, float eps, float divisor, vt_stream s) {
   if (!m || divisor == 0.f) return VT_EINVAL;
+  VTCHK(attention_join(m, (hipStream_t)s));
   if (!m->adam_m1) {
     HIPCHK(hipSetDevice(m->device));
     if (dalloc(m, &m->adam_m1, m->lo.n_trainable) != 0 || dalloc(m, &m->adam_m2, m->lo.n_trainable) != 0) return VT_ENOMEM;
@@ -958,6 +1076,7 @@ extern "C" int vt_model_adam_step(vt_model *m, float lr, float beta1, float beta
 extern "C" int vt_model_sgd_step_range(vt_model *m, float lr, float divisor, int first, int count, vt_stream s) {
   if (!m || first < 0 || count < 0 || (first & 3) || (long)first + count > m->lo.n_trainable) return VT_EINVAL;
   if (count == 0) return 0;
+  VTCHK(attention_join(m, (hipStream_t)s));
   STEP("sgd_update", vt_sgd_update(m->arena + first, m->grads + first, count, lr, divisor, 1, s));
   return 0;
 }
@@ -971,10 +1090,12 @@ static int capture_graph(vt_model *m, Body body) {
   if (m->graph) { (void)hipGraphDestroy(m->graph); m->graph = nullptr; }
   const std::string saved = m->prof_filter;
   m->prof_filter.clear();  // no timing events inside the captured region
-  HIPCHK(hipDeviceSynchronize());
+  VTCHK(quiesce(m));
+  m->capturing = true;  // a captured step keeps its attention backward inside the graph
   HIPCHK(hipStreamBeginCapture(m->gstream, hipStreamCaptureModeThreadLocal));
   const int rc = body((vt_stream)m->gstream);
   const hipError_t e = hipStreamEndCapture(m->gstream, &m->graph);
+  m->capturing = false;
   m->prof_filter = saved;
   if (rc != 0) return rc;
   if (e != hipSuccess) return (int)e;
@@ -1020,8 +1141,8 @@ extern "C" long vt_model_read(vt_model *m, const char *name, float *host, long c
     cnt = per_max / m->maxN * m->lastN;
   if (!host) return cnt;
   if (capacity < cnt) return VT_EINVAL;
-  if (hipSetDevice(m->device) != hipSuccess) return VT_EINVAL;
-  if (hipDeviceSynchronize() != hipSuccess) return VT_EINVAL;
+  DeviceGuard dg(m->device);
+  if (!dg.ok || quiesce(m) != 0) return VT_EINVAL;
   const float *src = it->second.first;
   if (src == m->probs && m->last_probs) src = m->last_probs;
   if (hipMemcpy(host, src, cnt * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return VT_EINVAL;

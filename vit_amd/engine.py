@@ -20,8 +20,9 @@ def Dims(num_classes=10, image_channels=1, input_dim=28, tokens=16, token_channe
     return VtDims(image_channels, input_dim, tokens, token_channels, vt_channels, heads, num_classes)
 
 
-def _stream_handle():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+def _stream_handle(device=None):
+    """The caller's current stream ON THE GIVEN DEVICE (a model's own), not on whichever device is current."""
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
 class Layout:
@@ -126,7 +127,7 @@ class VTCNN:
         self._n = n
         self._x = x  # keep alive: backward re-reads the images
         check(lib.vt_model_forward(self._h, C.c_void_p(x.data_ptr()), n, C.c_void_p(self._probs.data_ptr()),
-                                   _stream_handle()), "vt_model_forward")
+                                   _stream_handle(self.device)), "vt_model_forward")
         return self._probs[:n]
 
     def forward_grouped(self, x, group):
@@ -139,34 +140,34 @@ class VTCNN:
         self._n = n
         self._x = x
         check(lib.vt_model_forward_grouped(self._h, C.c_void_p(x.data_ptr()), n, int(group),
-                                           C.c_void_p(self._probs.data_ptr()), _stream_handle()), "vt_model_forward_grouped")
+                                           C.c_void_p(self._probs.data_ptr()), _stream_handle(self.device)), "vt_model_forward_grouped")
         return self._probs[:n]
 
     def backward(self, labels):
         """VTCNN::backward for the last forward; labels int32 CUDA tensor [N] (class indices; the
         reference passes the one-hot matrix, utils/trainer.hpp:47-52)."""
         assert labels.is_cuda and labels.dtype == torch.int32 and labels.numel() == self._n
-        check(lib.vt_model_backward(self._h, C.c_void_p(labels.data_ptr()), _stream_handle()), "vt_model_backward")
+        check(lib.vt_model_backward(self._h, C.c_void_p(labels.data_ptr()), _stream_handle(self.device)), "vt_model_backward")
 
     def backward_main(self, labels):
         """Backward of everything but the attention block: afterwards every gradient outside
         attention_range() is final (vt_model_backward_main)."""
         assert labels.is_cuda and labels.dtype == torch.int32 and labels.numel() == self._n
-        check(lib.vt_model_backward_main(self._h, C.c_void_p(labels.data_ptr()), _stream_handle()), "vt_model_backward_main")
+        check(lib.vt_model_backward_main(self._h, C.c_void_p(labels.data_ptr()), _stream_handle(self.device)), "vt_model_backward_main")
 
     def backward_attention(self, out=None):
         """The attention block's backward: writes the gradients inside attention_range(), or into
         `out` (float32 CUDA tensor of that many elements) instead of the gradient arena."""
         if out is not None:
             assert out.is_cuda and out.dtype == torch.float32 and out.is_contiguous() and out.numel() == self.attention_range()[1]
-        check(lib.vt_model_backward_attention(self._h, C.c_void_p(out.data_ptr() if out is not None else None), _stream_handle()),
+        check(lib.vt_model_backward_attention(self._h, C.c_void_p(out.data_ptr() if out is not None else None), _stream_handle(self.device)),
               "vt_model_backward_attention")
 
     def update_block(self, batch_size, first, grads):
         """SGD on arena[first : first + len(grads)] with the gradients in `grads` (cleared afterwards)."""
         assert grads.is_cuda and grads.dtype == torch.float32 and grads.is_contiguous()
         check(lib.vt_sgd_update(C.c_void_p(self.arena.data_ptr() + 4 * int(first)), C.c_void_p(grads.data_ptr()), grads.numel(),
-                                self.lr, float(batch_size), 1, _stream_handle()), "vt_sgd_update")
+                                self.lr, float(batch_size), 1, _stream_handle(self.device)), "vt_sgd_update")
 
     def attention_range(self):
         """(first, count): the floats of the arenas that hold mha.q*/k*/v*."""
@@ -176,20 +177,21 @@ class VTCNN:
 
     def update_weights(self, batch_size=32.0):
         """VTCNN::update_weights + zero_grad with the reference's constant divisor (trainer.hpp:53)."""
-        check(lib.vt_model_sgd_step(self._h, self.lr, float(batch_size), _stream_handle()), "vt_model_sgd_step")
+        check(lib.vt_model_sgd_step(self._h, self.lr, float(batch_size), _stream_handle(self.device)), "vt_model_sgd_step")
 
     def update_weights_adam(self, batch_size=32.0, lr=None, beta1=0.9, beta2=0.999, eps=1e-8):
         """One fused Adam pass over the trainable region (extension: the reference has SGD only)."""
         check(lib.vt_model_adam_step(self._h, self.lr if lr is None else float(lr), beta1, beta2, eps, float(batch_size),
-                                     _stream_handle()), "vt_model_adam_step")
+                                     _stream_handle(self.device)), "vt_model_adam_step")
 
     def update_weights_range(self, batch_size, first, count):
         """The same update over floats [first, first + count) of the trainable region."""
-        check(lib.vt_model_sgd_step_range(self._h, self.lr, float(batch_size), int(first), int(count), _stream_handle()),
+        check(lib.vt_model_sgd_step_range(self._h, self.lr, float(batch_size), int(first), int(count), _stream_handle(self.device)),
               "vt_model_sgd_step_range")
 
     def zero_grad(self):
-        self.grads.zero_()
+        with self._settled():
+            self.grads.zero_()
 
     def capture_step(self, x, labels, batch_size=32.0):
         """Captures forward + backward + SGD on the fixed device buffers x / labels as one HIP
@@ -212,7 +214,7 @@ class VTCNN:
         return self._probs[:self._n]
 
     def step_graph(self):
-        check(lib.vt_model_graph_launch(self._h, _stream_handle()), "vt_model_graph_launch")
+        check(lib.vt_model_graph_launch(self._h, _stream_handle(self.device)), "vt_model_graph_launch")
 
     def metrics(self, labels=None):
         """(sum of cross-entropy terms, argmax labels) of the last forward, computed on the device."""
@@ -220,13 +222,19 @@ class VTCNN:
         am = torch.zeros(self._n, dtype=torch.int32, device=self.device)
         lp = C.c_void_p(labels.data_ptr()) if labels is not None else None
         check(lib.vt_model_metrics(self._h, lp, C.c_void_p(loss.data_ptr()), C.c_void_p(am.data_ptr()),
-                                   _stream_handle()), "vt_model_metrics")
+                                   _stream_handle(self.device)), "vt_model_metrics")
         return loss, am
 
+    def _sync_for_host_io(self):
+        # the library's checkpoint I/O copies with the null stream: finish the caller's stream first
+        torch.cuda.current_stream(self.device).synchronize()
+
     def save(self, path):
+        self._sync_for_host_io()
         check(lib.vt_model_save(self._h, str(path).encode()), "vt_model_save(%s)" % path)
 
     def load(self, path):
+        self._sync_for_host_io()
         check(lib.vt_model_load(self._h, str(path).encode()), "vt_model_load(%s)" % path)
 
     def save_v2(self, path, epoch=0, step=0, loader_seed=42, loader_resets=0):
@@ -234,12 +242,14 @@ class VTCNN:
         training position (still loadable by the reference, which never reads past the fc layer)."""
         from ._lib import VtTrainState
         st = VtTrainState(2, int(epoch), int(step), int(loader_seed), int(loader_resets))
+        self._sync_for_host_io()
         check(lib.vt_model_save_v2(self._h, C.byref(st), str(path).encode()), "vt_model_save_v2(%s)" % path)
 
     def load_v2(self, path):
         """Loads a v1 or v2 file; returns dict(version, epoch, step, loader_seed, loader_resets)."""
         from ._lib import VtTrainState
         st = VtTrainState()
+        self._sync_for_host_io()
         check(lib.vt_model_load_v2(self._h, C.byref(st), str(path).encode()), "vt_model_load_v2(%s)" % path)
         return {"version": st.version, "epoch": st.epoch, "step": st.step, "loader_seed": st.loader_seed,
                 "loader_resets": st.loader_resets}
@@ -282,16 +292,35 @@ class VTCNN:
             raise RuntimeError("vt_model_read(%s) -> %d" % (name, got))
         return out
 
+    def set_deferred_attention(self, on):
+        """Run the attention block's backward and weight update beside the next step's forward
+        (vt_model_set_deferred_attention); same bytes.  Readers of the arenas go through join_attention()."""
+        check(lib.vt_model_set_deferred_attention(self._h, int(bool(on))), "vt_model_set_deferred_attention")
+
+    def join_attention(self):
+        """Makes the current stream wait for a deferred attention backward / update still in flight; call
+        before touching self.grads / self.arena on the device (collectives, optimizers of the caller)."""
+        check(lib.vt_model_attention_join(self._h, _stream_handle(self.device)), "vt_model_attention_join")
+
+    def _settled(self):
+        # arena readers and writers below run on the current stream of the model's device: order them behind
+        # work the model still has in flight on its own streams
+        self.join_attention()
+        return torch.cuda.stream(torch.cuda.current_stream(self.device))
+
     def get_arena(self):
-        return self.arena.detach().cpu().numpy()
+        with self._settled():
+            return self.arena.detach().cpu().numpy()
 
     def set_arena(self, host):
         host = np.ascontiguousarray(host, dtype=np.float32)
         assert host.size == self.layout.n_total
-        self.arena.copy_(torch.from_numpy(host))
+        with self._settled():
+            self.arena.copy_(torch.from_numpy(host))
 
     def get_grads(self):
-        return self.grads.detach().cpu().numpy()
+        with self._settled():
+            return self.grads.detach().cpu().numpy()
 
 
 # ---------------------------------------------------------------------------------------------

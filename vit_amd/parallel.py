@@ -71,6 +71,8 @@ class DataParallel:
         """One flat sum all-reduce of the whole gradient arena."""
         if self.world == 1:
             return None
+        if hasattr(self.model, "join_attention"):
+            self.model.join_attention()  # a deferred attention backward must have written its gradients
         return self.dist.all_reduce(self.model.grads, op=self.dist.ReduceOp.SUM, group=self.group, async_op=async_op)
 
     def train_step(self, x, y, batch_size):
