@@ -291,6 +291,9 @@ def main():
         dt = float(tt.item())
     prof = m.profile_read()
     m.profile(None)
+    if hasattr(m, "join_attention"):
+        m.join_attention()
+    weights_finite = bool(torch.isfinite(m.arena).all().item())  # after every timed update: nothing overflowed
 
     # what an event pair itself adds to the interval it brackets (the markers are queue packets of
     # their own): the launcher's HIP-event time minus this is what a kernel trace reports
@@ -398,6 +401,7 @@ def main():
                        "hip_graph": bool(use_graph), "two_stream_backward": bool(a.concurrent) and not generic, "deferred_attention_backward": deferred, "statistics_group": a.group if a.mode == "predict" else 0, "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world,
                        "exchange_overlapped": bool(dp.overlap and a.mode == "train" and not use_graph),
                        "grad_allreduce_floats": int(m.layout.n_trainable) if world > 1 else 0},
+            "weights_finite_after_run": weights_finite,
             "roofline": roof,
             "whole_step_hbm_frac": round(value / world * total_bytes / (HBM_PEAK_GBS * 1e9), 4),  # algorithmic bytes, not measured
             "measured_copy_gbs": None if copy_gbs is None else round(copy_gbs, 1),

@@ -383,7 +383,7 @@ int vt_transformer_bwd_c(const float *da, const float *n1_coef, const float *wo,
  * groups are `groups` chunks of N consecutive token rows.  The output projection's gradient is
  * identically zero in the reference (its cached input is the zero concat, :133) and the layer's
  * input delta is never used (layers/visual_transformer.hpp:160); neither is computed.
- * scratch >= groups * heads * ceil(N/64) * 1536 floats. */
+ * scratch >= heads*4*(2*32 + 3)*rows + heads*ceil(rows/64)*1536 + groups*32 floats, rows = N*groups. */
 int vt_mha_bwd(const float *qkv, const float *dc, const float *tok, const float *wqkv, float *g_qkv, float *scratch,
                int N, int groups, vt_stream s);
 /* The two halves of vt_mha_bwd, separately launchable (and separately timed): the per-row

@@ -154,7 +154,34 @@ def test_train_step_other_inputs_on_the_fused_kernels(n, k, ci, h):
     _step_vs_f64_oracle(n, k, ci, h)
 
 
-def _step_vs_f64_oracle(n, k, ci, h):
+@pytest.mark.parametrize("n", [32, 1024])
+@pytest.mark.parametrize("factor", [8.0, 32.0])
+def test_attention_backward_with_large_query_key_weights(n, factor):
+    """The attention backward shifts its softmax by a Cauchy-Schwarz bound on the scores and forms its
+    products from bf16 hi / lo halves; both are only ever exercised at initialisation scale by the other
+    tests.  Here the query and key weights are 8x and 32x larger (scores 64x / 1024x: saturated softmax
+    rows, bound far above the row maximum, heavy cancellation in the softmax backward): every gradient,
+    the attention block's included, must still agree with exact arithmetic, and nothing may be NaN.
+    At 32x the scores reach the thousands and fp32 itself runs out: the reference's own arithmetic (the
+    fp32 oracle) is 1.4e-4 (mha.q0.W) and 2.1e-4 (mha.k0.W) away from exact arithmetic at N = 32, so the
+    query / key gradients get 3e-4 there; everything else, and everything at 8x, stays at 1e-4."""
+    loose = {"mha.%s%d.W" % (t, h): 3e-4 for t in "qk" for h in (0, 1)} if factor > 8 else {}
+    _step_vs_f64_oracle(n, 8, 1, 28, qk_factor=factor, loose=loose)
+
+
+@pytest.mark.parametrize("n", [32, 1024])
+def test_train_step_vs_oracle_after_200_training_steps(n):
+    """The same two-part check from weights that have been trained (200 SGD steps at a learning rate 5x
+    the reference's, on a fixed set of batches, so that every tensor has left its initialisation scale)
+    instead of the seed-42 draw.  Training conditions the problem worse (some gradient tensors shrink by
+    orders of magnitude next to the activations they are differences of), and the reference's own fp32
+    arithmetic then misses exact arithmetic by more than 1e-4 on them; each gradient tensor is therefore
+    held to 1e-4 or to three times the distance of the fp32 oracle (the reference's arithmetic, same
+    decisions imposed) from the fp64 oracle, whichever is larger."""
+    _step_vs_f64_oracle(n, 8, 1, 28, pretrain_steps=200)
+
+
+def _step_vs_f64_oracle(n, k, ci, h, qk_factor=1.0, loose=None, pretrain_steps=0):
     """Batches beyond the committed reference fixtures, up to the benchmark's 1024.
 
     Checker: the oracle (pinned bit-exactly to the reference at N=2/5/32) in its double-precision
@@ -177,9 +204,26 @@ def _step_vs_f64_oracle(n, k, ci, h):
     y = rng.integers(0, k, size=n).astype(np.int32)
     m = VTCNN(Dims(num_classes=k, image_channels=ci, input_dim=h), max_batch=n, seed=42)
     arena32 = m.get_arena().copy()
+    if qk_factor != 1.0:
+        for name in m.layout.tensors:
+            if name.startswith("mha.q") or name.startswith("mha.k"):
+                m.layout.view(arena32, name)[...] *= np.float32(qk_factor)
+        m.set_arena(arena32)
+    if pretrain_steps:
+        m.lr = 0.005
+        tx = [torch.from_numpy(rng.integers(0, 256, size=(32, ci, h, h)).astype(np.float32) / np.float32(255.0)).cuda() for _ in range(8)]
+        ty = [torch.from_numpy(rng.integers(0, k, size=32).astype(np.int32)).cuda() for _ in range(8)]
+        for t in range(pretrain_steps):
+            m.forward(tx[t % 8]); m.backward(ty[t % 8]); m.update_weights(32.0)
+        m.lr = 0.001
+        arena32 = m.get_arena().copy()
+        assert np.all(np.isfinite(arena32))
+        moved = np.abs(m.layout.view(arena32, "mha.q0.W") - m.layout.view(VTCNN(Dims(num_classes=k, image_channels=ci, input_dim=h), max_batch=1, seed=42).get_arena(), "mha.q0.W")).max()
+        assert moved > 1e-3, moved
     pg = m.forward(torch.from_numpy(x).cuda()).cpu().numpy()
     m.backward(torch.from_numpy(y).cuda())
     gg = m.get_grads()
+    assert np.all(np.isfinite(gg))
     slots, mask = _routing_from_gpu(m, n)
     # part 1: forward floats and discrete decisions vs exact math (fp64 oracle, its own decisions)
     o = Oracle(make_dims(num_classes=k, image_channels=ci, input_dim=h), n, f64=True)
@@ -198,6 +242,15 @@ def _step_vs_f64_oracle(n, k, ci, h):
     po = o.forward(arena64.copy(), x, training=True)
     go = o.backward(arena64, y)
     assert rel_err(pg, po) < TOL
+    if pretrain_steps:  # how far the reference's own arithmetic is from exact arithmetic on these weights
+        o32 = Oracle(make_dims(num_classes=k, image_channels=ci, input_dim=h), n)
+        o32.set_routing(slots, mask)
+        o32.forward(arena32.copy(), x, training=True)
+        g32 = o32.backward(arena32, y)
+        loose = dict(loose or {})
+        for name, (off, size, shape, kind) in m.layout.tensors.items():
+            if kind == 0:
+                loose[name] = max(TOL, 3.0 * rel_err(g32[off:off + size], go[off:off + size]))
     bad = []
     for name in ("bwd.proj_dx", "bwd.proj_dt", "bwd.tr_ds2", "bwd.tr_dr", "bwd.tok_dx"):
         e = rel_err(m.read(name), o.get(name))
@@ -206,7 +259,7 @@ def _step_vs_f64_oracle(n, k, ci, h):
     for name, (off, size, shape, kind) in m.layout.tensors.items():
         if kind == 0:
             e = rel_err(gg[off:off + size], go[off:off + size])
-            if not e < TOL:
+            if not e < (loose or {}).get(name, TOL):
                 bad.append((name, e))
     assert not bad, bad
 

@@ -8,7 +8,7 @@ g = torch.Generator(device="cuda").manual_seed(1)
 qkv = torch.randn(3 * rows * D, device="cuda", generator=g) * 0.5
 dc = torch.randn(rows * D, device="cuda", generator=g) * 0.1
 tok = torch.randn(rows * D, device="cuda", generator=g)
-scratch = torch.zeros(2 * 4 * (2 * D + 2) * rows + 2 * (rows // 64 + 1) * 1536, device="cuda")
+scratch = torch.zeros(2 * 4 * (2 * D + 3) * rows + 2 * (rows // 64 + 1) * 1536 + L * D, device="cuda")
 p = lambda t: C.c_void_p(t.data_ptr())
 def run():
     return lib.vt_mha_bwd_rows(p(qkv), p(dc), p(tok), p(scratch), N, L, None)

@@ -22,10 +22,13 @@
 // the B operand of the next product, which contracts over j:
 //   Y^T[d][i] += sum_j X[j][d] E^T[j][i],   W^T[d][i] += sum_j X[j][d] (E*dA)^T[j][i].
 // No lane shuffles in the loop; per-row softmax quantities are per-lane scalars.
-// Softmax uses a per-row upper bound of the scores instead of the exact row maximum
-// (|K_i.Q_j| <= |K_i| max_j |Q_j|): softmax is shift invariant, so only the rounding changes, and
-// a whole pass over j disappears.
+// Softmax is shift invariant: the sweep subtracts a per-row running shift that trails the row maximum
+// (rescaling its sums when a tile overshoots it), so no pass over j comes before the sweep.
 // Kernel 2 (k_mha_wgrad): the three [D x HD] gradient products over row blocks, slab + reduce.
+#include <cstdlib>
+#include <cstring>
+#include <type_traits>
+
 #include "vtcnn_common.h"
 
 namespace vt {
@@ -37,9 +40,9 @@ constexpr int MH_STRIDE = 3 * D * HD;  // per-workgroup partials: gq[D*HD] | gk[
 // accumulator register v of lane half hh holds row (v&3) + 8*(v>>2) + 4*hh of a 32x32 tile
 __device__ __forceinline__ int acc_row(int v, int hh) { return (v & 3) + 8 * (v >> 2) + 4 * hh; }
 
-// Partial, unnormalised row sums of one j range ("split"): because every split uses the same
-// per-row score bound, partials from different splits simply add.
-//   yz [head][split][2 (Y~, W~)][D][rows]      st [head][split][2 (sum e, sum e*dattn)][rows]
+// Partial, unnormalised row sums of one j range ("split"), each relative to the split's own final shift r:
+// the gradient kernel brings the splits of a row to their common largest shift before adding them.
+//   yz [head][split][2 (Y~, W~)][D][rows]      st [head][split][3 (sum e, sum e*dattn, shift r)][rows]
 // (row index fastest: coalesced for both kernels)
 
 // fp32 products on the bf16 matrix pipe.  Every operand x is carried as two bf16 numbers,
@@ -65,6 +68,17 @@ __device__ __forceinline__ void split2(floatx2 f, unsigned &hi, unsigned &lo) {
   const floatx2 r = f - floatx2{__uint_as_float(hi << 16), __uint_as_float(hi & 0xffff0000u)};
   lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
 }
+// third piece: what the pair (hi, lo) still misses of (a, b); hi + lo + lo2 holds all 24 mantissa bits
+__device__ __forceinline__ void split3(floatx2 f, unsigned &hi, unsigned &lo, unsigned &lo2) {
+  hi = __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2));
+  const floatx2 r = f - floatx2{__uint_as_float(hi << 16), __uint_as_float(hi & 0xffff0000u)};
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
+  const floatx2 r2 = r - floatx2{__uint_as_float(lo << 16), __uint_as_float(lo & 0xffff0000u)};
+  lo2 = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2));
+}
+__device__ __forceinline__ void split3(float a, float b, unsigned &hi, unsigned &lo, unsigned &lo2) {
+  split3(floatx2{a, b}, hi, lo, lo2);
+}
 __device__ __forceinline__ bf16x8 as_bf8(uint4 v) { return __builtin_bit_cast(bf16x8, v); }
 __device__ __forceinline__ floatx16 mfma_bf(bf16x8 a, bf16x8 b, floatx16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
@@ -78,6 +92,7 @@ constexpr int XT = 36;       // LDS row stride (bf16 elements) of the transposed
 // with one 8-byte load.
 struct StageBuf {
   unsigned short qh[32 * HD], ql[32 * HD], vh[32 * HD], vl[32 * HD];
+  unsigned short q3[32 * HD];  // third bf16 piece of Q (read by the high-precision sweep only)
   unsigned short xh[D * XT], xl[D * XT];
 };
 
@@ -89,8 +104,8 @@ struct StageBuf {
 template <bool FULL>
 __global__ __launch_bounds__(64 * MR_WAVES) void k_mha_rows(const float *__restrict__ qkv, const float *__restrict__ dc,
                                                             const float *__restrict__ tok, float *__restrict__ yz,
-                                                            float *__restrict__ st, int T, long rows, int groups,
-                                                            int nsplit) {
+                                                            float *__restrict__ st, float *__restrict__ xbar, int T,
+                                                            long rows, int groups, int nsplit, int prec_mode) {
   static_assert(HD == 16 && D == 32 && MR_WAVES == 4, "tile shapes are written for head_dim 16, token channels 32");
   __shared__ __attribute__((aligned(16))) StageBuf sb[3];
   __shared__ float sred[MR_WAVES];
@@ -116,24 +131,69 @@ __global__ __launch_bounds__(64 * MR_WAVES) void k_mha_rows(const float *__restr
 
   // B operands of the score products (this wave's own rows, constant over the sweep): lane half hh
   // carries head columns e = 8*hh .. 8*hh+7, the k slots of its half of the 32x32x16 product
-  bf16x8 kbh, kbl, dbh, dbl;
-  float kn2 = 0.f;
+  bf16x8 kbh, kbl, kb3, dbh, dbl;
   {
     const float4 k0 = *reinterpret_cast<const float4 *>(Km + row_i * D + h * HD + 8 * hh);
     const float4 k1 = *reinterpret_cast<const float4 *>(Km + row_i * D + h * HD + 8 * hh + 4);
     const float4 d0 = *reinterpret_cast<const float4 *>(dc + row_i * D + h * HD + 8 * hh);
     const float4 d1 = *reinterpret_cast<const float4 *>(dc + row_i * D + h * HD + 8 * hh + 4);
-    uint4 ph, pl;
-    split2(k0.x, k0.y, ph.x, pl.x); split2(k0.z, k0.w, ph.y, pl.y); split2(k1.x, k1.y, ph.z, pl.z); split2(k1.z, k1.w, ph.w, pl.w);
-    kbh = as_bf8(ph); kbl = as_bf8(pl);
+    uint4 ph, pl, p3;
+    split3(k0.x, k0.y, ph.x, pl.x, p3.x); split3(k0.z, k0.w, ph.y, pl.y, p3.y); split3(k1.x, k1.y, ph.z, pl.z, p3.z); split3(k1.z, k1.w, ph.w, pl.w, p3.w);
+    kbh = as_bf8(ph); kbl = as_bf8(pl); kb3 = as_bf8(p3);
     split2(d0.x, d0.y, ph.x, pl.x); split2(d0.z, d0.w, ph.y, pl.y); split2(d1.x, d1.y, ph.z, pl.z); split2(d1.z, d1.w, ph.w, pl.w);
     dbh = as_bf8(ph); dbl = as_bf8(pl);
-    kn2 = k0.x * k0.x + k0.y * k0.y + k0.z * k0.z + k0.w * k0.w + k1.x * k1.x + k1.y * k1.y + k1.z * k1.z + k1.w * k1.w;
   }
   // staging roles: thread -> one float4 of the token tile and one of the Q (threads 0..127) or V tile
   const int xr = tid >> 3, xc = (tid & 7) * 4, t2 = tid & 127, qr = t2 >> 2, qc = (t2 & 3) * 4;
   const float *__restrict__ gx = tok + gbase * D + xc;
   const float *__restrict__ gq = (tid < 128 ? Qm : Vm) + gbase * D + h * HD + qc;
+  // Pivot of the group: the mean token row and the mean value row of its first 32 rows (any per-group constant
+  // is exact algebraically; a sample mean removes the common component to within a fifth of the spread and
+  // costs one tile of loads instead of a pass over the group).  The sweep works on token
+  // rows and value rows RELATIVE to it: softmax_backward subtracts the attention-weighted mean of dattn, so a
+  // constant added to every dattn of a row (dhead_i . V_mean) drops out exactly, and its row sums of dsc are
+  // zero, so a constant token row drops out of Z = sum_j dsc X_j as well.  Without this, tokens with a large
+  // component common to all rows (any trained model) make Z the small difference of two large sums, each
+  // carrying the 2^-17 relative error of the bf16 hi / lo products; with near-uniform attention and the mean
+  // as pivot both sums are small themselves.  The gradient kernel adds the mean back where the un-centred Y
+  // is needed (it reads it from xbar, written by the first workgroup of each group).
+  __shared__ float spiv[MR_WAVES][D + HD];
+  float4 px, pq;
+  {
+    float4 ax = make_float4(0.f, 0.f, 0.f, 0.f), aq = ax;
+    {  // the same loads and the same order in every workgroup of the group: the same bits
+      const int j0 = 0;
+      const float4 vx = *reinterpret_cast<const float4 *>(gx + (long)min(j0 + xr, T - 1) * D);
+      const float4 vq = *reinterpret_cast<const float4 *>(gq + (long)min(j0 + qr, T - 1) * D);
+      const float mx_ = j0 + xr < T ? 1.f : 0.f, mq_ = j0 + qr < T ? 1.f : 0.f;
+      ax.x += mx_ * vx.x; ax.y += mx_ * vx.y; ax.z += mx_ * vx.z; ax.w += mx_ * vx.w;
+      aq.x += mq_ * vq.x; aq.y += mq_ * vq.y; aq.z += mq_ * vq.z; aq.w += mq_ * vq.w;
+    }
+    // token sums: lanes with equal (tid & 7) hold the same four columns (rows xr = tid >> 3)
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) {
+      ax.x += __shfl_xor(ax.x, o); ax.y += __shfl_xor(ax.y, o); ax.z += __shfl_xor(ax.z, o); ax.w += __shfl_xor(ax.w, o);
+    }
+    // value sums (threads 128..255; the others summed Q rows, unused): equal (tid & 3) = same four columns
+#pragma unroll
+    for (int o = 4; o < 64; o <<= 1) {
+      aq.x += __shfl_xor(aq.x, o); aq.y += __shfl_xor(aq.y, o); aq.z += __shfl_xor(aq.z, o); aq.w += __shfl_xor(aq.w, o);
+    }
+    if (lane < 8) *reinterpret_cast<float4 *>(&spiv[wave][4 * lane]) = ax;
+    if (lane < 4) *reinterpret_cast<float4 *>(&spiv[wave][D + 4 * lane]) = aq;
+    __syncthreads();
+    const float invT = 1.0f / (float)min(T, 32);
+    const int xq = (tid & 7) * 4, vq_ = D + (tid & 3) * 4;
+    px.x = (spiv[0][xq] + spiv[1][xq] + spiv[2][xq] + spiv[3][xq]) * invT;
+    px.y = (spiv[0][xq + 1] + spiv[1][xq + 1] + spiv[2][xq + 1] + spiv[3][xq + 1]) * invT;
+    px.z = (spiv[0][xq + 2] + spiv[1][xq + 2] + spiv[2][xq + 2] + spiv[3][xq + 2]) * invT;
+    px.w = (spiv[0][xq + 3] + spiv[1][xq + 3] + spiv[2][xq + 3] + spiv[3][xq + 3]) * invT;
+    pq.x = tid < 128 ? 0.f : (spiv[2][vq_] + spiv[3][vq_]) * invT;
+    pq.y = tid < 128 ? 0.f : (spiv[2][vq_ + 1] + spiv[3][vq_ + 1]) * invT;
+    pq.z = tid < 128 ? 0.f : (spiv[2][vq_ + 2] + spiv[3][vq_ + 2]) * invT;
+    pq.w = tid < 128 ? 0.f : (spiv[2][vq_ + 3] + spiv[3][vq_ + 3]) * invT;
+    if (h == 0 && ib == 0 && sp == 0 && tid < 8) *reinterpret_cast<float4 *>(xbar + (size_t)bgrp * D + xq) = px;
+  }
   // two register sets: a tile's global loads are issued two sweep steps before it is needed in LDS
   // (one step of arithmetic is shorter than a trip to memory)
   float4 rxa, rqa, rxb, rqb;
@@ -141,14 +201,18 @@ __global__ __launch_bounds__(64 * MR_WAVES) void k_mha_rows(const float *__restr
     rx = *reinterpret_cast<const float4 *>(gx + (long)min(jt + xr, T - 1) * D);
     rq = *reinterpret_cast<const float4 *>(gq + (long)min(jt + qr, T - 1) * D);
   };
-  auto sstore = [&](int buf, const float4 &rx, const float4 &rq) {
+  auto sstore = [&](int buf, const float4 &rx_, const float4 &rq_) {
     StageBuf &B = sb[buf];
-    uint2 hv, lv;
-    split2(rq.x, rq.y, hv.x, lv.x);
-    split2(rq.z, rq.w, hv.y, lv.y);
+    // relative to the pivot; here and not at the load, whose data should stay in flight until now
+    const float4 rx = make_float4(rx_.x - px.x, rx_.y - px.y, rx_.z - px.z, rx_.w - px.w);
+    const float4 rq = make_float4(rq_.x - pq.x, rq_.y - pq.y, rq_.z - pq.z, rq_.w - pq.w);
+    uint2 hv, lv, tv;
+    split3(rq.x, rq.y, hv.x, lv.x, tv.x);
+    split3(rq.z, rq.w, hv.y, lv.y, tv.y);
     unsigned short *dh = tid < 128 ? B.qh : B.vh, *dl = tid < 128 ? B.ql : B.vl;
     *reinterpret_cast<uint2 *>(dh + qr * HD + qc) = hv;
     *reinterpret_cast<uint2 *>(dl + qr * HD + qc) = lv;
+    if (tid < 128) *reinterpret_cast<uint2 *>(B.q3 + qr * HD + qc) = tv;
     split2(rx.x, rx.y, hv.x, lv.x);
     split2(rx.z, rx.w, hv.y, lv.y);
     B.xh[(xc + 0) * XT + xr] = (unsigned short)hv.x; B.xh[(xc + 1) * XT + xr] = (unsigned short)(hv.x >> 16);
@@ -161,37 +225,26 @@ __global__ __launch_bounds__(64 * MR_WAVES) void k_mha_rows(const float *__restr
     gload(jbeg + 32 * min(1, ntile - 1), rxb, rqb);
   }
 
-  kn2 += __shfl_xor(kn2, 32);
-  // largest |Q_j|^2 of the whole group (identical in every split and row tile)
-  float qn2 = 0.f;
-  for (int j = tid; j < T; j += 64 * MR_WAVES) {
-    float sq = 0.f;
-#pragma unroll
-    for (int q = 0; q < HD / 4; ++q) {
-      const float4 v = *reinterpret_cast<const float4 *>(Qm + (gbase + j) * D + h * HD + 4 * q);
-      sq += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-    }
-    qn2 = fmaxf(qn2, sq);
-  }
-  qn2 = wave_max(qn2);
-  if (lane == 0) sred[wave] = qn2;
   if (ntile > 0) {
     sstore(0, rxa, rqa);
     sstore(1, rxb, rqb);
     gload(jbeg + 32 * min(2, ntile - 1), rxa, rqa);  // stored by sweep step 0
   }
   __syncthreads();
-  qn2 = fmaxf(fmaxf(sred[0], sred[1]), fmaxf(sred[2], sred[3]));
-  // e = exp(scale * s - mx) with mx = scale |K_i| max|Q_j| >= every scaled score of row i, evaluated
-  // as one fused multiply-add and one exp2
+  // e = exp(scale * s - r) as one fused multiply-add and one exp2, with a per-row running shift r (below)
   const float sc2 = scale * 1.44269504088896341f;
-  const float nmx = -sc2 * sqrtf(kn2) * sqrtf(qn2);
-
   floatx16 accY, accW;
 #pragma unroll
   for (int v = 0; v < 16; ++v) { accY[v] = 0.f; accW[v] = 0.f; }
   floatx2 ssum2 = {0.f, 0.f}, tsum2 = {0.f, 0.f};
-  const floatx2 sc2v = {sc2, sc2}, nmxv = {nmx, nmx};
+  const floatx2 sc2v = {sc2, sc2};
+  // Running shift of row i (binary orders), the flash-attention way but lazy: it follows the row maximum
+  // only when a tile's maximum exceeds it by more than LAZY orders, so numerators stay below 2^LAZY (fine in
+  // fp32 and in the bf16 pieces) and the accumulators are rescaled a few times per sweep at most.  No bound
+  // on the scores is needed (a bound can sit hundreds of orders above the true maximum once the weights
+  // have grown, and every numerator of the row then flushes to zero), and no pass over the group up front.
+  constexpr float LAZY = 8.0f;
+  float r = -INFINITY;
 
   // With one j range per row tile a SIMD holds a single wave, so the matrix pipe and the vector pipe
   // only overlap if independent work of both kinds sits next to each other in that wave's instruction
@@ -200,14 +253,20 @@ __global__ __launch_bounds__(64 * MR_WAVES) void k_mha_rows(const float *__restr
   // the second-stage products of one half tile run beside the vector work of the other half.
   // Transposed score and dattn tiles of one staged tile: rows j (this lane: j = c) x columns i,
   // contraction over the 16 head columns = one matrix instruction per partial product.
-  auto scores = [&](const StageBuf &B, floatx16 &aS, floatx16 &aD) {
+  auto scores = [&](auto prec, const StageBuf &B, floatx16 &aS, floatx16 &aD) {
+    constexpr bool P = decltype(prec)::value;
     const bf16x8 qh = as_bf8(*reinterpret_cast<const uint4 *>(B.qh + c * HD + 8 * hh));
     const bf16x8 ql = as_bf8(*reinterpret_cast<const uint4 *>(B.ql + c * HD + 8 * hh));
     const bf16x8 vh = as_bf8(*reinterpret_cast<const uint4 *>(B.vh + c * HD + 8 * hh));
     const bf16x8 vl = as_bf8(*reinterpret_cast<const uint4 *>(B.vl + c * HD + 8 * hh));
 #pragma unroll
     for (int v = 0; v < 16; ++v) { aS[v] = 0.f; aD[v] = 0.f; }
-    aS = mfma_bf(ql, kbl, aS);  // smallest partial product first
+    if constexpr (P) {
+      const bf16x8 q3 = as_bf8(*reinterpret_cast<const uint4 *>(B.q3 + c * HD + 8 * hh));
+      aS = mfma_bf(q3, kbh, aS);  // smallest partial products first
+      aS = mfma_bf(qh, kb3, aS);
+    }
+    aS = mfma_bf(ql, kbl, aS);
     aD = mfma_bf(vl, dbh, aD);
     aS = mfma_bf(ql, kbh, aS);
     aD = mfma_bf(vh, dbl, aD);
@@ -217,18 +276,35 @@ __global__ __launch_bounds__(64 * MR_WAVES) void k_mha_rows(const float *__restr
   };
   // one sweep step: tile k's scores are in (aS, aD); tile k+1's go to (nS, nD)
   // (rxs, rqs): tile k+2, loaded one step ago, goes to LDS at the end of this step; (rxl, rql) receives tile k+3
-  auto step = [&](int k, const floatx16 &aS, const floatx16 &aD, floatx16 &nS, floatx16 &nD, const float4 &rxs,
+  auto step = [&](auto prec, int k, const floatx16 &aS, const floatx16 &aD, floatx16 &nS, floatx16 &nD, const float4 &rxs,
                   const float4 &rqs, float4 &rxl, float4 &rql) {
+    constexpr bool P = decltype(prec)::value;
     const int jt = jbeg + 32 * k;
     gload(jbeg + 32 * min(k + 3, ntile - 1), rxl, rql);  // unconditional: past the end it re-reads the final tile
-    scores(sb[(k + 1) % 3], nS, nD);           // (past the end: the final tile again, result unused)
+    scores(prec, sb[(k + 1) % 3], nS, nD);     // (past the end: the final tile again, result unused)
     const StageBuf &B = sb[k % 3];
     // softmax numerators e and e * dattn, then their hi / lo halves as the B operands of the second
     // stage: registers 0..7 of lane half hh are tile rows {4hh..4hh+3, 8+4hh..}, registers 8..15 the
     // same + 16; the token operand presents its rows in that same order
+    {
+      float tm = -INFINITY;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) tm = fmaxf(tm, (FULL || jt + acc_row(v, hh) < T) ? aS[v] : -INFINITY);
+      tm = fmaxf(tm, __shfl_xor(tm, 32)) * sc2;  // both lane halves of column i agree
+      if (__any(tm > r + LAZY)) {
+        const float rn = tm > r + LAZY ? tm : r;
+        const float alpha = __builtin_amdgcn_exp2f(r - rn);  // first tile: r = -inf, alpha = 0 on zero sums
+#pragma unroll
+        for (int v = 0; v < 16; ++v) { accY[v] *= alpha; accW[v] *= alpha; }
+        ssum2 *= alpha;
+        tsum2 *= alpha;
+        r = rn;
+      }
+    }
+    const floatx2 nmxv = {-r, -r};
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
-      unsigned ph[4], pl[4], qh4[4], ql4[4];
+      unsigned ph[4], pl[4], qh4[4], ql4[4], p3[4] = {0, 0, 0, 0}, q34[4] = {0, 0, 0, 0};
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         // two adjacent accumulator registers at a time: the multiply-adds, products, sums and the
@@ -243,8 +319,13 @@ __global__ __launch_bounds__(64 * MR_WAVES) void k_mha_rows(const float *__restr
         const floatx2 ed = e * floatx2{aD[v], aD[v + 1]};
         ssum2 += e;
         tsum2 += ed;
-        split2(e, ph[q], pl[q]);
-        split2(ed, qh4[q], ql4[q]);
+        if constexpr (P) {
+          split3(e, ph[q], pl[q], p3[q]);
+          split3(ed, qh4[q], ql4[q], q34[q]);
+        } else {
+          split2(e, ph[q], pl[q]);
+          split2(ed, qh4[q], ql4[q]);
+        }
       }
       const uint4 eh = make_uint4(ph[0], ph[1], ph[2], ph[3]), el = make_uint4(pl[0], pl[1], pl[2], pl[3]);
       const uint4 fh = make_uint4(qh4[0], qh4[1], qh4[2], qh4[3]), fl = make_uint4(ql4[0], ql4[1], ql4[2], ql4[3]);
@@ -254,6 +335,13 @@ __global__ __launch_bounds__(64 * MR_WAVES) void k_mha_rows(const float *__restr
       const uint2 h0 = *reinterpret_cast<const uint2 *>(xph), h1 = *reinterpret_cast<const uint2 *>(xph + 8);
       const uint2 l0 = *reinterpret_cast<const uint2 *>(xpl), l1 = *reinterpret_cast<const uint2 *>(xpl + 8);
       const bf16x8 xh = as_bf8(make_uint4(h0.x, h0.y, h1.x, h1.y)), xl = as_bf8(make_uint4(l0.x, l0.y, l1.x, l1.y));
+      if constexpr (P) {
+        const uint4 e3 = make_uint4(p3[0], p3[1], p3[2], p3[3]), f3 = make_uint4(q34[0], q34[1], q34[2], q34[3]);
+        accY = mfma_bf(xh, as_bf8(e3), accY);
+        accW = mfma_bf(xh, as_bf8(f3), accW);
+        accY = mfma_bf(xl, as_bf8(el), accY);
+        accW = mfma_bf(xl, as_bf8(fl), accW);
+      }
       accY = mfma_bf(xl, as_bf8(eh), accY);
       accW = mfma_bf(xl, as_bf8(fh), accW);
       accY = mfma_bf(xh, as_bf8(el), accY);
@@ -264,12 +352,40 @@ __global__ __launch_bounds__(64 * MR_WAVES) void k_mha_rows(const float *__restr
     sstore((k + 2) % 3, rxs, rqs);  // the buffer of tile k-1: every wave left it before the last barrier
     __syncthreads();
   };
-  floatx16 s0, d0, s1, d1;
-  if (ntile > 0) scores(sb[0], s0, d0);
-  for (int k = 0; k < ntile; k += 2) {
-    step(k, s0, d0, s1, d1, rxa, rqa, rxb, rqb);
-    if (k + 1 < ntile) step(k + 1, s1, d1, s0, d0, rxb, rqb, rxa, rqa);
+  // Precision of the sweep, one decision per workgroup.  Two bf16 pieces per operand carry 16 mantissa bits:
+  // a score is then off by about 2^-17 of |K_i||Q_j|, and the softmax numerator by that many nats.  Harmless
+  // while the scores are of order one (initialisation scale: gradients within 1e-6 of exact arithmetic), but
+  // the query / key weights never influence the forward pass (the zero concat), so nothing holds them back
+  // during training: their gradients are unnormalised sums over the whole mini-batch, and within tens of
+  // steps the scores reach the tens and hundreds: saturated rows, where the softmax backward is a difference
+  // of nearly equal terms.  When the first staged tile shows scaled scores beyond PRECISE_ABOVE binary
+  // orders, the workgroup carries Q, K and both softmax numerators with three pieces (24 bits): six partial
+  // products for the scores instead of four, five instead of three in the second stage.
+  constexpr float PRECISE_ABOVE = 1.5f;
+  bool precise = prec_mode == 2;
+  if (prec_mode == 0) {
+    float ma = 0.f;
+    if (ntile > 0) {
+      floatx16 ts, td;
+      scores(std::false_type{}, sb[0], ts, td);
+#pragma unroll
+      for (int v = 0; v < 16; ++v) ma = fmaxf(ma, fabsf(ts[v]));
+    }
+    ma = wave_max(ma);
+    if (lane == 0) sred[wave] = ma;
+    __syncthreads();
+    precise = sc2 * fmaxf(fmaxf(sred[0], sred[1]), fmaxf(sred[2], sred[3])) > PRECISE_ABOVE;
   }
+  auto sweep = [&](auto prec) {
+    floatx16 s0, d0, s1, d1;
+    if (ntile > 0) scores(prec, sb[0], s0, d0);
+    for (int k = 0; k < ntile; k += 2) {
+      step(prec, k, s0, d0, s1, d1, rxa, rqa, rxb, rqb);
+      if (k + 1 < ntile) step(prec, k + 1, s1, d1, s0, d0, rxb, rqb, rxa, rqa);
+    }
+  };
+  if (precise) sweep(std::true_type{});
+  else sweep(std::false_type{});
   float ssum = ssum2.x + ssum2.y, tsum = tsum2.x + tsum2.y;
   ssum += __shfl_xor(ssum, 32);
   tsum += __shfl_xor(tsum, 32);
@@ -284,8 +400,9 @@ __global__ __launch_bounds__(64 * MR_WAVES) void k_mha_rows(const float *__restr
       wb[(size_t)d * rows] = accW[v];
     }
     if (hh == 0) {
-      st[(hs * 2 + 0) * rows + gbase + i] = ssum;
-      st[(hs * 2 + 1) * rows + gbase + i] = tsum;
+      st[(hs * 3 + 0) * rows + gbase + i] = ssum;
+      st[(hs * 3 + 1) * rows + gbase + i] = tsum;
+      st[(hs * 3 + 2) * rows + gbase + i] = r;
     }
   }
 }
@@ -303,7 +420,8 @@ __device__ __forceinline__ f4 mfma16(float a, float b, f4 c) { return __builtin_
 __global__ __launch_bounds__(TPB) void k_mha_wgrad(const float *__restrict__ yz, const float *__restrict__ st,
                                                    const float *__restrict__ qkv, const float *__restrict__ dc,
                                                    const float *__restrict__ tok, const float *__restrict__ Wqkv,
-                                                   float *__restrict__ slab, long rows, int nsplit, int single_key) {
+                                                   float *__restrict__ slab, const float *__restrict__ xbar, long rows,
+                                                   int nsplit, int single_key, int T) {
   __shared__ float sbuf[6][NW * 256];  // the six gradient tiles of the four waves, summed in one phase
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4, h = blockIdx.y;
   const long row0 = ((long)blockIdx.x * NW + wave) * 16;
@@ -313,30 +431,54 @@ __global__ __launch_bounds__(TPB) void k_mha_wgrad(const float *__restrict__ yz,
   // per-row softmax normalisers: for the registers-are-rows operands (rows 4g+v) and for row j
   f4 inv4 = zero, dot4 = zero;
   float invj = 0.f, dotj = 0.f;
+  // every split's sums are relative to its own shift r: factor exp2(r_split - r_max) brings them together
+  // (exactly 1 with a single split; 0 for a split that saw no tile, whose r is -inf)
+  f4 rm4 = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+  float rmj = -INFINITY;
+  for (int sp = 0; sp < nsplit; ++sp) {
+    const float *s2 = st + (((size_t)h * nsplit + sp) * 3 + 2) * rows;
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+      if (4 * g + v < nv) rm4[v] = fmaxf(rm4[v], s2[row0 + 4 * g + v]);
+    if (j < nv) rmj = fmaxf(rmj, s2[row0 + j]);
+  }
+  auto fac4 = [&](int sp) {
+    const float *s2 = st + (((size_t)h * nsplit + sp) * 3 + 2) * rows;
+    f4 f = zero;
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+      if (4 * g + v < nv) f[v] = exp2f(s2[row0 + 4 * g + v] - rm4[v]);
+    return f;
+  };
+  auto facj = [&](int sp) {
+    return j < nv ? exp2f(st[(((size_t)h * nsplit + sp) * 3 + 2) * rows + row0 + j] - rmj) : 0.f;
+  };
   {
     f4 s4 = zero, t4 = zero;
     float sj = 0.f, tj = 0.f;
     for (int sp = 0; sp < nsplit; ++sp) {
-      const float *s0 = st + (((size_t)h * nsplit + sp) * 2 + 0) * rows, *s1 = s0 + rows;
+      const float *s0 = st + (((size_t)h * nsplit + sp) * 3 + 0) * rows, *s1 = s0 + rows;
+      const f4 f = fac4(sp);
+      const float fj = facj(sp);
 #pragma unroll
       for (int v = 0; v < 4; ++v)
         if (4 * g + v < nv) {
-          s4[v] += s0[row0 + 4 * g + v];
-          t4[v] += s1[row0 + 4 * g + v];
+          s4[v] += s0[row0 + 4 * g + v] * f[v];
+          t4[v] += s1[row0 + 4 * g + v] * f[v];
         }
       if (j < nv) {
-        sj += s0[row0 + j];
-        tj += s1[row0 + j];
+        sj += s0[row0 + j] * fj;
+        tj += s1[row0 + j] * fj;
       }
     }
 #pragma unroll
     for (int v = 0; v < 4; ++v)
       if (4 * g + v < nv) {
-        inv4[v] = 1.0f / s4[v];
+        inv4[v] = s4[v] > 0.f ? 1.0f / s4[v] : 0.f;  // a row whose numerators all flushed to zero contributes nothing
         dot4[v] = t4[v] * inv4[v];
       }
     if (j < nv) {
-      invj = 1.0f / sj;
+      invj = sj > 0.f ? 1.0f / sj : 0.f;
       dotj = tj * invj;
     }
   }
@@ -348,16 +490,17 @@ __global__ __launch_bounds__(TPB) void k_mha_wgrad(const float *__restrict__ yz,
     for (int sp = 0; sp < nsplit; ++sp) {
       const float *yb = yz + ((((size_t)h * nsplit + sp) * 2 + 0) * D + (j + 16 * t)) * rows + row0 + 4 * g;
       const float *wb = yb + (size_t)D * rows;
+      const f4 f = fac4(sp);
       if (4 * g + 3 < nv) {  // the four rows of this lane group are consecutive floats, 16-byte aligned
         const f4 y4 = *reinterpret_cast<const f4 *>(yb), w4 = *reinterpret_cast<const f4 *>(wb);
-        y += y4;
-        w += w4;
+        y += y4 * f;
+        w += w4 * f;
       } else {
 #pragma unroll
         for (int v = 0; v < 4; ++v)
           if (4 * g + v < nv) {
-            y[v] += yb[v];
-            w[v] += wb[v];
+            y[v] += yb[v] * f[v];
+            w[v] += wb[v] * f[v];
           }
       }
     }
@@ -367,6 +510,9 @@ __global__ __launch_bounds__(TPB) void k_mha_wgrad(const float *__restrict__ yz,
       // a group of one row attends only to itself: its softmax is exactly 1 and softmax_backward
       // exactly 0 (tensor_cpu.hpp:946-950), which the difference of two rounded terms would miss
       zn[t][v] = single_key ? 0.f : w[v] * inv4[v] - dot4[v] * yn[t][v];
+      // the row sums came in relative to the group's mean token row (k_mha_rows); Z is independent of it, the
+      // attention-weighted token mean Y (for the value gradient) is not: the weights sum to one
+      if (4 * g + v < nv) yn[t][v] += xbar[((row0 + 4 * g + v) / T) * D + j + 16 * t];
     }
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
@@ -374,8 +520,9 @@ __global__ __launch_bounds__(TPB) void k_mha_wgrad(const float *__restrict__ yz,
       if (j < nv)
         for (int sp = 0; sp < nsplit; ++sp) {
           const size_t o = ((((size_t)h * nsplit + sp) * 2 + 0) * D + (16 * t + 4 * g + v)) * rows + row0 + j;
-          y1 += yz[o];
-          w1 += yz[o + (size_t)D * rows];
+          const float fj = facj(sp);
+          y1 += yz[o] * fj;
+          w1 += yz[o + (size_t)D * rows] * fj;
         }
       y1 *= invj;
       zt[t][v] = single_key ? 0.f : w1 * invj - dotj * y1;
@@ -442,6 +589,23 @@ static int mha_splits(int N, int groups) {
   return ns < 1 ? 1 : ns;
 }
 
+// The group means of the token rows [groups][D] sit behind the largest layout of the other scratch regions
+// (four j splits): heads*4*(2*D + 3)*rows + heads*ceil(rows/64)*1536 floats.
+static float *mha_xbar(float *scratch, long rows) {
+  return scratch + (size_t)HEADS * 4 * (2 * D + 3) * rows + (size_t)HEADS * ((rows + RB - 1) / RB) * MH_STRIDE;
+}
+
+// Measurement aid: VT_MHA_PRECISION=two / three forces the sweep's operand precision (default: chosen per
+// workgroup from the score magnitudes).
+static int mha_precision_mode() {
+  static const int mode = [] {
+    const char *e = getenv("VT_MHA_PRECISION");
+    if (!e) return 0;
+    return strcmp(e, "two") == 0 ? 1 : (strcmp(e, "three") == 0 ? 2 : 0);
+  }();
+  return mode;
+}
+
 // Step 1: per-row attention sums (k_mha_rows).  scratch as for vt_mha_bwd.
 extern "C" int vt_mha_bwd_rows(const float *qkv, const float *dc, const float *tok, float *scratch, int N, int groups,
                                vt_stream s) {
@@ -450,13 +614,14 @@ extern "C" int vt_mha_bwd_rows(const float *qkv, const float *dc, const float *t
   const long rows = (long)N * groups;
   float *yz = scratch;
   float *st = yz + (size_t)HEADS * ns * 2 * D * rows;
+  float *xbar = mha_xbar(scratch, rows);
   const int iblocks = (itiles + MR_WAVES - 1) / MR_WAVES;
   if (N % 32 == 0)
     hipLaunchKernelGGL(k_mha_rows<true>, dim3(HEADS * groups * iblocks * ns), dim3(64 * MR_WAVES), 0, (hipStream_t)s,
-                       qkv, dc, tok, yz, st, N, rows, groups, ns);
+                       qkv, dc, tok, yz, st, xbar, N, rows, groups, ns, mha_precision_mode());
   else
     hipLaunchKernelGGL(k_mha_rows<false>, dim3(HEADS * groups * iblocks * ns), dim3(64 * MR_WAVES), 0, (hipStream_t)s,
-                       qkv, dc, tok, yz, st, N, rows, groups, ns);
+                       qkv, dc, tok, yz, st, xbar, N, rows, groups, ns, mha_precision_mode());
   VT_CHECK_LAUNCH();
   return 0;
 }
@@ -470,9 +635,9 @@ extern "C" int vt_mha_bwd_wgrad(const float *qkv, const float *dc, const float *
   const int nrb = (int)((rows + RB - 1) / RB);
   float *yz = scratch;
   float *st = yz + (size_t)HEADS * ns * 2 * D * rows;
-  float *slab = st + (size_t)HEADS * ns * 2 * rows;
-  hipLaunchKernelGGL(k_mha_wgrad, dim3(nrb, HEADS), dim3(TPB), 0, (hipStream_t)s, yz, st, qkv, dc, tok, wqkv, slab, rows,
-                     ns, N == 1 ? 1 : 0);
+  float *slab = st + (size_t)HEADS * ns * 3 * rows;
+  hipLaunchKernelGGL(k_mha_wgrad, dim3(nrb, HEADS), dim3(TPB), 0, (hipStream_t)s, yz, st, qkv, dc, tok, wqkv, slab,
+                     mha_xbar(scratch, rows), rows, ns, N == 1 ? 1 : 0, N);
   VT_CHECK_LAUNCH();
   for (int h = 0; h < HEADS; ++h) {
     const int rc = reduce_rows(slab + (size_t)h * nrb * MH_STRIDE, nrb, MH_STRIDE, MH_STRIDE,
@@ -483,7 +648,7 @@ extern "C" int vt_mha_bwd_wgrad(const float *qkv, const float *dc, const float *
 }
 
 // g_qkv: [q0 | k0 | v0 | q1 | k1 | v1] gradients (arena order);
-// scratch >= heads*4*(2*D + 2)*rows + heads*ceil(rows/64)*1536 floats with rows = N*groups.
+// scratch >= heads*4*(2*D + 3)*rows + heads*ceil(rows/64)*1536 + groups*D floats with rows = N*groups.
 extern "C" int vt_mha_bwd(const float *qkv, const float *dc, const float *tok, const float *wqkv, float *g_qkv,
                           float *scratch, int N, int groups, vt_stream s) {
   const int rc = vt_mha_bwd_rows(qkv, dc, tok, scratch, N, groups, s);

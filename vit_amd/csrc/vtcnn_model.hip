@@ -221,7 +221,7 @@ extern "C" int vt_model_create(const vt_dims *dims, int max_batch, int device, f
   rc |= dalloc(m, &m->sc_ffn, nrb * 2112);
   rc |= dalloc(m, &m->sc_pt, nrb * 1552);
   rc |= dalloc(m, &m->sc_fc, ((N + 127) / 128) * (Q * K + K));
-  rc |= dalloc(m, &m->sc_mha, (size_t)HEADS * 4 * (2 * D + 2) * NL + (size_t)HEADS * nrb * 1536);
+  rc |= dalloc(m, &m->sc_mha, (size_t)HEADS * 4 * (2 * D + 3) * NL + (size_t)HEADS * nrb * 1536 + (size_t)L * D);
   rc |= dalloc(m, &m->coef_pn, 2 * C2, "coef.proj.norm");
   rc |= dalloc(m, &m->coef_n2, 2 * D, "coef.norm2");
   rc |= dalloc(m, &m->coef_n1, 2 * D, "coef.norm1");
