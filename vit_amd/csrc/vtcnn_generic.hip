@@ -507,13 +507,17 @@ namespace {
 struct Gemm {
   vt::GenModel *g;
   hipStream_t s;
+  bool reduced_ok = true;  // false: every product of this pass stays fp32 even in the reduced-precision mode
   // C = alpha * op(A).op(B) (+bias) (+C)
   int operator()(bool ta, bool tb, int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *C, int ldc,
                  const float *bias = nullptr, bool acc = false, float alpha = 1.f, int batch = 1, long sA = 0, long sB = 0,
                  long sC = 0) const {
-    // reduced-precision mode: the activation x weight and score products go through bf16; the
-    // gradient contractions over the batch's rows (transposed A) stay in fp32
-    auto fn = (g->bf16 && !ta) ? vt_gemm_bf16_mfma : vt_gemm_f32;
+    // reduced-precision mode: the forward pass's activation x weight and score products (and the backward's
+    // recomputation of the per-head query / key / value projections) go through bf16; the delta products of
+    // the backward pass and the gradient contractions over the batch's rows stay in fp32: bf16 noise on the
+    // deltas is amplified by the BatchNorm backward differences on its way to the first layers (conv.W ended
+    // 6e-2 from exact arithmetic with them in bf16, against the 1e-2 stated for the mode)
+    auto fn = (g->bf16 && reduced_ok && !ta) ? vt_gemm_bf16_mfma : vt_gemm_f32;
     return fn(ta, tb, M, N, K, alpha, A, lda, sA, B, ldb, sB, acc, C, ldc, sC, bias, batch, g->ws, g->ws_floats, (vt_stream)s);
   }
 };
@@ -714,7 +718,10 @@ int gen_forward(GenModel *g, const float *arena, const vt_layout *lo, float *are
   const long NP = (long)n * P, NL = (long)n * L;
   auto W = [&](const char *name) { return arena + lo->t[vt_find(lo, name)].offset; };
   auto RW = [&](const char *name) { return arena_rw + lo->t[vt_find(lo, name)].offset; };
-  const Gemm mm{g, s};
+  // mm_bf: the dense-layer products the reduced-precision mode sends through bf16 (feed-forward block, projector
+  // linear1 / linear2 / linear3, classifier); everything else (the convolution, products that feed an
+  // exponential, activation x activation products) stays fp32
+  const Gemm mm{g, s, false}, mm_exact{g, s, false}, mm_bf{g, s, true};
   // Conv2DLayer::forward as im2col x W^T (conv2d_layer.hpp:35-87); output pixel-major [N*P, C1]
   hipLaunchKernelGGL(k_im2col, dim3(nblk(NP * CK)), dim3(GT), 0, s, X, g->col, NP * CK, g->Ci, g->H, g->H);
   VT_CHECK_LAUNCH();
@@ -723,7 +730,7 @@ int gen_forward(GenModel *g, const float *arena, const vt_layout *lo, float *are
   VTG(bn_stats(g, g->conv, NP, C1, RW("bn.running_mean"), RW("bn.running_var"), g->stat_bn, !training, s));
   VTG(col_affine(0, g->conv, g->stat_bn, W("bn.gamma"), W("bn.beta"), g->x, NP, C1, s));
   // FilterTokenizer::forward (layers/tokenizer.hpp:22-48)
-  VTG(mm(false, false, (int)NP, L, C1, g->x, C1, W("tok.linear1.W"), L, g->tokA, L, W("tok.linear1.b")));
+  VTG(mm_exact(false, false, (int)NP, L, C1, g->x, C1, W("tok.linear1.W"), L, g->tokA, L, W("tok.linear1.b")));
   VTG(softmax_pixels(g, g->tokA, n, P, L, s));
   VTG(mm(true, false, L, C1, P, g->tokA, L, g->x, C1, g->T0, C1, nullptr, false, 1.f, n, (long)P * L, (long)P * C1,
          (long)L * C1));
@@ -732,18 +739,18 @@ int gen_forward(GenModel *g, const float *arena, const vt_layout *lo, float *are
   // (multi_head_attention.hpp:100-104), so the first residual is the tokens themselves
   VTG(bn_stats(g, g->tok, NL, D, RW("norm1.running_mean"), RW("norm1.running_var"), g->stat_n1, false, s));
   VTG(col_affine(0, g->tok, g->stat_n1, W("norm1.gamma"), W("norm1.beta"), g->a, NL, D, s));
-  VTG(mm(false, false, (int)NL, D, D, g->a, D, W("ffn.linear1.W"), D, g->hdn, D, W("ffn.linear1.b")));
+  VTG(mm_bf(false, false, (int)NL, D, D, g->a, D, W("ffn.linear1.W"), D, g->hdn, D, W("ffn.linear1.b")));
   VTG(ewise(g->hdn, nullptr, g->rl, NL * D, 2, s));
-  VTG(mm(false, false, (int)NL, D, D, g->rl, D, W("ffn.linear2.W"), D, g->s2, D, W("ffn.linear2.b")));
+  VTG(mm_bf(false, false, (int)NL, D, D, g->rl, D, W("ffn.linear2.W"), D, g->s2, D, W("ffn.linear2.b")));
   VTG(ewise(g->a, g->s2, g->s2, NL * D, 0, s));
   VTG(bn_stats(g, g->s2, NL, D, RW("norm2.running_mean"), RW("norm2.running_var"), g->stat_n2, false, s));
   VTG(col_affine(0, g->s2, g->stat_n2, W("norm2.gamma"), W("norm2.beta"), g->o, NL, D, s));
   // ProjectorLayer::forward (projector_layer.hpp:43-116)
-  VTG(mm(false, false, (int)NP, D, C1, g->x, C1, W("proj.linear1.W"), D, g->q, D));
-  VTG(mm(false, false, (int)NL, D, D, g->o, D, W("proj.linear2.W"), D, g->k, D));
-  VTG(mm(false, false, (int)NL, C2, D, g->o, D, W("proj.linear3.W"), C2, g->v, C2, W("proj.linear3.b")));
+  VTG(mm_bf(false, false, (int)NP, D, C1, g->x, C1, W("proj.linear1.W"), D, g->q, D));
+  VTG(mm_bf(false, false, (int)NL, D, D, g->o, D, W("proj.linear2.W"), D, g->k, D));
+  VTG(mm_bf(false, false, (int)NL, C2, D, g->o, D, W("proj.linear3.W"), C2, g->v, C2, W("proj.linear3.b")));
   VTG(mm(false, false, (int)NP, C2, C1, g->x, C1, W("proj.downsample.W"), C2, g->z, C2, W("proj.downsample.b")));
-  VTG(mm(false, true, P, L, D, g->q, D, g->k, D, g->pa, L, nullptr, false, 1.f, n, (long)P * D, (long)L * D, (long)P * L));
+  VTG(mm_exact(false, true, P, L, D, g->q, D, g->k, D, g->pa, L, nullptr, false, 1.f, n, (long)P * D, (long)L * D, (long)P * L));
   VTG(softmax_rows(g->pa, NP, L, s));
   VTG(mm(false, false, P, C2, L, g->pa, L, g->v, C2, g->z, C2, nullptr, true, 1.f, n, (long)P * L, (long)L * C2,
          (long)P * C2));
@@ -756,7 +763,7 @@ int gen_forward(GenModel *g, const float *arena, const vt_layout *lo, float *are
                        g->pk);
     VT_CHECK_LAUNCH();
   }
-  VTG(mm(false, false, n, K, Q, g->pooled, Q, W("fc.W"), K, g->logits, K, W("fc.b")));
+  VTG(mm_bf(false, false, n, K, Q, g->pooled, Q, W("fc.W"), K, g->logits, K, W("fc.b")));
   float *probs = probs_out ? probs_out : g->probs;
   HIPCHK_G(hipMemcpyAsync(probs, g->logits, (size_t)n * K * sizeof(float), hipMemcpyDeviceToDevice, s));
   VTG(softmax_rows(probs, (long)n, K, s));
@@ -771,7 +778,7 @@ int gen_backward(GenModel *g, const float *arena, const vt_layout *lo, float *gr
   const long NP = (long)n * P, NL = (long)n * L;
   auto W = [&](const char *name) { return arena + lo->t[vt_find(lo, name)].offset; };
   auto G = [&](const char *name) { return grads + lo->t[vt_find(lo, name)].offset; };
-  const Gemm mm{g, s};
+  const Gemm mm{g, s, false}, mm_fwd{g, s, true};
   if (phase & 1) {
     // softmax - onehot, fc (softmax_layer.hpp:29, dense_layer.hpp:92-99)
     hipLaunchKernelGGL(k_dlogits, dim3((n * K + GT - 1) / GT), dim3(GT), 0, s, g->probs, labels, g->dlogits, n * K, K);
@@ -851,9 +858,9 @@ int gen_backward(GenModel *g, const float *arena, const vt_layout *lo, float *gr
     for (int h = 0; h < g->heads; ++h) {
       const std::string hs = std::to_string(h);
       const std::string nq = "mha.q" + hs + ".W", nk = "mha.k" + hs + ".W", nv = "mha.v" + hs + ".W";
-      VTG(mm(false, false, (int)NL, hd, D, g->tok, D, W(nq.c_str()), hd, g->Qm, hd));
-      VTG(mm(false, false, (int)NL, hd, D, g->tok, D, W(nk.c_str()), hd, g->Km, hd));
-      VTG(mm(false, false, (int)NL, hd, D, g->tok, D, W(nv.c_str()), hd, g->Vm, hd));
+      VTG(mm_fwd(false, false, (int)NL, hd, D, g->tok, D, W(nq.c_str()), hd, g->Qm, hd));
+      VTG(mm_fwd(false, false, (int)NL, hd, D, g->tok, D, W(nk.c_str()), hd, g->Km, hd));
+      VTG(mm_fwd(false, false, (int)NL, hd, D, g->tok, D, W(nv.c_str()), hd, g->Vm, hd));
       VTG(mm(false, true, n, n, hd, g->Km, hd, g->Qm, hd, g->attn, n, nullptr, false, scale, L, sG, sG, sS));
       VTG(softmax_rows(g->attn, NL, n, s));
       const float *dhd = g->dc + h * hd;  // this head's columns of the concat delta, row stride D
