@@ -428,6 +428,18 @@ int vt_gemm_bf16_mfma(int transA, int transB, int M, int N, int K, float alpha, 
  * Tensor::softmax_backward (tensor_cpu.hpp:946-950): da <- a * (da - sum_last(a * da)), in place on da. */
 int vt_softmax_rows(float *S, long rows, int width, vt_stream s);
 int vt_softmax_bwd_rows(const float *a, float *da, long rows, int width, vt_stream s);
+/* BatchNormLayer1D::forward / backward (layers/batch_normalization_layer.hpp:142-200) over a row matrix
+ * in [R, C]; BatchNorm2DLayer (:262-327) is the same arithmetic on the [N*H*W, C] view of its input.
+ * training != 0: batch statistics (biased variance), running = 0.1 batch + 0.9 running; else the running
+ * buffers.  stat [2C] receives (mean, 1/sqrt(var + 1e-5)) and is what the backward pass takes.  backward:
+ * ggamma = sum delta*xhat, gbeta = sum delta, din = the reference's input delta including its row-0
+ * variance term (:197-199).  scratch: vt_batchnorm_scratch_floats(C) floats. */
+long vt_batchnorm_scratch_floats(int C);
+int vt_batchnorm_fwd(const float *in, long R, int C, const float *gamma, const float *beta, float *running_mean,
+                     float *running_var, int training, float *stat, float *out, float *scratch, long scratch_floats,
+                     vt_stream s);
+int vt_batchnorm_bwd(const float *delta, const float *in, const float *stat, const float *gamma, long R, int C,
+                     float *ggamma, float *gbeta, float *din, float *scratch, long scratch_floats, vt_stream s);
 /* SelfAttention (layers/self_attention.hpp; the single-head layer the reference ships beside
  * MultiHeadAttention; VTCNN itself never instantiates it).
  * forward (:31-55): key = x.Wk, query = x.Wq (DenseLayer without bias), attn = softmax_last(key.query^T)

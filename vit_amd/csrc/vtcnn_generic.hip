@@ -881,6 +881,35 @@ int gen_backward(GenModel *g, const float *arena, const vt_layout *lo, float *gr
 }  // namespace vt
 
 // ---------------------------------------------------------------------------------------------
+// BatchNormLayer1D / BatchNorm2DLayer as stand-alone launchers over a row matrix [R, C] (channels innermost),
+// for hosts that keep their own layer objects (layers/batch_normalization_layer.hpp:142-200, 262-327).
+// scratch holds the per-block partial sums (4096 blocks at most) and the 2C backward coefficients.
+// ---------------------------------------------------------------------------------------------
+extern "C" long vt_batchnorm_scratch_floats(int C) { return C < 1 ? 0 : 4096L * 2 * C + 2L * C; }
+
+extern "C" int vt_batchnorm_fwd(const float *in, long R, int C, const float *gamma, const float *beta, float *running_mean,
+                                float *running_var, int training, float *stat, float *out, float *scratch,
+                                long scratch_floats, vt_stream s) {
+  if (!in || !gamma || !beta || !running_mean || !running_var || !stat || !out || R < 1 || C < 1 || C > 1024) return VT_EINVAL;
+  if (training && (!scratch || scratch_floats < vt_batchnorm_scratch_floats(C))) return VT_EINVAL;
+  vt::GenModel g{};
+  g.part = scratch;
+  g.part_floats = 4096L * 2 * C;
+  VTG(bn_stats(&g, in, R, C, running_mean, running_var, stat, !training, (hipStream_t)s));
+  return col_affine(0, in, stat, gamma, beta, out, R, C, (hipStream_t)s);
+}
+
+extern "C" int vt_batchnorm_bwd(const float *delta, const float *in, const float *stat, const float *gamma, long R, int C,
+                                float *ggamma, float *gbeta, float *din, float *scratch, long scratch_floats, vt_stream s) {
+  if (!delta || !in || !stat || !gamma || !ggamma || !gbeta || !din || R < 1 || C < 1 || C > 1024) return VT_EINVAL;
+  if (!scratch || scratch_floats < vt_batchnorm_scratch_floats(C)) return VT_EINVAL;
+  vt::GenModel g{};
+  g.part = scratch;
+  g.part_floats = 4096L * 2 * C;
+  return bn_backward(&g, delta, in, stat, gamma, R, C, ggamma, gbeta, scratch + 4096L * 2 * C, din, (hipStream_t)s);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Stand-alone launchers over the same kernels: Tensor::softmax / softmax_backward over the last axis
 // and the reference's single-head SelfAttention layer.
 // ---------------------------------------------------------------------------------------------
