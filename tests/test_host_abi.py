@@ -276,3 +276,15 @@ def test_reference_main_compiles_unchanged_against_the_mirror_headers(tmp_path):
            "-L" + os.path.join(root, "vit_amd"), "-lvtcnn_hip"]
     r = subprocess.run(cmd, cwd=work, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
+
+
+def test_cpp_tensor_operations_follow_the_reference_semantics():
+    """cpp/tests/tensor_ops_check.cpp: permute relabels, concat returns zeros, operator* keeps the left
+    operand's shape (row 0 of a taller right operand), the two sum(axis) forms, slices, pad, broadcasting
+    rules, draw order of the initialisers: the host half of the Tensor type, no device needed."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cpp", "build", "tensor_ops_check")
+    if not os.path.exists(exe):
+        pytest.fail("cpp/build/tensor_ops_check is not built (run __graft_entry__.build())")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
