@@ -4,7 +4,11 @@
 // and the same console lines (the web frontend greps "Imagen predicción:").  Runs on HIP device 0.
 // Environment overrides that do not change the positional CLI: VTCNN_BATCH_SIZE (default 32),
 // VTCNN_NUM_CLASSES (default 10), VTCNN_DATA_ROOT (default "."), VTCNN_LABELS_OUT (predict mode:
-// file that receives the predicted test labels, one per line, in loader order).
+// file that receives the predicted test labels, one per line, in loader order), VTCNN_EVAL_CHUNK (evaluate this
+// many images per launch set as consecutive loader batches with their own BatchNorm1D statistics; default:
+// one loader batch at a time, which is bit-identical to the host loop, while chunks differ from it in the
+// last bits of the running statistics), VTCNN_HOST_LOOP=1 (the reference's per-batch host loop instead of the
+// device-resident one).
 #include <algorithm>
 #include <cstdlib>
 #include <fstream>
@@ -59,7 +63,8 @@ void run_pipeline(const DatasetInfo &ds, bool train_mode, const std::string &dev
   DataLoader test_loader(test_set.images, test_set.labels, batch_size);
 
   VTCNN model(image_channels, input_dim, vt_layers_num, tokens, token_channels, vt_channels, transformer_enc_layers,
-              transformer_heads, transformer_fc_dim, transformer_dropout, num_classes, batch_size);
+              transformer_heads, transformer_fc_dim, transformer_dropout, num_classes,
+              std::max(batch_size, env_int("VTCNN_EVAL_CHUNK", 0)));  // workspace: evaluation runs this many images per launch set
   Trainer trainer(model, train_loader, val_loader, num_classes, batch_size, &test_loader);
   if (train_mode) {
     std::cout << "🚀 Entrenando modelo por " << epochs << " épocas...\n";

@@ -3,6 +3,7 @@
 // save / load, same exceptions.  All compute is delegated to libvtcnn_hip.so (include/vtcnn_hip.h);
 // this class stages mini-batches through pinned host memory and one HIP stream.
 #pragma once
+#include <cmath>
 #include <string>
 #include <vector>
 
@@ -25,6 +26,46 @@ class VTCNN : public Model {
     if (code != 0) throw std::runtime_error(std::string(what) + ": " + vt_error_string(code));
   }
 
+  // Weights are drawn from Tensor::global_gen AS IT STANDS (the reference's layers call Tensor::kaiming_normal /
+  // rand_uniform in construction order, model/vit_cnn.hpp:56-91), so a program that seeds or advances the
+  // generator before constructing the model gets what it would get from the reference; with the generator
+  // freshly seeded with 42 (main.cpp:12) this is the arena of vt_model_init_seed(42), bit for bit.
+  void init_from_global_gen() {
+    vt_layout lo;
+    check(vt_model_layout(h_, &lo), "VTCNN: vt_model_layout");
+    std::vector<float> arena(lo.n_total, 0.0f);
+    auto put = [&](const std::string &name, const Tensor &t) {
+      const int k = vt_find(&lo, name.c_str());
+      if (k < 0 || lo.t[k].size != (int)t.data.size()) throw std::runtime_error("VTCNN: layout has no tensor " + name);
+      std::copy(t.data.begin(), t.data.end(), arena.begin() + lo.t[k].offset);
+    };
+    auto dense = [&](const std::string &name, int in, int out) {
+      const float limit = std::sqrt(6.0f / (in + out));
+      put(name, Tensor::rand_uniform({in, out}, -limit, limit));
+    };
+    const int Ci = dims_.image_channels, c2 = dims_.vt_channels, c1 = c2 / 2, L = dims_.tokens, D = dims_.token_channels;
+    const int hd = D / dims_.heads;
+    put("conv.W", Tensor::kaiming_normal({c1, Ci, 3, 3}, Ci * 9));
+    dense("tok.linear1.W", c1, L);
+    dense("tok.linear2.W", c1, D);
+    for (int h = 0; h < dims_.heads; ++h)
+      for (const char *w : {"q", "k", "v"}) dense("mha." + std::string(w) + std::to_string(h) + ".W", D, hd);
+    dense("mha.o.W", D, D);
+    dense("ffn.linear1.W", D, D);
+    dense("ffn.linear2.W", D, D);
+    dense("proj.linear1.W", c1, D);
+    dense("proj.linear2.W", D, D);
+    dense("proj.linear3.W", D, c2);
+    dense("proj.downsample.W", c1, c2);
+    dense("fc.W", c2 * 14 * 14, dims_.num_classes);
+    for (const char *n : {"bn.gamma", "norm1.gamma", "norm2.gamma", "proj.norm.gamma", "bn.running_var", "norm1.running_var",
+                          "norm2.running_var", "proj.norm.running_var"}) {
+      const int k = vt_find(&lo, n);
+      std::fill(arena.begin() + lo.t[k].offset, arena.begin() + lo.t[k].offset + lo.t[k].size, 1.0f);
+    }
+    check(vt_model_set_arena(h_, arena.data()), "VTCNN: vt_model_set_arena");
+  }
+
  public:
   // transformer_enc_layers, transformer_fc_dim and transformer_dropout are accepted and ignored,
   // exactly as in the reference (visual_transformer.hpp:42, transformer_layer.hpp:18-23);
@@ -42,8 +83,7 @@ class VTCNN : public Model {
     dims_.heads = transformer_heads;
     dims_.num_classes = num_classes;
     check(vt_model_create(&dims_, max_batch_, device, nullptr, nullptr, &h_), "VTCNN: vt_model_create");
-    // weights come from Tensor::global_gen's seed (42 in main.cpp:12) in construction order
-    check(vt_model_init_seed(h_, 42u), "VTCNN: vt_model_init_seed");
+    init_from_global_gen();
     const size_t in_n = (size_t)max_batch_ * image_channels * input_dim * input_dim;
     vt_host::hip_check(hipStreamCreate(&stream_), "hipStreamCreate");
     vt_host::hip_check(hipMalloc((void **)&d_in_, in_n * sizeof(float)), "hipMalloc");
@@ -134,4 +174,39 @@ class VTCNN : public Model {
     return st;
   }
   vt_model *handle() { return h_; }
+
+  // ---- device-resident stepping (used by Trainer when the loader keeps its dataset on the device; the
+  // reference has no counterpart: its loop copies every batch through host tensors) ------------------------
+  int max_batch() const { return max_batch_; }
+  int num_classes() const { return dims_.num_classes; }
+  hipStream_t stream() const { return stream_; }
+  // one training iteration on images gathered on the device from the resident dataset: loader batch (rows
+  // d_indices[0..n) of the u8 image matrix, utils/load_dataset.hpp:129-151), forward, backward,
+  // update_weights(batch_size), and the batch's loss sum / correct count into slot `slot` of the two device
+  // arrays (utils/trainer.hpp:39-58).  Nothing is copied to the host and nothing waits.
+  void train_batch_resident(const unsigned char *d_images_u8, const int *d_all_labels, const int *d_indices, int n,
+                            float batch_size, int slot, float *d_loss_sums, int *d_correct) {
+    const int pixels = dims_.image_channels * dims_.input_dim * dims_.input_dim;
+    check(vt_loader_gather(d_images_u8, d_all_labels, d_indices, n, pixels, d_in_, d_labels_, stream_), "vt_loader_gather");
+    check(vt_model_forward(h_, d_in_, n, d_probs_, stream_), "VTCNN::forward");
+    check(vt_eval_accumulate(d_probs_, d_labels_, n, dims_.num_classes, slot, d_loss_sums, d_correct, nullptr, nullptr, stream_),
+          "vt_eval_accumulate");
+    check(vt_model_backward(h_, d_labels_, stream_), "VTCNN::backward");
+    check(vt_model_sgd_step(h_, lr_, batch_size, stream_), "update_weights");
+    last_n_ = n;
+  }
+  // forward-only over n gathered images that are consecutive loader batches of `group` images each (the last
+  // may be short), every batch with its own BatchNorm1D statistics as Trainer::evaluate sees them; per-batch
+  // loss sums / correct counts into slots slot0.., confusion matrix and arg-max labels (may be null) on the device
+  void eval_chunk_resident(const unsigned char *d_images_u8, const int *d_all_labels, const int *d_indices, int n, int group,
+                           int slot0, float *d_loss_sums, int *d_correct, int *d_confusion, int *d_argmax) {
+    const int pixels = dims_.image_channels * dims_.input_dim * dims_.input_dim;
+    check(vt_loader_gather(d_images_u8, d_all_labels, d_indices, n, pixels, d_in_, d_labels_, stream_), "vt_loader_gather");
+    if (n > group) check(vt_model_forward_grouped(h_, d_in_, n, group, d_probs_, stream_), "VTCNN::forward_grouped");
+    else check(vt_model_forward(h_, d_in_, n, d_probs_, stream_), "VTCNN::forward");
+    check(vt_eval_accumulate_grouped(d_probs_, d_labels_, n, dims_.num_classes, group, slot0, d_loss_sums, d_correct, d_confusion,
+                                     d_argmax, stream_),
+          "vt_eval_accumulate_grouped");
+    last_n_ = n;
+  }
 };

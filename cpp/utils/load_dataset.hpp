@@ -85,9 +85,71 @@ class DataLoader {
     index = 0;
     ++resets;
     reshuffle();
+    indices_uploaded_ = false;
   }
   size_t total_batches() const { return (images.size() + batch_size - 1) / batch_size; }
   const std::vector<int> &order() const { return indices; }
+  size_t size() const { return images.size(); }
+  size_t batch() const { return batch_size; }
+  const std::vector<int> &all_labels() const { return labels; }
+
+  // ---- device residency (no counterpart in the reference, whose next_batch copies every batch on the host,
+  // :129-151).  The whole dataset is kept on the device as the IDX bytes it was decoded from (pixel * 255 is an
+  // exact integer for data that came from loadImages2D: u8 / 255.0f), with the labels; a batch is then rows
+  // indices[first .. first + n) of that matrix, gathered by vt_loader_gather with the same division.  Only
+  // the shuffled index vector travels per epoch.  make_resident returns false (and the caller keeps the host
+  // loop) if some pixel is not of that form.
+  struct Resident {
+    unsigned char *images_u8 = nullptr;
+    int *labels = nullptr, *indices = nullptr;
+    int pixels = 0;
+  };
+  bool make_resident() {
+    if (resident_.images_u8) return true;
+    if (resident_failed_ || images.empty()) return false;
+    const size_t per = (size_t)C * H * W;
+    std::vector<unsigned char> bytes(images.size() * per);
+    for (size_t i = 0; i < images.size(); ++i) {
+      if (images[i].size() != per) return !(resident_failed_ = true);
+      for (size_t p = 0; p < per; ++p) {
+        const float v = images[i][p] * 255.0f;
+        const int q = (int)(v + 0.5f);
+        if (q < 0 || q > 255 || static_cast<float>(q) / 255.0f != images[i][p]) return !(resident_failed_ = true);
+        bytes[i * per + p] = (unsigned char)q;
+      }
+    }
+    if (per % 4 != 0) return !(resident_failed_ = true);
+    vt_host::hip_check(hipMalloc((void **)&resident_.images_u8, bytes.size()), "hipMalloc dataset");
+    vt_host::hip_check(hipMalloc((void **)&resident_.labels, labels.size() * sizeof(int)), "hipMalloc labels");
+    vt_host::hip_check(hipMalloc((void **)&resident_.indices, labels.size() * sizeof(int)), "hipMalloc indices");
+    vt_host::hip_check(hipMemcpy(resident_.images_u8, bytes.data(), bytes.size(), hipMemcpyHostToDevice), "H2D dataset");
+    vt_host::hip_check(hipMemcpy(resident_.labels, labels.data(), labels.size() * sizeof(int), hipMemcpyHostToDevice), "H2D labels");
+    resident_.pixels = (int)per;
+    indices_uploaded_ = false;
+    return true;
+  }
+  // the resident view with the CURRENT shuffled order on the device (uploaded once per reset)
+  const Resident &resident(hipStream_t stream) {
+    if (!indices_uploaded_) {
+      vt_host::hip_check(hipMemcpyAsync(resident_.indices, indices.data(), indices.size() * sizeof(int), hipMemcpyHostToDevice, stream),
+                         "H2D indices");
+      vt_host::hip_check(hipStreamSynchronize(stream), "sync");  // `indices` may be reshuffled right after
+      indices_uploaded_ = true;
+    }
+    return resident_;
+  }
+  void skip_to_end() { index = images.size(); }
+  DataLoader(const DataLoader &) = delete;
+  DataLoader &operator=(const DataLoader &) = delete;
+  ~DataLoader() {
+    if (resident_.images_u8) (void)hipFree(resident_.images_u8);
+    if (resident_.labels) (void)hipFree(resident_.labels);
+    if (resident_.indices) (void)hipFree(resident_.indices);
+  }
+
+ private:
+  Resident resident_;
+  bool resident_failed_ = false, indices_uploaded_ = false;
 };
 
 // Custom images for `predict` (utils/load_dataset.hpp:167-209): the .png / .jpg / .jpeg files of the

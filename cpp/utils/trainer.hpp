@@ -7,7 +7,10 @@
 #include <iomanip>
 #include <iostream>
 
+#include <cstdlib>
+
 #include "../model/model.hpp"
+#include "../model/vit_cnn.hpp"
 #include "load_dataset.hpp"
 #include "tensor.hpp"
 
@@ -24,8 +27,97 @@ class Trainer {
     int batches = 0;
     std::vector<int> truth, pred;
   };
+  // ---- device-resident path: taken when the model is the HIP VTCNN and the loader's dataset can live on the
+  // device (set VTCNN_HOST_LOOP=1 to force the host loop below, which is the reference's own).  Same batches
+  // in the same order, same arithmetic per batch; the per-batch loss and accuracy stay on the device until
+  // the sweep ends, so nothing in the loop waits for the GPU.
+  struct DeviceCounters {
+    float *loss_sums = nullptr;
+    int *correct = nullptr, *confusion = nullptr, *argmax = nullptr;
+    int slots = 0, K = 0, images = 0;
+    DeviceCounters(int slots_, int K_, int images_) : slots(slots_), K(K_), images(images_) {
+      vt_host::hip_check(hipMalloc((void **)&loss_sums, sizeof(float) * slots), "hipMalloc");
+      vt_host::hip_check(hipMalloc((void **)&correct, sizeof(int) * slots), "hipMalloc");
+      vt_host::hip_check(hipMalloc((void **)&confusion, sizeof(int) * K * K), "hipMalloc");
+      vt_host::hip_check(hipMalloc((void **)&argmax, sizeof(int) * std::max(images, 1)), "hipMalloc");
+      vt_host::hip_check(hipMemset(confusion, 0, sizeof(int) * K * K), "hipMemset");
+    }
+    ~DeviceCounters() {
+      (void)hipFree(loss_sums);
+      (void)hipFree(correct);
+      (void)hipFree(confusion);
+      (void)hipFree(argmax);
+    }
+    DeviceCounters(const DeviceCounters &) = delete;
+    DeviceCounters &operator=(const DeviceCounters &) = delete;
+  };
+  VTCNN *device_model(DataLoader &loader) {
+    const char *force = std::getenv("VTCNN_HOST_LOOP");
+    if (force && *force && *force != '0') return nullptr;
+    VTCNN *m = dynamic_cast<VTCNN *>(&model);
+    if (!m || (int)loader.batch() > m->max_batch() || !loader.make_resident()) return nullptr;
+    return m;
+  }
+  // per-batch means summed in batch order, as the reference's loop accumulates them (utils/trainer.hpp:55-58)
+  static void fold_batches(const std::vector<float> &loss_sums, const std::vector<int> &correct, size_t total, size_t bs, Pass &p) {
+    for (size_t b = 0; b < loss_sums.size(); ++b) {
+      const float n = (float)std::min(bs, total - b * bs);
+      p.loss += loss_sums[b] / n;
+      p.acc += static_cast<float>(correct[b]) / n;
+      ++p.batches;
+    }
+  }
+  Pass sweep_resident(VTCNN &m, DataLoader &loader, bool keep_labels) {
+    Pass p;
+    const size_t total = loader.size(), bs = loader.batch(), nb = loader.total_batches();
+    DeviceCounters dc((int)nb, num_classes, (int)total);
+    const DataLoader::Resident &r = loader.resident(m.stream());
+    m.set_training(false);
+    // consecutive loader batches go through one launch set per chunk; each keeps its own BatchNorm1D statistics
+    const size_t per_chunk = (bs % 4 == 0) ? std::max<size_t>(1, (size_t)m.max_batch() / bs) : 1;
+    for (size_t b0 = 0; b0 < nb; b0 += per_chunk) {
+      const size_t first = b0 * bs, n = std::min(per_chunk * bs, total - first);
+      m.eval_chunk_resident(r.images_u8, r.labels, r.indices + first, (int)n, (int)bs, (int)b0, dc.loss_sums, dc.correct,
+                            dc.confusion, dc.argmax + first);
+    }
+    m.set_training(true);
+    std::vector<float> ls(nb);
+    std::vector<int> ok(nb);
+    vt_host::hip_check(hipMemcpyAsync(ls.data(), dc.loss_sums, sizeof(float) * nb, hipMemcpyDeviceToHost, m.stream()), "D2H");
+    vt_host::hip_check(hipMemcpyAsync(ok.data(), dc.correct, sizeof(int) * nb, hipMemcpyDeviceToHost, m.stream()), "D2H");
+    if (keep_labels) {
+      p.pred.resize(total);
+      vt_host::hip_check(hipMemcpyAsync(p.pred.data(), dc.argmax, sizeof(int) * total, hipMemcpyDeviceToHost, m.stream()), "D2H");
+      p.truth.resize(total);
+      for (size_t i = 0; i < total; ++i) p.truth[i] = loader.all_labels()[loader.order()[i]];
+    }
+    vt_host::hip_check(hipStreamSynchronize(m.stream()), "sync");
+    fold_batches(ls, ok, total, bs, p);
+    loader.skip_to_end();
+    return p;
+  }
+  // one epoch of training on the device-resident dataset; returns images trained
+  long train_epoch_resident(VTCNN &m, Pass &p) {
+    const size_t total = train_loader.size(), bs = train_loader.batch(), nb = train_loader.total_batches();
+    DeviceCounters dc((int)nb, num_classes, 0);
+    const DataLoader::Resident &r = train_loader.resident(m.stream());
+    for (size_t b = 0; b < nb; ++b) {
+      const size_t first = b * bs, n = std::min(bs, total - first);
+      m.train_batch_resident(r.images_u8, r.labels, r.indices + first, (int)n, (float)batch_size, (int)b, dc.loss_sums, dc.correct);
+    }
+    std::vector<float> ls(nb);
+    std::vector<int> ok(nb);
+    vt_host::hip_check(hipMemcpyAsync(ls.data(), dc.loss_sums, sizeof(float) * nb, hipMemcpyDeviceToHost, m.stream()), "D2H");
+    vt_host::hip_check(hipMemcpyAsync(ok.data(), dc.correct, sizeof(int) * nb, hipMemcpyDeviceToHost, m.stream()), "D2H");
+    vt_host::hip_check(hipStreamSynchronize(m.stream()), "sync");
+    fold_batches(ls, ok, total, bs, p);
+    train_loader.skip_to_end();
+    return (long)total;
+  }
+
   // forward-only sweep over a loader in eval mode
   Pass sweep(DataLoader &loader, bool keep_labels) {
+    if (VTCNN *m = device_model(loader)) return sweep_resident(*m, loader, keep_labels);
     Pass p;
     model.set_training(false);
     while (loader.has_next()) {
@@ -60,6 +152,13 @@ class Trainer {
       float epoch_loss = 0.0f, epoch_acc = 0.0f;
       int batches = 0;
       long images = 0;
+      if (VTCNN *m = device_model(train_loader)) {
+        Pass p;
+        images = train_epoch_resident(*m, p);
+        epoch_loss = p.loss;
+        epoch_acc = p.acc;
+        batches = p.batches;
+      }
       while (train_loader.has_next()) {
         auto batch = train_loader.next_batch();
         const Tensor &X = batch.first, &y = batch.second;
@@ -131,6 +230,7 @@ class Trainer {
     const Tensor input({1, 1, 28, 28}, image_data);
     model.set_training(false);
     const Tensor out = model.forward(input);
+    (void)out.printsummary();  // the reference builds this string and drops it (utils/trainer.hpp:208): nothing is printed
     int best = 0;
     for (size_t i = 1; i < out.data.size(); ++i)
       if (out.data[i] > out.data[best]) best = (int)i;

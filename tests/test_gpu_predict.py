@@ -150,6 +150,22 @@ def test_cpp_cli_train_one_epoch_runs_and_saves(tmp_path):
     a1 = m.get_arena()
     nt = m.layout.n_trainable
     assert np.isfinite(a1).all() and not np.array_equal(a0[:nt], a1[:nt])
+    # The run above used the device-resident loop (dataset on the device as bytes, batches gathered there,
+    # per-batch loss / accuracy kept on the device).  The reference's own loop shape (every batch through host
+    # tensors, VTCNN_HOST_LOOP=1) must train to the same bytes and print the same epoch numbers.
+    first = ck.read_bytes()
+    r2 = subprocess.run([exe, "bloodmnist", "train", "1"], env=dict(env, VTCNN_HOST_LOOP="1"), capture_output=True, text=True, timeout=110)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    assert ck.read_bytes() == first
+
+    def numbers(out, key):
+        line = [ln for ln in out.splitlines() if ln.startswith(key)][0]
+        return [float(v) for v in re.findall(r"(?:Loss|Accuracy): ([0-9.]+)", line)]
+    for key in ("Train Loss:", "Val Loss:", "[TEST] Final Evaluation"):
+        a, b = numbers(r.stdout, key), numbers(r2.stdout, key)
+        assert len(a) == 2 and abs(a[0] - b[0]) <= 2e-4 * max(1.0, b[0]) and abs(a[1] - b[1]) < 1e-3, (key, a, b)
+    cm = lambda out: out[out.index("Matriz de Confusi"):]
+    assert cm(r.stdout) == cm(r2.stdout)
 
 
 def test_predict_batch_8192_labels_vs_oracle():
