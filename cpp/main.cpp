@@ -8,7 +8,8 @@
 // many images per launch set as consecutive loader batches with their own BatchNorm1D statistics; default:
 // one loader batch at a time, which is bit-identical to the host loop, while chunks differ from it in the
 // last bits of the running statistics), VTCNN_HOST_LOOP=1 (the reference's per-batch host loop instead of the
-// device-resident one).
+// device-resident one), VTCNN_GPUS (train data-parallel over that many GPUs of the node: one replica and one
+// loader batch per GPU and round, gradients summed over RCCL, see utils/trainer.hpp).
 #include <algorithm>
 #include <cstdlib>
 #include <fstream>

@@ -4,6 +4,8 @@
 // this class stages mini-batches through pinned host memory and one HIP stream.
 #pragma once
 #include <cmath>
+#include <memory>
+#include <random>
 #include <string>
 #include <vector>
 
@@ -14,7 +16,7 @@
 class VTCNN : public Model {
   vt_model *h_ = nullptr;
   vt_dims dims_{};
-  int max_batch_;
+  int max_batch_, device_;
   hipStream_t stream_ = nullptr;
   float *d_in_ = nullptr, *d_probs_ = nullptr, *pin_in_ = nullptr, *pin_out_ = nullptr;
   int *d_labels_ = nullptr;
@@ -73,7 +75,7 @@ class VTCNN : public Model {
   VTCNN(int image_channels, int input_dim, int vt_layers_num, int tokens, int token_channels, int vt_channels,
         int /*transformer_enc_layers*/, int transformer_heads, int /*transformer_fc_dim*/ = 1024,
         float /*transformer_dropout*/ = 0.5f, int num_classes = 1000, int max_batch = 32, int device = 0)
-      : max_batch_(max_batch) {
+      : max_batch_(max_batch), device_(device) {
     if (vt_layers_num != 1) throw std::runtime_error("VTCNN: only vt_layers_num == 1 is supported");
     dims_.image_channels = image_channels;
     dims_.input_dim = input_dim;
@@ -82,6 +84,7 @@ class VTCNN : public Model {
     dims_.vt_channels = vt_channels;
     dims_.heads = transformer_heads;
     dims_.num_classes = num_classes;
+    vt_host::DeviceScope on_device(device_);  // stream and staging buffers live on the model's device
     check(vt_model_create(&dims_, max_batch_, device, nullptr, nullptr, &h_), "VTCNN: vt_model_create");
     init_from_global_gen();
     const size_t in_n = (size_t)max_batch_ * image_channels * input_dim * input_dim;
@@ -95,6 +98,7 @@ class VTCNN : public Model {
   VTCNN(const VTCNN &) = delete;
   VTCNN &operator=(const VTCNN &) = delete;
   ~VTCNN() override {
+    (void)hipSetDevice(device_);
     if (stream_) (void)hipStreamSynchronize(stream_);
     vt_model_destroy(h_);
     (void)hipFree(d_in_);
@@ -178,6 +182,28 @@ class VTCNN : public Model {
   // ---- device-resident stepping (used by Trainer when the loader keeps its dataset on the device; the
   // reference has no counterpart: its loop copies every batch through host tensors) ------------------------
   int max_batch() const { return max_batch_; }
+  int device() const { return device_; }
+  const vt_dims &dims() const { return dims_; }
+  float learning_rate() const { return lr_; }
+  // a second model of the same shape on another device with this model's weights and statistics (data-parallel rank);
+  // Tensor::global_gen is left as it was
+  std::unique_ptr<VTCNN> replica_on(int device) {
+    const std::mt19937 keep = Tensor::global_gen;
+    std::unique_ptr<VTCNN> r(new VTCNN(dims_.image_channels, dims_.input_dim, 1, dims_.tokens, dims_.token_channels, dims_.vt_channels,
+                                       0, dims_.heads, 0, 0.0f, dims_.num_classes, max_batch_, device));
+    Tensor::global_gen = keep;
+    r->copy_weights_from(*this);
+    return r;
+  }
+  void copy_weights_from(VTCNN &other) {
+    vt_layout lo;
+    check(vt_model_layout(h_, &lo), "VTCNN: vt_model_layout");
+    std::vector<float> arena(lo.n_total);
+    vt_host::hip_check(hipStreamSynchronize(other.stream_), "sync");
+    check(vt_model_get_arena(other.h_, arena.data()), "VTCNN: vt_model_get_arena");
+    vt_host::hip_check(hipStreamSynchronize(stream_), "sync");
+    check(vt_model_set_arena(h_, arena.data()), "VTCNN: vt_model_set_arena");
+  }
   int num_classes() const { return dims_.num_classes; }
   hipStream_t stream() const { return stream_; }
   // one training iteration on images gathered on the device from the resident dataset: loader batch (rows
@@ -186,13 +212,19 @@ class VTCNN : public Model {
   // arrays (utils/trainer.hpp:39-58).  Nothing is copied to the host and nothing waits.
   void train_batch_resident(const unsigned char *d_images_u8, const int *d_all_labels, const int *d_indices, int n,
                             float batch_size, int slot, float *d_loss_sums, int *d_correct) {
+    gradients_resident(d_images_u8, d_all_labels, d_indices, n, slot, d_loss_sums, d_correct);
+    check(vt_model_sgd_step(h_, lr_, batch_size, stream_), "update_weights");
+  }
+  // the same iteration up to and including backward: the summed gradients of the batch stay in the gradient arena
+  // (a data-parallel caller exchanges them before update_weights)
+  void gradients_resident(const unsigned char *d_images_u8, const int *d_all_labels, const int *d_indices, int n, int slot,
+                          float *d_loss_sums, int *d_correct) {
     const int pixels = dims_.image_channels * dims_.input_dim * dims_.input_dim;
     check(vt_loader_gather(d_images_u8, d_all_labels, d_indices, n, pixels, d_in_, d_labels_, stream_), "vt_loader_gather");
     check(vt_model_forward(h_, d_in_, n, d_probs_, stream_), "VTCNN::forward");
     check(vt_eval_accumulate(d_probs_, d_labels_, n, dims_.num_classes, slot, d_loss_sums, d_correct, nullptr, nullptr, stream_),
           "vt_eval_accumulate");
     check(vt_model_backward(h_, d_labels_, stream_), "VTCNN::backward");
-    check(vt_model_sgd_step(h_, lr_, batch_size, stream_), "update_weights");
     last_n_ = n;
   }
   // forward-only over n gathered images that are consecutive loader batches of `group` images each (the last

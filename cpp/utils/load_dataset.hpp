@@ -23,10 +23,12 @@ struct Dataset {
 
 inline std::vector<std::vector<float>> loadImages2D(const std::string &filename, int max_images = 9999999) {
   int n = 0, r = 0, c = 0;
-  if (vt_idx_read_images(filename.c_str(), max_images, nullptr, &n, &r, &c) != 0)
-    throw std::runtime_error("No se pudo abrir el archivo de imágenes");
+  int rc = vt_idx_read_images(filename.c_str(), max_images, nullptr, &n, &r, &c);
+  if (rc == VT_EIO) throw std::runtime_error("No se pudo abrir el archivo de imágenes");
+  if (rc != 0) throw std::runtime_error("Archivo de imágenes IDX inválido: " + filename + " (" + vt_error_string(rc) + ")");
   std::vector<float> flat((size_t)n * r * c);
-  vt_idx_read_images(filename.c_str(), max_images, flat.data(), &n, &r, &c);
+  rc = vt_idx_read_images(filename.c_str(), max_images, flat.data(), &n, &r, &c);
+  if (rc != 0) throw std::runtime_error("No se pudo leer el archivo de imágenes: " + filename + " (" + vt_error_string(rc) + ")");
   std::vector<std::vector<float>> out(n);
   for (int i = 0; i < n; ++i) out[i].assign(flat.begin() + (size_t)i * r * c, flat.begin() + (size_t)(i + 1) * r * c);
   return out;
@@ -34,10 +36,12 @@ inline std::vector<std::vector<float>> loadImages2D(const std::string &filename,
 
 inline std::vector<int> loadLabels(const std::string &filename, int max_labels = 9999999) {
   int n = 0;
-  if (vt_idx_read_labels(filename.c_str(), max_labels, nullptr, &n) != 0)
-    throw std::runtime_error("No se pudo abrir el archivo de etiquetas");
+  int rc = vt_idx_read_labels(filename.c_str(), max_labels, nullptr, &n);
+  if (rc == VT_EIO) throw std::runtime_error("No se pudo abrir el archivo de etiquetas");
+  if (rc != 0) throw std::runtime_error("Archivo de etiquetas IDX inválido: " + filename + " (" + vt_error_string(rc) + ")");
   std::vector<int> out(n);
-  vt_idx_read_labels(filename.c_str(), max_labels, out.data(), &n);
+  rc = vt_idx_read_labels(filename.c_str(), max_labels, out.data(), &n);
+  if (rc != 0) throw std::runtime_error("No se pudo leer el archivo de etiquetas: " + filename + " (" + vt_error_string(rc) + ")");
   return out;
 }
 

@@ -43,6 +43,17 @@ struct DeviceBuffer {
   DeviceBuffer(const DeviceBuffer &) = delete;
   DeviceBuffer &operator=(const DeviceBuffer &) = delete;
 };
+// makes `device` the calling thread's HIP device for the scope's lifetime
+struct DeviceScope {
+  int previous = 0;
+  explicit DeviceScope(int device) {
+    hip_check(hipGetDevice(&previous), "hipGetDevice");
+    if (device != previous) hip_check(hipSetDevice(device), "hipSetDevice");
+  }
+  ~DeviceScope() { (void)hipSetDevice(previous); }
+  DeviceScope(const DeviceScope &) = delete;
+  DeviceScope &operator=(const DeviceScope &) = delete;
+};
 }  // namespace vt_host
 
 class Tensor {

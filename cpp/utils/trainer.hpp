@@ -8,6 +8,9 @@
 #include <iostream>
 
 #include <cstdlib>
+#include <exception>
+#include <memory>
+#include <thread>
 
 #include "../model/model.hpp"
 #include "../model/vit_cnn.hpp"
@@ -115,6 +118,122 @@ class Trainer {
     return (long)total;
   }
 
+  // ---- data parallel over the GPUs of the node from this one process (environment VTCNN_GPUS = G; unset: the
+  // single-device loops above.  No counterpart in the reference).  Rank r owns a replica of the model and of the
+  // resident training set on a device of its own and a host thread that issues its work; round t trains loader
+  // batches t*G .. t*G+G-1, one per rank, the gradient arenas are summed across the ranks and every rank applies
+  // update_weights(G * batch_size): one SGD step on G batches per round.  Every rank's BatchNorm layers see the
+  // statistics of its own batch only; a last round with fewer than G batches is not trained; validation and the
+  // test sweep run on rank 0, whose model is the caller's.  With G = 1 the sum is the identity and the run is the
+  // single-device one, byte for byte.
+  struct DataParallel {
+    vt_dp *dp = nullptr;
+    std::vector<std::unique_ptr<VTCNN>> replicas;  // ranks 1 .. G-1
+    std::vector<VTCNN *> models;                   // rank -> model (rank 0: the caller's)
+    std::vector<unsigned char *> images;           // rank -> resident u8 image matrix on that rank's device
+    std::vector<int *> labels, indices;
+    int trainable = 0;
+    ~DataParallel() {
+      for (size_t r = 1; r < models.size(); ++r) {  // rank 0's buffers belong to the loader
+        (void)hipFree(images[r]);
+        (void)hipFree(labels[r]);
+        (void)hipFree(indices[r]);
+      }
+      replicas.clear();
+      if (dp) vt_dp_destroy(dp);
+    }
+  };
+  std::unique_ptr<DataParallel> dp_;
+  DataParallel *data_parallel(VTCNN &m) {
+    const char *want = std::getenv("VTCNN_GPUS");
+    if (!want || !*want) return nullptr;
+    if (dp_) return dp_.get();
+    int have = 0;
+    vt_host::hip_check(hipGetDeviceCount(&have), "hipGetDeviceCount");
+    const int G = std::atoi(want);
+    if (G < 1 || G > have) throw std::runtime_error("VTCNN_GPUS must be between 1 and the number of visible GPUs");
+    std::unique_ptr<DataParallel> g(new DataParallel);
+    std::vector<int> devices{m.device()};
+    for (int d = 0; d < have && (int)devices.size() < G; ++d)
+      if (d != m.device()) devices.push_back(d);
+    const int rc = vt_dp_init(G, devices.data(), &g->dp);
+    if (rc != 0) throw std::runtime_error(std::string("vt_dp_init: ") + vt_error_string(rc));
+    vt_layout lo;
+    vt_model_layout(m.handle(), &lo);
+    g->trainable = lo.n_trainable;
+    const DataLoader::Resident &r0 = train_loader.resident(m.stream());
+    const size_t count = train_loader.size(), bytes = count * (size_t)r0.pixels;
+    g->models.push_back(&m);
+    g->images.push_back(r0.images_u8);
+    g->labels.push_back(r0.labels);
+    g->indices.push_back(r0.indices);
+    for (int r = 1; r < G; ++r) {
+      g->replicas.push_back(m.replica_on(devices[r]));
+      g->models.push_back(g->replicas.back().get());
+      vt_host::DeviceScope on_device(devices[r]);
+      unsigned char *img = nullptr;
+      int *lab = nullptr, *idx = nullptr;
+      vt_host::hip_check(hipMalloc((void **)&img, bytes), "hipMalloc dataset");
+      vt_host::hip_check(hipMalloc((void **)&lab, count * sizeof(int)), "hipMalloc labels");
+      vt_host::hip_check(hipMalloc((void **)&idx, count * sizeof(int)), "hipMalloc indices");
+      g->images.push_back(img);
+      g->labels.push_back(lab);
+      g->indices.push_back(idx);
+      vt_host::hip_check(hipMemcpyPeer(img, devices[r], r0.images_u8, m.device(), bytes), "dataset to peer");
+      vt_host::hip_check(hipMemcpyPeer(lab, devices[r], r0.labels, m.device(), count * sizeof(int)), "labels to peer");
+    }
+    dp_ = std::move(g);
+    return dp_.get();
+  }
+  long train_epoch_data_parallel(DataParallel &g, Pass &p) {
+    const size_t total = train_loader.size(), bs = train_loader.batch(), nb = train_loader.total_batches();
+    const size_t G = g.models.size(), rounds = nb / G;
+    if (rounds == 0) throw std::runtime_error("VTCNN_GPUS: the training set has fewer batches than GPUs");
+    (void)train_loader.resident(g.models[0]->stream());  // this epoch's order on rank 0's device
+    std::vector<std::vector<float>> ls(G, std::vector<float>(rounds));
+    std::vector<std::vector<int>> ok(G, std::vector<int>(rounds));
+    std::vector<std::exception_ptr> failure(G);
+    auto rank_epoch = [&](size_t r) {
+      try {
+        VTCNN &m = *g.models[r];
+        vt_host::DeviceScope on_device(m.device());
+        DeviceCounters dc((int)std::max<size_t>(rounds, 1), num_classes, 0);
+        if (r > 0)
+          vt_host::hip_check(hipMemcpyAsync(g.indices[r], train_loader.order().data(), total * sizeof(int), hipMemcpyHostToDevice,
+                                            m.stream()), "H2D indices");
+        for (size_t t = 0; t < rounds; ++t) {
+          const size_t first = (t * G + r) * bs, n = std::min(bs, total - first);
+          m.gradients_resident(g.images[r], g.labels[r], g.indices[r] + first, (int)n, (int)t, dc.loss_sums, dc.correct);
+          const int rc = vt_dp_allreduce_rank_async(g.dp, (int)r, vt_model_grads_ptr(m.handle()), 0, g.trainable, m.stream());
+          if (rc != 0) throw std::runtime_error(std::string("vt_dp_allreduce_rank_async: ") + vt_error_string(rc));
+          m.update_weights((float)(G * (size_t)batch_size));
+        }
+        vt_host::hip_check(hipMemcpyAsync(ls[r].data(), dc.loss_sums, sizeof(float) * rounds, hipMemcpyDeviceToHost, m.stream()), "D2H");
+        vt_host::hip_check(hipMemcpyAsync(ok[r].data(), dc.correct, sizeof(int) * rounds, hipMemcpyDeviceToHost, m.stream()), "D2H");
+        vt_host::hip_check(hipStreamSynchronize(m.stream()), "sync");
+      } catch (...) {
+        failure[r] = std::current_exception();
+      }
+    };
+    std::vector<std::thread> workers;
+    for (size_t r = 1; r < G; ++r) workers.emplace_back(rank_epoch, r);
+    rank_epoch(0);
+    for (std::thread &w : workers) w.join();
+    for (const std::exception_ptr &e : failure)
+      if (e) std::rethrow_exception(e);
+    long images = 0;
+    for (size_t t = 0; t < rounds; ++t)  // per-batch means folded in loader order, as the single-device loop does
+      for (size_t r = 0; r < G; ++r) {
+        const float n = (float)std::min(bs, total - (t * G + r) * bs);
+        p.loss += ls[r][t] / n;
+        p.acc += static_cast<float>(ok[r][t]) / n;
+        ++p.batches;
+        images += (long)n;
+      }
+    train_loader.skip_to_end();
+    return images;
+  }
+
   // forward-only sweep over a loader in eval mode
   Pass sweep(DataLoader &loader, bool keep_labels) {
     if (VTCNN *m = device_model(loader)) return sweep_resident(*m, loader, keep_labels);
@@ -154,7 +273,8 @@ class Trainer {
       long images = 0;
       if (VTCNN *m = device_model(train_loader)) {
         Pass p;
-        images = train_epoch_resident(*m, p);
+        DataParallel *g = data_parallel(*m);
+        images = g ? train_epoch_data_parallel(*g, p) : train_epoch_resident(*m, p);
         epoch_loss = p.loss;
         epoch_acc = p.acc;
         batches = p.batches;

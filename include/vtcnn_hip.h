@@ -56,6 +56,10 @@ int vt_model_create(const vt_dims *dims, int max_batch, int device, float *ext_a
                     vt_model **out);
 int vt_model_destroy(vt_model *m);
 int vt_model_layout(const vt_model *m, vt_layout *out);
+/* 1: the handle has the reference's main.cpp shape and runs the fused kernels (the only ones behind
+ * vt_model_forward_grouped, the two-stream backward, deferred attention and graph capture of a step);
+ * 0: any other shape, run by the general step. */
+int vt_model_is_fused(const vt_model *m);
 
 /* Weight initialisation in the reference's construction and draw order from mt19937(seed)
  * (main.cpp:12; Tensor::kaiming_normal / rand_uniform, utils/tensor/tensor_cpu.hpp:69-106;
@@ -220,7 +224,9 @@ int vt_model_save_v2(vt_model *m, const vt_train_state *state, const char *path)
 int vt_model_load_v2(vt_model *m, vt_train_state *state, const char *path);
 
 /* loadImages2D / loadLabels (utils/load_dataset.hpp:20-85): big-endian IDX headers, pixel
- * u8 / 255.0f, label u8 -> int.  Query sizes with out == NULL. */
+ * u8 / 255.0f, label u8 -> int.  Query sizes with out == NULL.  The magic number is not checked (the
+ * reference reads and ignores it); VT_EIO: the file cannot be opened, VT_EFORMAT: header shorter than its
+ * fields, a negative count or a pixel count beyond int, VT_ENOMEM: no host memory for the staging copy. */
 int vt_idx_read_images(const char *path, int max_images, float *out, int *n, int *rows, int *cols);
 int vt_idx_read_labels(const char *path, int max_labels, int *out, int *n);
 /* load_image_as_vector's decode step (utils/load_image_stb.hpp:9-26: stbi_load(path, &w, &h, &n, 1)):
@@ -477,6 +483,36 @@ int vt_sgd_update(float *w, float *g, int n, float lr, float divisor, int zero_g
  * provided as an extension, parity unpinned. */
 int vt_adam_update(float *w, float *g, float *m1, float *m2, int n, float lr, float beta1, float beta2, float eps,
                    int step, float divisor, vt_stream s);
+
+/* ---------------------------------------------------------------------------------------------
+ * Data parallel over the GPUs of one node, driven from ONE process (the C++ CLI's form; a host with
+ * one process per GPU exchanges the gradient arena with its own collective library instead).
+ * No counterpart in the reference, which trains on one device (utils/trainer.hpp:28-101): every
+ * rank runs Trainer::train's forward + backward on its own mini-batch, the gradient arenas are
+ * summed, and every rank calls vt_model_sgd_step with divisor ranks * batch_size, which is the
+ * reference's update for one mini-batch of ranks * batch_size images except that each rank's
+ * BatchNorm layers see the statistics of its own share only.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct vt_dp vt_dp;
+/* One RCCL communicator per entry of device_ids (distinct HIP devices, 1 <= ranks <= 64).  RCCL is
+ * opened at run time (librccl.so.1, or the path in the environment variable VT_RCCL_LIBRARY):
+ * VT_EUNSUPPORTED when it cannot be found, VT_EIO when it reports an error. */
+int vt_dp_init(int ranks, const int *device_ids, vt_dp **out);
+int vt_dp_destroy(vt_dp *dp);
+int vt_dp_ranks(const vt_dp *dp);
+/* In-place sum over the ranks of the `count` floats starting at d_bufs[r] + first (d_bufs[r]: a buffer
+ * on rank r's device, e.g. vt_model_grads_ptr), issued on streams[r] behind whatever that stream
+ * already holds; returns without waiting.  Splitting the arena into several calls (buckets) lets the
+ * exchange of one part start while another part's backward kernels are still being issued. */
+int vt_dp_allreduce_async(vt_dp *dp, float *const *d_bufs, long first, long count, const vt_stream *streams);
+/* The share of ONE rank in the same exchange, for a host that drives every GPU from a thread of its own (one
+ * thread issuing for all ranks is bound by its launch rate long before the GPUs are busy): every rank's
+ * thread makes this call with the same first / count, in the same order; the exchange runs once all of
+ * them have.  Calls for different ranks may run concurrently; calls for one rank may not. */
+int vt_dp_allreduce_rank_async(vt_dp *dp, int rank, float *d_buf, long first, long count, vt_stream stream);
+/* Blocks the host until the exchanges issued so far have finished on every rank.  Work issued on
+ * streams[r] after vt_dp_allreduce_async is ordered behind the exchange without this call. */
+int vt_dp_wait(vt_dp *dp);
 
 #ifdef __cplusplus
 }

@@ -53,6 +53,47 @@ def test_python_trainer_evaluate_test_matches_reference():
         assert rel_err(p, g["probs"][s:s + 32]) < 1e-4, s
 
 
+def test_python_trainer_evaluates_a_general_shape_model_with_20_classes():
+    """A model outside the headline shape (general step) with more classes than the fused kernels take and a
+    workspace of several loader batches: Trainer.evaluate / evaluate_test must go batch by batch (there is no
+    grouped launch set for this shape), keep the bookkeeping on the device for K = 20, and print the reference's
+    aggregate and per-class lines (utils/trainer.hpp:128-167)."""
+    from vit_amd import VTCNN, Dims
+    from vit_amd.engine import DataLoader, Trainer, class_stats
+    k, n, bs = 20, 72, 16
+    rng = np.random.default_rng(20)
+    x = (rng.integers(0, 256, size=(n, 784)).astype(np.float32) / np.float32(255.0))
+    y = rng.integers(0, k, size=n).astype(np.int32)
+    m = VTCNN(Dims(num_classes=k, tokens=8, token_channels=16, vt_channels=8, heads=2), max_batch=64, seed=42)
+    assert not m.fused
+    loader = DataLoader(x, y, bs)
+    lines = []
+    tr = Trainer(m, loader, loader, k, bs, test_loader=loader, out=lines.append)
+    vloss, vacc = tr.evaluate()
+    loss, acc, pred, truth, cm = tr.evaluate_test()
+    assert int(cm.sum()) == n and np.array_equal(truth, y[loader.indices])
+    # the same sweep by hand: eval mode, one forward per loader batch
+    m.set_training(False)
+    xs = torch.from_numpy(x.reshape(n, 1, 28, 28)).cuda()
+    losses, accs, preds = [], [], []
+    for s0 in range(0, n, bs):
+        sel = loader.indices[s0:s0 + bs]
+        p = m.forward(xs[torch.from_numpy(sel.astype(np.int64)).cuda()].contiguous()).cpu().numpy()
+        losses.append(float(np.mean(-np.log(p[np.arange(len(sel)), y[sel]] + np.float32(1e-8)))))
+        preds.append(p.argmax(1))
+        accs.append(float(np.mean(preds[-1] == y[sel])))
+    m.set_training(True)
+    assert np.array_equal(pred, np.concatenate(preds))
+    assert abs(loss - np.mean(losses)) < 1e-5 * max(1.0, abs(loss)) and abs(acc - np.mean(accs)) < 1e-6
+    want = np.zeros((k, k), dtype=np.int64)
+    np.add.at(want, (truth, pred), 1)
+    assert np.array_equal(cm, want)
+    text = "\n".join(lines)
+    st = class_stats(cm)
+    assert " - F1 Score (macro):    %.4f" % st["macro_f1"] in text and " - Recall (macro):      " in text
+    assert "Per-Class Metrics" in text and text.count("\n") > 2 * k
+
+
 @pytest.mark.parametrize("n", [1, 7, 256])
 def test_eval_forward_other_batch_sizes_vs_oracle(n):
     """Predict at batch sizes the fixture does not hold.  Only the first BatchNorm honours eval mode
@@ -166,6 +207,23 @@ def test_cpp_cli_train_one_epoch_runs_and_saves(tmp_path):
         assert len(a) == 2 and abs(a[0] - b[0]) <= 2e-4 * max(1.0, b[0]) and abs(a[1] - b[1]) < 1e-3, (key, a, b)
     cm = lambda out: out[out.index("Matriz de Confusi"):]
     assert cm(r.stdout) == cm(r2.stdout)
+    # The data-parallel driver with one rank (replica threads, gradient arena through an RCCL all-reduce, divisor
+    # ranks * batch_size) is the single-device run, byte for byte.
+    r3 = subprocess.run([exe, "bloodmnist", "train", "1"], env=dict(env, VTCNN_GPUS="1"), capture_output=True, text=True, timeout=110)
+    assert r3.returncode == 0, r3.stderr[-2000:]
+    assert ck.read_bytes() == first
+    assert numbers(r3.stdout, "Train Loss:") == numbers(r.stdout, "Train Loss:")
+    assert cm(r3.stdout) == cm(r.stdout)
+
+
+def test_dp_entry_points_sum_over_visible_gpus():
+    """cpp/build/dp_check: argument errors of vt_dp_init / vt_dp_allreduce_*, then an exact in-place sum over
+    every visible GPU through both the grouped call and one call per rank from separate host threads."""
+    exe = os.path.join(ROOT, "cpp", "build", "dp_check")
+    assert os.access(exe, os.X_OK)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=110)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    assert "GPU(s) OK" in r.stdout
 
 
 def test_predict_batch_8192_labels_vs_oracle():

@@ -187,6 +187,21 @@ def test_idx_decode_bit_exact(tmp_path):
     o2 = np.ones((2, 784), dtype=np.float32)
     assert lib.vt_idx_read_images(str(short).encode(), 2, o2.ctypes.data, C.byref(n), C.byref(r), C.byref(c)) == 0
     assert np.array_equal(o2[0], out[0]) and np.all(o2[1, 100:] == 0.0) and np.array_equal(o2[1, :100], out[1, :100])
+    # headers the reference's containers would refuse: negative count, negative side, pixel count beyond int
+    import struct
+    for hdr in (struct.pack(">iiii", 0x803, -5, 28, 28), struct.pack(">iiii", 0x803, 2, -28, 28),
+                struct.pack(">iiii", 0x803, 2, 65536, 65536), struct.pack(">ii", 0x803, 2)):
+        bad = tmp_path / "bad-idx3"
+        bad.write_bytes(hdr)
+        assert lib.vt_idx_read_images(str(bad).encode(), 0, None, C.byref(n), C.byref(r), C.byref(c)) == -5
+    badl = tmp_path / "bad-idx1"
+    badl.write_bytes(struct.pack(">ii", 0x801, -1))
+    assert lib.vt_idx_read_labels(str(badl).encode(), 0, None, C.byref(m)) == -5
+    # the magic number is not checked, as in the reference
+    odd = tmp_path / "odd-idx1"
+    odd.write_bytes(struct.pack(">ii", 0x1234, 3) + bytes([7, 8, 9]))
+    three = np.zeros(3, dtype=np.int32)
+    assert lib.vt_idx_read_labels(str(odd).encode(), 0, three.ctypes.data, C.byref(m)) == 0 and three.tolist() == [7, 8, 9]
 
 
 def test_layout_matches_python_mirror():
@@ -288,3 +303,28 @@ def test_cpp_tensor_operations_follow_the_reference_semantics():
         pytest.fail("cpp/build/tensor_ops_check is not built (run __graft_entry__.build())")
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_class_stats_against_an_independent_implementation():
+    """vit_amd.engine.class_stats (what evaluate_test prints after the loss line, utils/trainer.hpp:131-153): per
+    class precision / recall / F1 with 0 for empty denominators, macro means over the classes present among the
+    true labels, F1 weighted by their support; compared with scikit-learn on a matrix with an absent class and a
+    never-predicted class."""
+    from vit_amd.engine import class_stats
+    from sklearn.metrics import precision_recall_fscore_support as prfs
+    rng = np.random.default_rng(3)
+    k = 6
+    truth = rng.integers(0, k, size=400)
+    truth[truth == 4] = 1  # class 4 never occurs
+    pred = rng.integers(0, k, size=400)
+    pred[pred == 2] = 0   # class 2 is never predicted
+    cm = np.zeros((k, k), dtype=np.int64)
+    np.add.at(cm, (truth, pred), 1)
+    st = class_stats(cm)
+    p, r, f, sup = prfs(truth, pred, labels=list(range(k)), zero_division=0)
+    assert np.allclose(st["precision"], p, atol=1e-6) and np.allclose(st["recall"], r, atol=1e-6)
+    assert np.allclose(st["f1"], f, atol=1e-6)
+    present = sup > 0
+    assert abs(st["macro_f1"] - f[present].mean()) < 1e-6 and abs(st["macro_precision"] - p[present].mean()) < 1e-6
+    assert abs(st["macro_recall"] - r[present].mean()) < 1e-6
+    assert abs(st["weighted_f1"] - (f * sup).sum() / sup.sum()) < 1e-6

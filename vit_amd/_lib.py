@@ -42,6 +42,7 @@ SIGNATURES = {
     "vt_model_create": (i, [C.POINTER(VtDims), i, i, p, p, C.POINTER(p)]),
     "vt_model_destroy": (i, [p]),
     "vt_model_layout": (i, [p, C.POINTER(VtLayout)]),
+    "vt_model_is_fused": (i, [p]),
     "vt_model_init_seed": (i, [p, u]),
     "vt_model_set_arena": (i, [p, p]),
     "vt_model_get_arena": (i, [p, p]),
@@ -103,6 +104,12 @@ SIGNATURES = {
     "vt_head_bwd": (i, [p] * 11 + [i, i, i, p]),
     "vt_fc_wgrad": (i, [p] * 5 + [i, i, i, p]),
     "vt_fc_wgrad_static": (i, [p] * 4 + [i, i, i, p]),
+    "vt_dp_init": (i, [i, p, p]),
+    "vt_dp_destroy": (i, [p]),
+    "vt_dp_ranks": (i, [p]),
+    "vt_dp_allreduce_async": (i, [p, p, l, l, p]),
+    "vt_dp_allreduce_rank_async": (i, [p, i, p, l, l, p]),
+    "vt_dp_wait": (i, [p]),
     "vt_bn_bwd_finalize": (i, [p, i, i, l, p, p, p, p, p, p, p]),
     "vt_projector_bwd": (i, [p] * 13 + [i, i, p]),
     "vt_dense_bwd_rows": (i, [p, p, p, p, p, p, i, p, l, i, i, i, p]),

@@ -302,7 +302,8 @@ __global__ __launch_bounds__(TPB) void k_eval_accumulate(const float *__restrict
   __shared__ int sok;
   // workgroup = one mini-batch of the sweep: images [first, first + cnt)
   const int first = blockIdx.x * group, cnt = min(group, N - first);
-  for (int i = threadIdx.x; i < K * K; i += TPB) scm[i] = 0;
+  const bool staged = K <= KMAX;  // larger class counts add to the global matrix directly
+  for (int i = threadIdx.x; staged && i < K * K; i += TPB) scm[i] = 0;
   if (threadIdx.x == 0) sok = 0;
   __syncthreads();
   float part[1] = {0.f};
@@ -322,7 +323,10 @@ __global__ __launch_bounds__(TPB) void k_eval_accumulate(const float *__restrict
     if (argmax) argmax[n] = best;
     part[0] += -logf(probs[(size_t)n * K + truth] + 1e-8f);
     ok += best == truth ? 1 : 0;
-    if (truth >= 0 && truth < K) atomicAdd(&scm[truth * K + best], 1);  // integer add: order-independent
+    if (truth >= 0 && truth < K) {  // integer adds: order-independent
+      if (staged) atomicAdd(&scm[truth * K + best], 1);
+      else if (cm != nullptr) atomicAdd(&cm[(size_t)truth * K + best], 1);
+    }
   }
   atomicAdd(&sok, ok);
   block_sum<1>(part, red);
@@ -330,7 +334,7 @@ __global__ __launch_bounds__(TPB) void k_eval_accumulate(const float *__restrict
     loss_sums[slot0 + blockIdx.x] = part[0];
     correct[slot0 + blockIdx.x] = sok;
   }
-  if (cm != nullptr)
+  if (cm != nullptr && staged)
     for (int i = threadIdx.x; i < K * K; i += TPB)
       if (scm[i] != 0) atomicAdd(&cm[i], scm[i]);
 }
@@ -398,7 +402,7 @@ extern "C" int vt_loader_gather(const unsigned char *images_u8, const int *label
 
 extern "C" int vt_eval_accumulate_grouped(const float *probs, const int *labels, int N, int K, int group, int slot0,
                                           float *loss_sums, int *correct, int *confusion, int *argmax, vt_stream s) {
-  if (N < 1 || K < 1 || K > KMAX || group < 1 || slot0 < 0 || !probs || !labels || !loss_sums || !correct) return VT_EINVAL;
+  if (N < 1 || K < 1 || group < 1 || slot0 < 0 || !probs || !labels || !loss_sums || !correct) return VT_EINVAL;
   hipLaunchKernelGGL(k_eval_accumulate, dim3((N + group - 1) / group), dim3(TPB), 0, (hipStream_t)s, probs, labels, N, K,
                      group, slot0, loss_sums, correct, confusion, argmax);
   VT_CHECK_LAUNCH();

@@ -259,6 +259,7 @@ extern "C" int vt_model_destroy(vt_model *m) {
   return 0;
 }
 
+extern "C" int vt_model_is_fused(const vt_model *m) { return !m ? VT_EINVAL : (m->gen ? 0 : 1); }
 extern "C" int vt_model_layout(const vt_model *m, vt_layout *out) {
   if (!m || !out) return VT_EINVAL;
   *out = m->lo;
@@ -600,16 +601,26 @@ extern "C" int vt_idx_read_images(const char *path, int max_images, float *out, 
     return VT_EFORMAT;
   }
   if (max_images > 0 && max_images < num) num = max_images;  // load_dataset.hpp:37-38
+  // The magic number is read and ignored, as in the reference (:26-32).  Sizes that the reference's own
+  // containers would refuse (negative counts, a pixel count beyond int) are a format error here.
+  if (num < 0 || r < 0 || c < 0 || (long long)r * c > 0x7fffffffLL || (long long)num * r * c > (1LL << 40)) {
+    std::fclose(f);
+    return VT_EFORMAT;
+  }
   if (n) *n = num;
   if (rows) *rows = r;
   if (cols) *cols = c;
   int rc = 0;
   if (out) {
     const size_t total = (size_t)num * r * c;
-    std::vector<unsigned char> raw(total);
-    const size_t got = std::fread(raw.data(), 1, total, f);
-    // a short file leaves the remaining pixels at 0, as the reference's failed reads do (:48-50)
-    for (size_t i = 0; i < total; ++i) out[i] = static_cast<float>(i < got ? raw[i] : 0) / 255.0f;
+    try {
+      std::vector<unsigned char> raw(total);
+      const size_t got = std::fread(raw.data(), 1, total, f);
+      // a short file leaves the remaining pixels at 0, as the reference's failed reads do (:48-50)
+      for (size_t i = 0; i < total; ++i) out[i] = static_cast<float>(i < got ? raw[i] : 0) / 255.0f;
+    } catch (const std::bad_alloc &) {
+      rc = VT_ENOMEM;
+    }
   }
   std::fclose(f);
   return rc;
@@ -624,14 +635,23 @@ extern "C" int vt_idx_read_labels(const char *path, int max_labels, int *out, in
     return VT_EFORMAT;
   }
   if (max_labels > 0 && max_labels < num) num = max_labels;
+  if (num < 0) {
+    std::fclose(f);
+    return VT_EFORMAT;
+  }
   if (n) *n = num;
+  int rc = 0;
   if (out) {
-    std::vector<unsigned char> raw(num);
-    const size_t got = std::fread(raw.data(), 1, num, f);
-    for (int i = 0; i < num; ++i) out[i] = (size_t)i < got ? (int)raw[i] : 0;
+    try {
+      std::vector<unsigned char> raw(num);
+      const size_t got = std::fread(raw.data(), 1, num, f);
+      for (int i = 0; i < num; ++i) out[i] = (size_t)i < got ? (int)raw[i] : 0;
+    } catch (const std::bad_alloc &) {
+      rc = VT_ENOMEM;
+    }
   }
   std::fclose(f);
-  return 0;
+  return rc;
 }
 
 extern "C" int vt_loader_indices(int n, unsigned seed, int resets, int *out) {

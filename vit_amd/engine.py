@@ -71,6 +71,7 @@ class VTCNN:
                                       C.byref(self._h)), "vt_model_create")
         check(lib.vt_model_layout(self._h, C.byref(lo)), "vt_model_layout")
         self.layout = Layout(lo)
+        self.fused = lib.vt_model_is_fused(self._h) == 1  # headline shape: fused kernels; otherwise the general step
         self.training = True
         self._probs = torch.zeros(self.max_batch, self.dims.num_classes, dtype=torch.float32, device=self.device)
         self._n = 0
@@ -524,6 +525,38 @@ class DataLoader:
         return x, y
 
 
+def class_stats(cm):
+    """Tensor::precision_recall / f1_score (utils/tensor/tensor_cpu.hpp; printed by Trainer::evaluate_test,
+    utils/trainer.hpp:131-153) from a confusion matrix cm[truth][pred], in single precision as there: per-class
+    precision tp/column, recall tp/row (0 where the denominator is 0), F1 = 2pr/(p+r); macro means over the classes
+    that occur among the true labels; weighted F1 by the number of true samples of each class."""
+    cm = np.asarray(cm, dtype=np.int64)
+    k = cm.shape[0]
+    f = np.float32
+    precision, recall, f1 = np.zeros(k, f), np.zeros(k, f), np.zeros(k, f)
+    mp = mr = mf = wf = f(0)
+    present = total = 0
+    for c in range(k):
+        col, row, tp = int(cm[:, c].sum()), int(cm[c, :].sum()), f(cm[c, c])
+        if col > 0:
+            precision[c] = tp / f(col)
+        if row > 0:
+            recall[c] = tp / f(row)
+        if precision[c] + recall[c] > 0:
+            f1[c] = f(2) * (precision[c] * recall[c]) / (precision[c] + recall[c])
+        if row > 0:
+            mp, mr, mf = mp + precision[c], mr + recall[c], mf + f1[c]
+            wf = wf + f1[c] * f(row)
+            total += row
+            present += 1
+    if present > 0:
+        mp, mr, mf = mp / f(present), mr / f(present), mf / f(present)
+    if total > 0:
+        wf = wf / f(total)
+    return {"precision": precision, "recall": recall, "f1": f1, "macro_precision": float(mp), "macro_recall": float(mr),
+            "macro_f1": float(mf), "weighted_f1": float(wf)}
+
+
 class Trainer:
     """Trainer (utils/trainer.hpp:9-243): train / evaluate / evaluate_test / predict."""
 
@@ -544,7 +577,9 @@ class Trainer:
         self.model.set_training(False)
         b = 0
         bs = loader.batch_size
-        per_call = (self.model.max_batch // bs) if (bs % 4 == 0 and hasattr(loader, "next_batches")) else 0
+        # the grouped launch set exists for the fused headline kernels only; every other shape goes batch by batch
+        grouped = bs % 4 == 0 and hasattr(loader, "next_batches") and getattr(self.model, "fused", False)
+        per_call = (self.model.max_batch // bs) if grouped else 0
         if per_call >= 2:
             # whole chunks of loader batches per launch set (vt_model_forward_grouped): each batch
             # keeps its own BatchNorm1D statistics, as in the reference's batch-by-batch loop
@@ -620,6 +655,16 @@ class Trainer:
         self.out("[TEST] Final Evaluation — Loss: %.4f | Accuracy: %.4f%%" % (loss, acc * 100.0))
         k = self.num_classes
         cm = self._last_cm  # accumulated on the device, confusion[truth][pred]
+        st = class_stats(cm)
+        self.out(" - F1 Score (macro):    %.4f" % st["macro_f1"])
+        self.out(" - F1 Score (weighted): %.4f" % st["weighted_f1"])
+        self.out(" - Precision (macro):   %.4f" % st["macro_precision"])
+        self.out(" - Recall (macro):      %.4f" % st["macro_recall"])
+        self.out("\n📊 Per-Class Metrics:")
+        self.out("%8s%12s%12s%12s" % ("Class", "Precision", "Recall", "F1 Score"))
+        self.out("-" * 44)
+        for i_ in range(k):
+            self.out("%8d%12.4f%12.4f%12.4f" % (i_, st["precision"][i_], st["recall"][i_], st["f1"][i_]))
         self.out("\n🧩 Matriz de Confusión:\n    " + "".join("%4d" % j for j in range(k)))
         for i_ in range(k):
             self.out("%2d: " % i_ + "".join("%4d" % cm[i_, j] for j in range(k)))
