@@ -147,6 +147,13 @@ int vt_model_forward_grouped(vt_model *m, const float *d_images, int n, int grou
  * utils/optimizer.hpp:22-28):  g <- g * (1/divisor);  w <- w - g * lr  over the trainable region.
  * The reference always passes divisor = Trainer::batch_size = 32 (utils/trainer.hpp:53). */
 int vt_model_sgd_step(vt_model *m, float lr, float divisor, vt_stream s);
+/* One training iteration of Trainer::train (utils/trainer.hpp:41-53) in one call: vt_model_forward,
+ * vt_model_backward and vt_model_sgd_step with the same arguments, the same bytes in the arena and in
+ * d_probs afterwards, gradients cleared.  Knowing that the update follows, the headline-shape step applies it
+ * inside the launch that finishes the weight-gradient reductions (one launch fewer); a data-parallel caller,
+ * who must exchange gradients between backward and update, keeps the separate calls. */
+int vt_model_train_step(vt_model *m, const float *d_images, int n, const int *d_labels, float lr, float divisor,
+                        float *d_probs, vt_stream s);
 /* One fused Adam pass over the trainable region (g scaled by 1/divisor first, as update_weights
  * scales it; bias-corrected moments; gradients cleared), the moments kept by the model and the step
  * count advanced by every call.  The reference trains with SGD only (utils/optimizer.hpp:14-28):
@@ -339,6 +346,19 @@ int vt_head_bwd(const float *probs, const int *labels, const float *wfc, const u
 /* fc DenseLayer::backward weight/bias gradients (dense_layer.hpp:92-96): gW = pooled^T . d_logits. */
 int vt_fc_wgrad(const float *pooled, const float *d_logits, float *gw, float *gb, float *scratch, int N, int Q, int K,
                 vt_stream s);
+/* The same backward for 28x28 inputs (2x2 pooling) without the dense delta.  dpair [N, P*C2/2] receives one
+ * float per horizontally adjacent element pair (flat offsets F, F+1 with F even) of the [N,C2,H,W] view: 0, or,
+ * if the pair holds the arg-max element of its pooling window and the window's maximum was positive (ReLU
+ * active), the window's fc input delta with its lowest mantissa bit replaced by the arg-max column (0 = F,
+ * 1 = F+1).  du is that delta (bit cleared) at the arg-max element and zero elsewhere; vt_head_expand_windows
+ * forms it.  pooled = the window maxima kept by vt_head_fwd; z is read only for a channel whose gamma is exactly
+ * 0.  part receives vt_head_bwd_windows_blocks(N) records of [2][C2] partial sums (sum du, sum du*xhat), not
+ * one per image: pass that count to vt_bn_bwd_finalize. */
+int vt_head_bwd_windows_blocks(int N);
+int vt_head_bwd_windows(const float *probs, const int *labels, const float *wfc, const unsigned char *pool_idx,
+                        const float *pooled, const float *z, const float *pn_stat, const float *pn_gamma,
+                        const float *pn_beta, float *d_logits, float *dpair, float *part, int N, int H, int K, vt_stream s);
+int vt_head_expand_windows(const float *dpair, float *du, int N, int H, vt_stream s);
 /* vt_fc_wgrad without the scratch argument and without any allocation.  No counterpart in the
  * reference: it is for callers that cannot allocate device memory (code under HIP graph capture,
  * tight serving loops, harnesses that forbid hipMalloc).  The partial slab lives in a fixed device
@@ -360,6 +380,10 @@ int vt_bn_bwd_finalize(const float *part, int nblocks, int C, long rows_total, c
 int vt_projector_bwd(const float *du, const float *pn_coef, const float *conv_out, const float *bn_stat,
                      const float *bn_gamma, const float *bn_beta, const float *pk, const float *wq,
                      const float *wd, float *pdx, float *dv, float *dk, float *gslab, int N, int P, vt_stream s);
+/* vt_projector_bwd fed by vt_head_bwd_windows: dpair instead of du; P must be 784. */
+int vt_projector_bwd_windows(const float *dpair, const float *pn_coef, const float *conv_out, const float *bn_stat,
+                             const float *bn_gamma, const float *bn_beta, const float *pk, const float *wq,
+                             const float *wd, float *pdx, float *dv, float *dk, float *gslab, int N, int P, vt_stream s);
 /* ProjectorLayer::backward, token side (projector_layer.hpp:186-202): Dense backward of linear3
  * (values) and linear2 (keys) over the N*L token rows.  g_wk_wv_bv receives the contiguous
  * gradient block [proj.linear2.W | proj.linear3.W | proj.linear3.b]; pdt the token delta.

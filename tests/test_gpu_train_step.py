@@ -177,7 +177,8 @@ def test_train_step_vs_oracle_after_200_training_steps(n):
     orders of magnitude next to the activations they are differences of), and the reference's own fp32
     arithmetic then misses exact arithmetic by more than 1e-4 on them; each gradient tensor is therefore
     held to 1e-4 or to three times the distance of the fp32 oracle (the reference's arithmetic, same
-    decisions imposed) from the fp64 oracle, whichever is larger."""
+    decisions imposed) from the fp64 oracle, whichever is larger; that distance is taken as the largest over four
+    batches on the same weights, because a single batch is one noisy draw of it."""
     _step_vs_f64_oracle(n, 8, 1, 28, pretrain_steps=200)
 
 
@@ -225,6 +226,7 @@ def _step_vs_f64_oracle(n, k, ci, h, qk_factor=1.0, loose=None, pretrain_steps=0
     gg = m.get_grads()
     assert np.all(np.isfinite(gg))
     slots, mask = _routing_from_gpu(m, n)
+    inter = {name: m.read(name) for name in ("bwd.proj_dx", "bwd.proj_dt", "bwd.tr_ds2", "bwd.tr_dr", "bwd.tok_dx")}
     # part 1: forward floats and discrete decisions vs exact math (fp64 oracle, its own decisions)
     o = Oracle(make_dims(num_classes=k, image_channels=ci, input_dim=h), n, f64=True)
     arena64 = arena32.astype(np.float64)
@@ -251,9 +253,27 @@ def _step_vs_f64_oracle(n, k, ci, h, qk_factor=1.0, loose=None, pretrain_steps=0
         for name, (off, size, shape, kind) in m.layout.tensors.items():
             if kind == 0:
                 loose[name] = max(TOL, 3.0 * rel_err(g32[off:off + size], go[off:off + size]))
+        # One batch gives one draw of that distance, and on an ill-conditioned tensor (a gradient that is a small
+        # difference of large sums) draws scatter by an order of magnitude: three more batches on the same weights,
+        # each with the decisions the HIP path takes on it, and the largest distance seen is the yardstick.
+        o64b = Oracle(make_dims(num_classes=k, image_channels=ci, input_dim=h), n, f64=True)
+        for _ in range(3):
+            xe = (rng.integers(0, 256, size=(n, ci, h, h)).astype(np.float32) / np.float32(255.0))
+            ye = rng.integers(0, k, size=n).astype(np.int32)
+            m.set_arena(arena32)
+            m.forward(torch.from_numpy(xe).cuda())
+            m.backward(torch.from_numpy(ye).cuda())
+            se, me = _routing_from_gpu(m, n)
+            for oo, ar in ((o32, arena32), (o64b, arena64)):
+                oo.set_routing(se, me)
+                oo.forward(ar.copy(), xe, training=True)
+            g32e, g64e = o32.backward(arena32, ye), o64b.backward(arena64, ye)
+            for name, (off, size, shape, kind) in m.layout.tensors.items():
+                if kind == 0:
+                    loose[name] = max(loose[name], 3.0 * rel_err(g32e[off:off + size], g64e[off:off + size]))
     bad = []
-    for name in ("bwd.proj_dx", "bwd.proj_dt", "bwd.tr_ds2", "bwd.tr_dr", "bwd.tok_dx"):
-        e = rel_err(m.read(name), o.get(name))
+    for name in inter:
+        e = rel_err(inter[name], o.get(name))
         if not e < TOL:
             bad.append((name, e))
     for name, (off, size, shape, kind) in m.layout.tensors.items():
@@ -516,3 +536,24 @@ def test_adam_step_matches_textbook_recurrences():
         assert rel_err(got, w) < 1e-5, t
         assert not m.get_grads().any()
         w = got.astype(np.float64)  # follow the device weights so that only one step's rounding is compared
+
+
+@pytest.mark.parametrize("n", [32, 1024])
+def test_train_step_entry_point_is_bit_identical_to_three_calls(n):
+    """vt_model_train_step (forward + backward + SGD, the update applied inside the launch that finishes the weight
+    gradient reductions) against vt_model_forward / vt_model_backward / vt_model_sgd_step: same probabilities, same
+    arena and an all-zero gradient arena after each of three steps."""
+    import torch
+    from vit_amd import VTCNN, Dims
+    rng = np.random.default_rng(7 + n)
+    xs = [torch.from_numpy(rng.integers(0, 256, size=(n, 1, 28, 28)).astype(np.float32) / np.float32(255.0)).cuda() for _ in range(3)]
+    ys = [torch.from_numpy(rng.integers(0, 8, size=n).astype(np.int32)).cuda() for _ in range(3)]
+    a, b = (VTCNN(Dims(num_classes=8), max_batch=n, seed=42) for _ in range(2))
+    for x, y in zip(xs, ys):
+        pa = a.forward(x).clone()
+        a.backward(y)
+        a.update_weights(32.0)
+        pb = b.train_step(x, y, 32.0).clone()
+        assert torch.equal(pa, pb)
+        assert np.array_equal(a.get_arena(), b.get_arena())
+        assert not b.get_grads().any() and not a.get_grads().any()

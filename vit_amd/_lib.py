@@ -43,6 +43,7 @@ SIGNATURES = {
     "vt_model_destroy": (i, [p]),
     "vt_model_layout": (i, [p, C.POINTER(VtLayout)]),
     "vt_model_is_fused": (i, [p]),
+    "vt_model_train_step": (i, [p, p, i, p, C.c_float, C.c_float, p, p]),
     "vt_model_init_seed": (i, [p, u]),
     "vt_model_set_arena": (i, [p, p]),
     "vt_model_get_arena": (i, [p, p]),
@@ -112,6 +113,10 @@ SIGNATURES = {
     "vt_dp_wait": (i, [p]),
     "vt_bn_bwd_finalize": (i, [p, i, i, l, p, p, p, p, p, p, p]),
     "vt_projector_bwd": (i, [p] * 13 + [i, i, p]),
+    "vt_projector_bwd_windows": (i, [p] * 13 + [i, i, p]),
+    "vt_head_bwd_windows_blocks": (i, [i]),
+    "vt_head_bwd_windows": (i, [p] * 12 + [i, i, i, p]),
+    "vt_head_expand_windows": (i, [p, p, i, i, p]),
     "vt_dense_bwd_rows": (i, [p, p, p, p, p, p, i, p, l, i, i, i, p]),
     "vt_tokenizer_bwd": (i, [p] * 11 + [i, i, p]),
     "vt_conv3x3_wgrad": (i, [p, p, p, p, i, i, i, i, p]),

@@ -70,6 +70,69 @@ __global__ __launch_bounds__(1024) void k_reduce_multi(const ReduceBatch batch) 
   }
 }
 
+// k_reduce_multi whose results are consumed on the spot by the SGD update (k_sgd's arithmetic, gradients
+// cleared): a column that lands in the gradient arena gr[0, n) updates its weight instead of being stored,
+// and workgroups past the reduction jobs update the floats of the arena that no job produces (gradients
+// written directly by other kernels).  One launch instead of two at the end of a training step.
+__global__ __launch_bounds__(1024) void k_reduce_multi_sgd(const ReduceBatch batch, float *__restrict__ w,
+                                                           float *__restrict__ gr, int n, float lr, float inv_div) {
+  __shared__ float sh[16][65];
+  if ((int)blockIdx.x >= batch.blocks) {
+    const int i = ((int)blockIdx.x - batch.blocks) * 1024 + (int)threadIdx.x;
+    if (i >= n) return;
+    bool produced = false;
+#pragma unroll 1
+    for (int k = 0; k < batch.n; ++k) {
+      const long off = (long)i - (long)(batch.job[k].out - gr);
+      produced |= off >= 0 && off < batch.job[k].cols;
+    }
+    if (!produced) {
+      const float gs = __fmul_rn(gr[i], inv_div);
+      w[i] = __fsub_rn(w[i], __fmul_rn(gs, lr));
+      gr[i] = 0.f;
+    }
+    return;
+  }
+  int ji = 0;
+#pragma unroll 1
+  for (int k = 1; k < batch.n; ++k)
+    if ((int)blockIdx.x >= batch.job[k].first_block) ji = k;
+  const float *__restrict__ slab = batch.job[ji].slab;
+  const long rows = batch.job[ji].rows;
+  const int cols = batch.job[ji].cols, ld = batch.job[ji].ld;
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = ((int)blockIdx.x - batch.job[ji].first_block) * 64 + cl;
+  const long off = (long)(batch.job[ji].out - gr) + c;
+  const bool in_arena = off >= 0 && off < n;
+  float wv = 0.f;
+  if (rl == 0 && c < cols && in_arena) wv = w[off];  // its round trip runs under the reduction
+  float s = 0.f;
+  if (c < cols) {
+    long r = rl;
+    for (; r + 7 * 16 < rows; r += 8 * 16) {  // 8 independent loads in flight
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = slab[(r + 16 * k) * ld + c];
+      s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    }
+    for (; r < rows; r += 16) s += slab[r * ld + c];
+  }
+  sh[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0 && c < cols) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += sh[k][cl];
+    if (in_arena) {
+      const float gs = __fmul_rn(t, inv_div);
+      w[off] = __fsub_rn(wv, __fmul_rn(gs, lr));
+      batch.job[ji].out[c] = 0.f;
+    } else {
+      batch.job[ji].out[c] = t;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // BatchNorm backward reduction step (reference layers/batch_normalization_layer.hpp:187-199 and
 // 316-326).  From S1 = sum delta, S2 = sum delta*xhat per channel:
@@ -273,6 +336,16 @@ int vt::reduce_batch_flush(hipStream_t s) {
   g_reduce_batch = nullptr;
   if (!b || b->n == 0) return 0;
   hipLaunchKernelGGL(k_reduce_multi, dim3(b->blocks), dim3(1024), 0, s, *b);
+  VT_CHECK_LAUNCH();
+  return 0;
+}
+int vt::reduce_batch_flush_sgd(float *w, float *g, int n, float lr, float divisor, hipStream_t s) {
+  ReduceBatch *b = g_reduce_batch;
+  g_reduce_batch = nullptr;
+  if (n < 1 || divisor == 0.f) return VT_EINVAL;
+  static const ReduceBatch none{};
+  const ReduceBatch &rb = b ? *b : none;
+  hipLaunchKernelGGL(k_reduce_multi_sgd, dim3(rb.blocks + (n + 1023) / 1024), dim3(1024), 0, s, rb, w, g, n, lr, 1.0f / divisor);
   VT_CHECK_LAUNCH();
   return 0;
 }

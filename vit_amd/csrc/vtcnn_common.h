@@ -168,6 +168,9 @@ int reduce_rows(const float *slab, long rows, int cols, int ld, float *out, hipS
 void reduce_batch_begin(ReduceBatch *b);         // b must outlive the matching flush / abandon
 int reduce_batch_flush(hipStream_t s);           // launches the queued jobs and closes the batch
 void reduce_batch_abandon();                     // closes the batch without launching
+// flush whose reductions feed the SGD update of the whole trainable arena in the same launch (w, g: arena and
+// gradient arena of n floats; gradients end cleared)
+int reduce_batch_flush_sgd(float *w, float *g, int n, float lr, float divisor, hipStream_t s);
 // vt_sgd_update (gradients cleared) that leaves floats [hole_first, hole_first + hole_count) untouched
 int sgd_update_hole(float *w, float *g, int n, float lr, float divisor, int hole_first, int hole_count, hipStream_t s);
 

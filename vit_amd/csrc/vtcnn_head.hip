@@ -6,6 +6,8 @@
 // base, base+1, ..., base+W, ... of the image's record block, and the BatchNorm channel of a flat
 // offset F is F mod C2.  Both kernels work straight from global memory (no LDS staging), so many
 // workgroups fit per CU and latency is hidden by occupancy.
+#include <algorithm>
+
 #include "vtcnn_common.h"
 
 namespace vt {
@@ -279,6 +281,156 @@ __global__ __launch_bounds__(TPB) void k_head_bwd(const float *__restrict__ prob
   if (tid < 2 * C2) part[(size_t)n * 2 * C2 + tid] = s[tid];
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same backward for 2x2 pooling of 28x28 maps, without the dense delta: per pooling window only
+// the arg-max element can receive a delta, and the ReLU gate is known from the window maximum.  The delta
+// leaves as dpair [N, P*C2/2]: one float per horizontally adjacent element pair (flat offsets F, F+1, F even)
+// of the [N,C2,H,W] view, i.e. per window two entries, top row and bottom row: the entry of the row that
+// holds the arg-max carries the window's fc input delta with its lowest mantissa bit replaced by the arg-max
+// column (0 = left, 1 = right), the other entry is 0.  That is half the dense [N,P,C2] tensor, in the
+// order in which the projector backward walks pixel records, with nothing to look up.
+// Nothing is read from z either: the window maximum
+// mv kept by the forward pass is the post-ReLU value of the winning element, so that element was active
+// iff mv > 0 and its normalised input is x_hat = (mv - beta) / gamma (z is consulted only for a channel
+// whose gamma is exactly 0, where the BatchNorm output no longer determines x_hat).
+// Window-major: a thread owns one window f for a chunk of HW_NB images, so its fc weight row is loaded
+// once (one workgroup per image would stream the whole 100 KB matrix through every workgroup), the
+// loads and stores of a wave are 256 contiguous bytes per image, and the BatchNorm channel of the
+// window's four slots is fixed: the partial sums (sum d, sum d*x_hat) are four predicated accumulators
+// per thread, brought to channel order through LDS in a fixed order at the end.
+// part receives one [2][C2] record per workgroup (gridDim.x * gridDim.y of them).
+// ---------------------------------------------------------------------------------------------
+constexpr int HW_NB = 16;   // most images per workgroup
+constexpr int HW_RS = 16;   // LDS row stride of the per-thread channel bins
+constexpr int HW_B1 = TPB * HW_RS + 16;  // start of the second bin array: half the banks away from the first
+template <int K>
+__global__ __launch_bounds__(TPB) void k_head_bwd_win(const float *__restrict__ probs, const int *__restrict__ labels,
+                                                      const float *__restrict__ Wfc,
+                                                      const unsigned char *__restrict__ pool_idx,
+                                                      const float *__restrict__ pooled, const float *__restrict__ z,
+                                                      const float *__restrict__ st, const float *__restrict__ g,
+                                                      const float *__restrict__ b, float *__restrict__ dlogits,
+                                                      float *__restrict__ dpair, float *__restrict__ part, int N, int nb) {
+  constexpr int W = 28, P = 784, Q = C2 * 196;
+  __shared__ __attribute__((aligned(16))) float sbin[HW_B1 + TPB * HW_RS];  // [sum d | sum d*x_hat][thread][channel]
+  __shared__ float sred[8][2 * C2];
+  const int tid = threadIdx.x;
+  const int f = blockIdx.x * TPB + tid, fc = min(f, Q - 1);
+  const bool okf = f < Q;
+  const int n0 = blockIdx.y * nb, nn = min(nb, N - n0);
+  // every load of the workgroup is requested before anything waits: the window maxima and slot bytes of all its
+  // images (one trip to memory for the whole chunk) and the weight row
+  float mv[HW_NB];
+  int sl[HW_NB];
+#pragma unroll
+  for (int u = 0; u < HW_NB; ++u) {
+    const size_t o = (size_t)(n0 + min(u, nn - 1)) * Q + fc;
+    mv[u] = pooled[o];
+    sl[u] = pool_idx[o];
+  }
+  float w[K];
+  load_wrow<K>(Wfc, fc, w);
+  if (blockIdx.x == 0)
+    for (int idx = tid; idx < nn * K; idx += TPB) {
+      const int n = n0 + idx / K, k = idx % K;
+      dlogits[(size_t)n * K + k] = probs[(size_t)n * K + k] - (k == labels[n] ? 1.0f : 0.0f);
+    }
+  // the four elements of the window in the [N,C2,H,W] view and their BatchNorm channels (flat offset mod C2)
+  const int ch = fc / 196, ij = fc - ch * 196, i = ij / 14, jj = ij - i * 14;
+  const int F00 = ch * P + (2 * i) * W + 2 * jj;
+  int cq[4];
+  float gq4[4], bq4[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    cq[q] = (F00 + (q >> 1) * W + (q & 1)) & (C2 - 1);
+    gq4[q] = g[cq[q]];
+    bq4[q] = b[cq[q]];
+  }
+  // this thread's channel bins start at zero
+  {
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) *reinterpret_cast<float4 *>(&sbin[a * HW_B1 + tid * HW_RS + 4 * q]) = z4;
+  }
+  // per slot q: sum of the deltas routed to it and of delta * window maximum; x_hat = (mv - beta) / gamma turns the
+  // pair into sum d*x_hat after the loop
+  float ad[4] = {0.f, 0.f, 0.f, 0.f}, am[4] = {0.f, 0.f, 0.f, 0.f};
+  const int e_top = ch * (P / 2) + (2 * i) * (W / 2) + jj;  // pair index of the window's top row; bottom: + W/2
+#pragma unroll
+  for (int u = 0; u < HW_NB; ++u) {
+    if (u < nn) {  // uniform
+      const int n = n0 + u;
+      const int label = labels[n];  // uniform: scalar loads
+      float d = 0.f;
+#pragma unroll
+      for (int k = 0; k < K; ++k) d += (probs[(size_t)n * K + k] - (k == label ? 1.0f : 0.0f)) * w[k];
+      d = (okf && mv[u] > 0.f) ? d : 0.f;
+      if (okf) {
+        const float enc = __uint_as_float((__float_as_uint(d) & ~1u) | (unsigned)(sl[u] & 1));
+        float *dst = dpair + (size_t)n * (P * C2 / 2) + e_top;
+        dst[0] = (sl[u] >> 1) == 0 ? enc : 0.f;
+        dst[W / 2] = (sl[u] >> 1) == 1 ? enc : 0.f;
+      }
+      const float dm = d * mv[u];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const bool hit = sl[u] == q;
+        ad[q] += hit ? d : 0.f;
+        am[q] += hit ? dm : 0.f;
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int F = F00 + (q >> 1) * W + (q & 1), c = cq[q];
+    const float gq = gq4[q], bq = bq4[q];
+    float ax;
+    if (gq != 0.f) {
+      ax = (am[q] - bq * ad[q]) / gq;
+    } else {  // the BatchNorm output no longer determines x_hat: take it from z (never in practice)
+      ax = 0.f;
+      for (int u = 0; u < nn; ++u) {
+        const size_t o = (size_t)(n0 + u) * Q + fc;
+        if (okf && pool_idx[o] == q && pooled[o] > 0.f) {
+          float d = 0.f;
+          const int label = labels[n0 + u];
+          for (int k = 0; k < K; ++k) d += (probs[(size_t)(n0 + u) * K + k] - (k == label ? 1.0f : 0.0f)) * w[k];
+          ax += d * (z[(size_t)(n0 + u) * P * C2 + F] - st[c]) * st[C2 + c];
+        }
+      }
+    }
+    sbin[tid * HW_RS + c] = ad[q];  // the four channels of a window are distinct
+    sbin[HW_B1 + tid * HW_RS + c] = ax;
+  }
+  __syncthreads();
+  {
+    // thread = (channel c, which sum, eighth of the workgroup): 32 bins in a fixed order
+    const int c = tid & 15, which = (tid >> 4) & 1, e8 = tid >> 5;
+    const float *col = &sbin[which * HW_B1 + (e8 * 32) * HW_RS + c];
+    float sum = 0.f;
+#pragma unroll 8
+    for (int r = 0; r < 32; ++r) sum += col[r * HW_RS];
+    sred[e8][which * C2 + c] = sum;
+  }
+  __syncthreads();
+  if (tid < 2 * C2) {
+    float tot = 0.f;
+#pragma unroll
+    for (int e8 = 0; e8 < 8; ++e8) tot += sred[e8][tid];
+    part[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 * C2 + tid] = tot;
+  }
+}
+
+// dpair -> the dense [N,P,C2] delta (what k_head_bwd writes): for hosts and tests that want it
+__global__ __launch_bounds__(TPB) void k_head_expand_win(const float *__restrict__ dpair, float *__restrict__ du, long total) {
+  const long i = (long)blockIdx.x * TPB + threadIdx.x;
+  if (i >= total) return;
+  const unsigned bits = __float_as_uint(dpair[i >> 1]);
+  du[i] = (bits & 1u) == (unsigned)(i & 1) ? __uint_as_float(bits & ~1u) : 0.f;
+}
+
 }  // namespace vt
 
 using namespace vt;
@@ -335,6 +487,38 @@ extern "C" int vt_head_bwd(const float *probs, const int *labels, const float *w
 #define CALL(KK) launch_head_bwd<KK>(probs, labels, wfc, pool_idx, z, pn_stat, pn_gamma, pn_beta, d_logits, du, part, N, H, (hipStream_t)s)
   VT_FOR_K(CALL)
 #undef CALL
+  VT_CHECK_LAUNCH();
+  return 0;
+}
+
+// Images per workgroup and workgroups of k_head_bwd_win for a mini-batch of N: about 64 chunks of images at
+// most HW_NB long, times the 13 window blocks.
+static int head_win_chunk(int N) { return std::max(1, std::min(HW_NB, N / 64)); }
+extern "C" int vt_head_bwd_windows_blocks(int N) {
+  if (N < 1) return VT_EINVAL;
+  const int nb = head_win_chunk(N);
+  return ((C2 * 196 + TPB - 1) / TPB) * ((N + nb - 1) / nb);
+}
+extern "C" int vt_head_bwd_windows(const float *probs, const int *labels, const float *wfc, const unsigned char *pool_idx,
+                                   const float *pooled, const float *z, const float *pn_stat, const float *pn_gamma,
+                                   const float *pn_beta, float *d_logits, float *dpair, float *part, int N, int H, int K,
+                                   vt_stream s) {
+  if (N < 1 || H != 28 || K < 1 || K > KMAX) return VT_EUNSUPPORTED;
+  const int nb = head_win_chunk(N);
+  const dim3 grid((C2 * 196 + TPB - 1) / TPB, (N + nb - 1) / nb);
+#define CALL(KK)                                                                                                        \
+  hipLaunchKernelGGL(k_head_bwd_win<KK>, grid, dim3(TPB), 0, (hipStream_t)s, probs, labels, wfc, pool_idx, pooled, z, \
+                     pn_stat, pn_gamma, pn_beta, d_logits, dpair, part, N, nb)
+  VT_FOR_K(CALL)
+#undef CALL
+  VT_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int vt_head_expand_windows(const float *dpair, float *du, int N, int H, vt_stream s) {
+  if (N < 1 || H != 28) return VT_EUNSUPPORTED;
+  const long total = (long)N * 784 * C2;
+  hipLaunchKernelGGL(k_head_expand_win, dim3((unsigned)((total + TPB - 1) / TPB)), dim3(TPB), 0, (hipStream_t)s, dpair, du, total);
   VT_CHECK_LAUNCH();
   return 0;
 }

@@ -65,6 +65,8 @@ struct vt_model {
   const float *last_images = nullptr;
   float *last_probs = nullptr;  // where the last forward left the probabilities (the caller's buffer or m->probs)
   // backward workspace
+  float *dpair = nullptr;   // delta per element pair [N, P*C2/2]: what the head backward hands the projector on 28x28 inputs
+  bool du_windows = false;  // the last backward left dpair, not the dense du
   float *dlogits, *du, *pdx, *pdt, *dv, *dk, *d0, *ds2, *dh, *da, *dr, *dc, *dT0, *dy, *qkv, *gslab, *gslab_conv;
   float *sc_fc, *sc_pt, *sc_ffn, *sc_mha;  // partial-gradient slabs, one per launcher: they stay live until the fused reduction
   float *coef_pn, *coef_n2, *coef_n1, *coef_bn;
@@ -191,7 +193,9 @@ extern "C" int vt_model_create(const vt_dims *dims, int max_batch, int device, f
   rc |= dalloc(m, &pi, (N * Q + 3) / 4, "fwd.pool_idx");  // raw bytes, 4 slots per float word
   m->pool_idx = (unsigned char *)pi;
   const size_t nrb = (NL + RB - 1) / RB;
-  rc |= dalloc(m, &m->part, std::max(N, nrb) * 64);
+  // partial-sum records: one per image or row block, or the head backward's window-major count, which is not
+  // monotonic in the batch size (at most 13 * 128 workgroups for any batch up to N)
+  rc |= dalloc(m, &m->part, std::max<size_t>(std::max(N, nrb) * 64, std::min<size_t>(13 * N, 13 * 128) * 2 * C2));
   rc |= dalloc(m, &m->part_side, std::max(N, nrb) * 64);
   rc |= dalloc(m, &m->stat_bn, 2 * C1, "stat.bn");
   // one (mean, inv) record per statistics group: grouped forward runs up to maxN/4 groups
@@ -202,6 +206,7 @@ extern "C" int vt_model_create(const vt_dims *dims, int max_batch, int device, f
   rc |= dalloc(m, &m->batch_mv, max_groups * 2 * D);
   rc |= dalloc(m, &m->dlogits, N * K, "bwd.d_logits");
   rc |= dalloc(m, &m->du, N * P * C2, "bwd.du");
+  rc |= dalloc(m, &m->dpair, N * P * C2 / 2, "bwd.dpair");
   rc |= dalloc(m, &m->pdx, N * P * C1, "bwd.proj_dx");
   rc |= dalloc(m, &m->pdt, NL * D, "bwd.proj_dt");
   rc |= dalloc(m, &m->dv, NL * C2, "bwd.proj_dv");
@@ -937,13 +942,30 @@ static int backward_main(vt_model *m, const int *d_labels, vt_stream s) {
   const bool fork = m->concurrent && m->side != nullptr;
   const vt_stream t = fork ? (vt_stream)m->side : s;
   // head: softmax/fc/pool/relu backward + projector BatchNorm1D backward sums
-  STEP("head_bwd", vt_head_bwd(m->last_probs, d_labels, m->P_("fc.W"), m->pool_idx, m->z, m->stat_pn, m->P_("proj.norm.gamma"),
-                    m->P_("proj.norm.beta"), m->dlogits, m->du, m->part, n, H, K, s));
-  STEP("bn_bwd_finalize", vt_bn_bwd_finalize(m->part, n, C2, (long)n * P, m->P_("proj.norm.gamma"), m->stat_pn, m->z,
+  // On 28x28 inputs (2x2 pooling) the delta between the two is one float per element pair, not the dense [N,P,C2]
+  // tensor, three quarters of which are zeros.
+  static const bool dense_delta = [] {  // measurement aid: VT_HEAD_DENSE=1 keeps the dense [N,P,C2] delta on every input size
+    const char *e = getenv("VT_HEAD_DENSE");
+    return e && *e && *e != '0';
+  }();
+  const bool windows = H == 28 && !dense_delta;
+  m->du_windows = windows;
+  if (windows)
+    STEP("head_bwd", vt_head_bwd_windows(m->last_probs, d_labels, m->P_("fc.W"), m->pool_idx, m->pooled, m->z, m->stat_pn,
+                      m->P_("proj.norm.gamma"), m->P_("proj.norm.beta"), m->dlogits, m->dpair, m->part, n, H, K, s));
+  else
+    STEP("head_bwd", vt_head_bwd(m->last_probs, d_labels, m->P_("fc.W"), m->pool_idx, m->z, m->stat_pn, m->P_("proj.norm.gamma"),
+                      m->P_("proj.norm.beta"), m->dlogits, m->du, m->part, n, H, K, s));
+  STEP("bn_bwd_finalize", vt_bn_bwd_finalize(m->part, windows ? vt_head_bwd_windows_blocks(n) : n, C2, (long)n * P, m->P_("proj.norm.gamma"), m->stat_pn, m->z,
                            m->G_("proj.norm.gamma"), m->G_("proj.norm.beta"), m->coef_pn, s));
   // projector
-  STEP("projector_bwd", vt_projector_bwd(m->du, m->coef_pn, m->conv, m->stat_bn, m->P_("bn.gamma"), m->P_("bn.beta"), m->pk,
-                         m->P_("proj.linear1.W"), m->P_("proj.downsample.W"), m->pdx, m->dv, m->dk, m->gslab, n, P, s));
+  if (windows)
+    STEP("projector_bwd", vt_projector_bwd_windows(m->dpair, m->coef_pn, m->conv, m->stat_bn, m->P_("bn.gamma"),
+                           m->P_("bn.beta"), m->pk, m->P_("proj.linear1.W"), m->P_("proj.downsample.W"), m->pdx, m->dv, m->dk,
+                           m->gslab, n, P, s));
+  else
+    STEP("projector_bwd", vt_projector_bwd(m->du, m->coef_pn, m->conv, m->stat_bn, m->P_("bn.gamma"), m->P_("bn.beta"), m->pk,
+                           m->P_("proj.linear1.W"), m->P_("proj.downsample.W"), m->pdx, m->dv, m->dk, m->gslab, n, P, s));
   VTCHK(vt_reduce_rows(m->gslab, n, C1 * D, 400, m->G_("proj.linear1.W"), s));  // queued
   VTCHK(vt_reduce_rows(m->gslab + C1 * D, n, C1 * C2 + C2, 400, m->G_("proj.downsample.W"), s));
   // projector token side + transformer step a (targets = projector token delta, same bytes:
@@ -1030,6 +1052,24 @@ extern "C" int vt_model_backward(vt_model *m, const int *d_labels, vt_stream s) 
     m->attn_update_pending = true;
     m->attn_tok_parity = m->tok_parity;
   }
+  return 0;
+}
+
+extern "C" int vt_model_train_step(vt_model *m, const float *d_images, int n, const int *d_labels, float lr, float divisor,
+                                   float *d_probs, vt_stream s) {
+  if (!m || !d_labels || divisor == 0.f) return VT_EINVAL;
+  VTCHK(forward_impl(m, d_images, n, 0, d_probs, s));
+  if (m->gen || m->defer_attn) {  // no queued reductions to fold the update into / the attention update trails
+    VTCHK(vt_model_backward(m, d_labels, s));
+    return vt_model_sgd_step(m, lr, divisor, s);
+  }
+  VTCHK(attention_join(m, (hipStream_t)s));
+  BatchScope batch(m);
+  VTCHK(backward_main(m, d_labels, s));
+  VTCHK(backward_attention(m, nullptr, s));
+  VTCHK(join_side(m, s));
+  STEP("reduce_rows_sgd", reduce_batch_flush_sgd(m->arena, m->grads, m->lo.n_trainable, lr, divisor, (hipStream_t)s));
+  m->attention_pending = false;
   return 0;
 }
 
@@ -1165,6 +1205,11 @@ extern "C" long vt_model_read(vt_model *m, const char *name, float *host, long c
   if (!dg.ok || quiesce(m) != 0) return VT_EINVAL;
   const float *src = it->second.first;
   if (src == m->probs && m->last_probs) src = m->last_probs;
+  if (src == m->du && m->du_windows && m->lastN > 0) {  // the dense delta is only formed on request
+    if (vt_head_expand_windows(m->dpair, m->du, m->lastN, m->d.input_dim, nullptr) != 0 ||
+        hipDeviceSynchronize() != hipSuccess)
+      return VT_EINVAL;
+  }
   if (hipMemcpy(host, src, cnt * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return VT_EINVAL;
   return cnt;
 }

@@ -278,6 +278,10 @@ __global__ __launch_bounds__(TPB) void k_proj_fwd(const float *__restrict__ conv
 constexpr int GS_STRIDE = C1 * D + C1 * C2 + C2;  // 400
 constexpr int PB_RS = 60;                          // LDS row stride of the transposition patch
 constexpr int PB_X = 0, PB_A = 8, PB_DZ = 24, PB_DS = 40;
+// WIN: du is not the dense [N,P,C2] delta but one float per horizontally adjacent element pair, [N, P*C2/2]
+// (k_head_bwd_win): zero, or the delta of the pair's pooling window with the arg-max column in its lowest
+// mantissa bit.  A thread's four elements 4g..4g+3 of a pixel record are two such pairs, one 8-byte load.
+template <bool WIN>
 __global__ __launch_bounds__(TPB) void k_proj_bwd(const float *__restrict__ du, const float *__restrict__ coef,
                                                   const float *__restrict__ conv, const float *__restrict__ st,
                                                   const float *__restrict__ g, const float *__restrict__ b,
@@ -312,16 +316,43 @@ __global__ __launch_bounds__(TPB) void k_proj_bwd(const float *__restrict__ du, 
   f4 accG = {0.f, 0.f, 0.f, 0.f}, accW = accG, accV = accG;
   float *pt = patch[wave];
   const int ntiles = (P + 15) >> 4;
+  // The operands of a tile are requested one trip ahead (the loads of tile t + NW are in flight during the
+  // arithmetic of tile t); rows past the image re-read the last pixel and are masked where they are used.
+  struct Fetch {
+    float2 raw;
+    f4 u;       // dense delta (WIN == false)
+    float2 e2;  // the two pair entries (WIN == true)
+  };
+  auto fetch = [&](int t) {
+    Fetch f;
+    const int p = min(t * 16 + j, P - 1);
+    f.raw = *reinterpret_cast<const float2 *>(conv + ((size_t)n * P + p) * C1 + 2 * gq);
+    if (WIN) f.e2 = *reinterpret_cast<const float2 *>(du + ((size_t)n * P + p) * (C2 / 2) + 2 * gq);
+    else f.u = *reinterpret_cast<const f4 *>(du + ((size_t)n * P + p) * C2 + 4 * gq);
+    return f;
+  };
+  Fetch nxt = fetch(wave);
   for (int t = wave; t < ntiles; t += NW) {
     const int p = t * 16 + j;
     const bool ok = p < P;
+    const Fetch cur = nxt;
+    if (t + NW < ntiles) nxt = fetch(t + NW);
     float x0 = 0.f, x1 = 0.f;
     f4 dz = {0.f, 0.f, 0.f, 0.f};
     if (ok) {
-      const float2 raw = *reinterpret_cast<const float2 *>(conv + ((size_t)n * P + p) * C1 + 2 * gq);
-      const f4 u = *reinterpret_cast<const f4 *>(du + ((size_t)n * P + p) * C2 + 4 * gq);
-      x0 = bn.apply(raw.x, 0);
-      x1 = bn.apply(raw.y, 1);
+      f4 u;
+      if (WIN) {
+        const unsigned b0 = __float_as_uint(cur.e2.x), b1 = __float_as_uint(cur.e2.y);
+        const float v0 = __uint_as_float(b0 & ~1u), v1 = __uint_as_float(b1 & ~1u);
+        u[0] = (b0 & 1u) ? 0.f : v0;
+        u[1] = (b0 & 1u) ? v0 : 0.f;
+        u[2] = (b1 & 1u) ? 0.f : v1;
+        u[3] = (b1 & 1u) ? v1 : 0.f;
+      } else {
+        u = cur.u;
+      }
+      x0 = bn.apply(cur.raw.x, 0);
+      x1 = bn.apply(cur.raw.y, 1);
 #pragma unroll
       for (int v = 0; v < 4; ++v) dz[v] = u[v] * cf0[v] + cf1[v];
     }
@@ -849,7 +880,18 @@ extern "C" int vt_projector_bwd(const float *du, const float *pn_coef, const flo
                                 const float *wd, float *pdx, float *dv, float *dk, float *gslab, int N, int P,
                                 vt_stream s) {
   if (N < 1 || P < 1) return VT_EUNSUPPORTED;
-  hipLaunchKernelGGL(k_proj_bwd, dim3(N), dim3(TPB), 0, (hipStream_t)s, du, pn_coef, conv_out, bn_stat, bn_gamma,
+  hipLaunchKernelGGL(k_proj_bwd<false>, dim3(N), dim3(TPB), 0, (hipStream_t)s, du, pn_coef, conv_out, bn_stat, bn_gamma,
+                     bn_beta, pk, wq, wd, pdx, dv, dk, gslab, P);
+  VT_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int vt_projector_bwd_windows(const float *dpair, const float *pn_coef, const float *conv_out,
+                                        const float *bn_stat, const float *bn_gamma, const float *bn_beta, const float *pk,
+                                        const float *wq, const float *wd, float *pdx, float *dv, float *dk, float *gslab,
+                                        int N, int P, vt_stream s) {
+  if (N < 1 || P != 784) return VT_EUNSUPPORTED;
+  hipLaunchKernelGGL(k_proj_bwd<true>, dim3(N), dim3(TPB), 0, (hipStream_t)s, dpair, pn_coef, conv_out, bn_stat, bn_gamma,
                      bn_beta, pk, wq, wd, pdx, dv, dk, gslab, P);
   VT_CHECK_LAUNCH();
   return 0;

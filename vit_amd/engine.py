@@ -131,6 +131,24 @@ class VTCNN:
                                    _stream_handle(self.device)), "vt_model_forward")
         return self._probs[:n]
 
+    def train_step(self, x, labels, batch_size=32.0):
+        """forward + backward + update_weights in one call (vt_model_train_step): the same bytes as the three
+        calls, one launch fewer on the headline shape.  Returns the softmax probabilities [N,K]."""
+        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+        assert labels.is_cuda and labels.dtype == torch.int32 and labels.is_contiguous()
+        n = x.shape[0]
+        d = self.dims
+        if tuple(x.shape[1:]) != (d.image_channels, d.input_dim, d.input_dim) or labels.numel() != n:
+            raise ValueError("input shape %s / labels %s do not match the model" % (tuple(x.shape), tuple(labels.shape)))
+        if n < 1 or n > self.max_batch:
+            raise ValueError("batch %d outside [1, max_batch=%d]" % (n, self.max_batch))
+        self._n = n
+        self._x = x
+        check(lib.vt_model_train_step(self._h, C.c_void_p(x.data_ptr()), n, C.c_void_p(labels.data_ptr()), self.lr,
+                                      float(batch_size), C.c_void_p(self._probs.data_ptr()), _stream_handle(self.device)),
+              "vt_model_train_step")
+        return self._probs[:n]
+
     def forward_grouped(self, x, group):
         """Eval-mode forward of consecutive mini-batches of `group` images in one launch set;
         equal to forward() on each batch up to rounding of the statistics (vt_model_forward_grouped)."""
