@@ -81,14 +81,14 @@ SHAPES = {  # hyper-parameters besides the class count
 LAUNCHER_KERNEL = {  # launcher name (vt_model_profile) -> device kernel it launches
     "conv3x3_fwd": "k_conv_fwd", "tokenizer_fwd": "k_tokenizer_fwd", "transformer_ffn_fwd": "k_tr_ffn_fwd",
     "projector_tokens_fwd": "k_proj_tokens_fwd", "projector_fwd": "k_proj_fwd", "head_fwd": "k_head_fwd",
-    "head_bwd": "k_head_bwd", "projector_bwd": "k_proj_bwd", "transformer_bwd_b": "k_tr_bwd_b",
+    "head_bwd": "k_head_bwd_win", "projector_bwd": "k_proj_bwd", "transformer_bwd_b": "k_tr_bwd_b",
     "tokenizer_bwd": "k_tokenizer_bwd", "conv3x3_wgrad": "k_conv_wgrad", "mha_bwd_rows": "k_mha_rows",
 }
 
 
 def measured_traffic(launcher, batch, classes):
     """HBM bytes per launch of the launcher's kernel from the committed PMC passes
-    (profiles/r01_hbm_traffic_b1024_k8.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+    (profiles/r02_hbm_traffic_b1024_k8.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
     runs of this same command, 2*FETCH_SIZE + WRITE_SIZE as the gfx950 notes prescribe).  Only
     valid for the configuration it was measured on; None otherwise."""
     t = measured_traffic_table(batch, classes)
