@@ -212,8 +212,14 @@ class VTCNN : public Model {
   // arrays (utils/trainer.hpp:39-58).  Nothing is copied to the host and nothing waits.
   void train_batch_resident(const unsigned char *d_images_u8, const int *d_all_labels, const int *d_indices, int n,
                             float batch_size, int slot, float *d_loss_sums, int *d_correct) {
-    gradients_resident(d_images_u8, d_all_labels, d_indices, n, slot, d_loss_sums, d_correct);
-    check(vt_model_sgd_step(h_, lr_, batch_size, stream_), "update_weights");
+    const int pixels = dims_.image_channels * dims_.input_dim * dims_.input_dim;
+    check(vt_loader_gather(d_images_u8, d_all_labels, d_indices, n, pixels, d_in_, d_labels_, stream_), "vt_loader_gather");
+    // forward + backward + update in one call (the update rides in the step's last launch); the probabilities stay
+    // in d_probs_ for the bookkeeping below
+    check(vt_model_train_step(h_, d_in_, n, d_labels_, lr_, batch_size, d_probs_, stream_), "VTCNN::train_step");
+    check(vt_eval_accumulate(d_probs_, d_labels_, n, dims_.num_classes, slot, d_loss_sums, d_correct, nullptr, nullptr, stream_),
+          "vt_eval_accumulate");
+    last_n_ = n;
   }
   // the same iteration up to and including backward: the summed gradients of the batch stay in the gradient arena
   // (a data-parallel caller exchanges them before update_weights)
