@@ -187,6 +187,7 @@ def main():
                     help="1: the attention block's backward and weight update run on a stream of their own "
                          "beside the next step's forward, which never reads those weights (same bytes; "
                          "vt_model_set_deferred_attention); only without a gradient exchange (one GPU)")
+    ap.add_argument("--fused-reductions", type=int, default=-1, help="BatchNorm reductions closed inside their producer kernels: 1 / 0, default: the library's choice")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel", default=None, help="launcher to time with HIP events (default: the slowest)")
     a = ap.parse_args()
@@ -213,6 +214,8 @@ def main():
     if a.bf16:
         m.set_matmul_precision(True)
     m.set_concurrency(bool(a.concurrent))
+    if a.fused_reductions >= 0 and not generic:
+        m.set_fused_reductions(bool(a.fused_reductions))
     deferred = bool(a.defer_attention) and world == 1 and not generic and not a.exchange_alone and a.mode == "train"
     if deferred:
         m.set_deferred_attention(True)

@@ -102,6 +102,17 @@ int vt_model_set_matmul_precision(vt_model *m, int bf16);
  * caller's stream.  General-shape models ignore it.  No counterpart in the reference. */
 int vt_model_set_concurrency(vt_model *m, int on);
 
+/* Where the eight mini-batch-wide BatchNorm reductions of a headline-shape training step are closed (four
+ * forward statistics, batch_normalization_layer.hpp:152-168, four backward reductions, :187-199 / 316-326).
+ * on == 0 (the default): by vt_bn_stats_finalize / vt_bn_bwd_finalize launches.  on != 0: inside the kernel that
+ * produces their partial sums, by its last workgroup to finish (write-through partial records, a sharded
+ * arrival counter, one acquire; no workgroup waits for another), which removes eight dependent launches per
+ * step.  Measured on MI355X the arrival protocol costs what the launches cost (batch 32: 150 vs 152 us per
+ * step; batch 1024: 292 vs 270 us), hence the default.  The two orders of summation differ in the last bits
+ * (both sum in double precision); each is deterministic.  Grouped evaluation sweeps always use the launches.
+ * General-shape models accept only 0.  No counterpart in the reference. */
+int vt_model_set_fused_reductions(vt_model *m, int on);
+
 /* Deferred attention backward (headline shape; no counterpart in the reference).  on != 0: vt_model_backward
  * issues the attention block's backward (MultiHeadAttention::backward's q/k/v weight gradients,
  * layers/multi_head_attention.hpp:109-181) on a stream of the model's own instead of the caller's, and

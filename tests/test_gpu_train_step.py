@@ -557,3 +557,38 @@ def test_train_step_entry_point_is_bit_identical_to_three_calls(n):
         assert torch.equal(pa, pb)
         assert np.array_equal(a.get_arena(), b.get_arena())
         assert not b.get_grads().any() and not a.get_grads().any()
+
+
+@pytest.mark.parametrize("n", [1, 5, 32, 200, 1024])
+def test_reductions_closed_in_kernel_match_the_finalize_launches(n):
+    """The BatchNorm reductions closed by the last workgroup of their producer kernels (opt-in) against the same
+    step with the separate finalize launches (default): statistics, gradients and updated weights agree to rounding of the
+    double-precision sums (1e-6), over three steps; and two runs of the in-kernel form are bit-identical (the
+    result does not depend on which workgroup finishes last)."""
+    import torch
+    from vit_amd import VTCNN, Dims
+    rng = np.random.default_rng(11 + n)
+    xs = [torch.from_numpy(rng.integers(0, 256, size=(n, 1, 28, 28)).astype(np.float32) / np.float32(255.0)).cuda() for _ in range(3)]
+    ys = [torch.from_numpy(rng.integers(0, 8, size=n).astype(np.int32)).cuda() for _ in range(3)]
+    a, b, c = (VTCNN(Dims(num_classes=8), max_batch=n, seed=42) for _ in range(3))
+    a.set_fused_reductions(True)
+    b.set_fused_reductions(True)
+    for x, y in zip(xs, ys):
+        outs = []
+        for m in (a, b, c):
+            p = m.forward(x).cpu().numpy().copy()
+            m.backward(y)
+            g = m.get_grads().copy()
+            st = [m.read(k)[:w] for k, w in (("stat.bn", 16), ("stat.norm1", 64), ("stat.norm2", 64), ("stat.proj.norm", 32))]
+            m.update_weights(32.0)
+            outs.append((p, g, st, m.get_arena().copy()))
+        assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][3], outs[1][3])
+        assert rel_err(outs[0][0], outs[2][0]) < 1e-5
+        for sa, sc in zip(outs[0][2], outs[2][2]):
+            assert rel_err(sa, sc) < 1e-6
+        nt = a.layout.n_trainable
+        for name, (off, size, shape, kind) in a.layout.tensors.items():
+            if kind == 0 and np.abs(outs[2][1][off:off + size]).max() > 0:
+                assert rel_err(outs[0][1][off:off + size], outs[2][1][off:off + size]) < 2e-4, name
+        assert rel_err(outs[0][3][:nt], outs[2][3][:nt]) < 1e-6
+

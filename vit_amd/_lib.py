@@ -43,6 +43,7 @@ SIGNATURES = {
     "vt_model_destroy": (i, [p]),
     "vt_model_layout": (i, [p, C.POINTER(VtLayout)]),
     "vt_model_is_fused": (i, [p]),
+    "vt_model_set_fused_reductions": (i, [p, i]),
     "vt_model_train_step": (i, [p, p, i, p, C.c_float, C.c_float, p, p]),
     "vt_model_init_seed": (i, [p, u]),
     "vt_model_set_arena": (i, [p, p]),

@@ -8,6 +8,7 @@
 // HBM layout: feature maps [N,P,C] channel-innermost (one 32-byte / 64-byte record per pixel,
 // fully coalesced per wave), token matrices [N*L, D].
 #include "vtcnn_common.h"
+#include "vtcnn_tail.h"
 
 namespace vt {
 
@@ -21,7 +22,7 @@ namespace vt {
 __global__ __launch_bounds__(TPB) void k_conv_fwd(const float *__restrict__ X, const float *__restrict__ Wc,
                                                   const float *__restrict__ bc, float *__restrict__ conv,
                                                   float *__restrict__ part, int Ci, int H, int W, unsigned w_magic,
-                                                  unsigned tw_magic) {
+                                                  unsigned tw_magic, const BnFwdTail tail) {
   extern __shared__ float sm[];
   const int P = H * W, TH = H + 2, TW = W + 2, plane = TH * TW;
   const int tile_n = Ci * plane;
@@ -109,10 +110,18 @@ __global__ __launch_bounds__(TPB) void k_conv_fwd(const float *__restrict__ X, c
     m2[co] = q;
   }
   block_sum<C1>(m2, red);
-  if (tid < C1) {
-    part[(size_t)n * 2 * C1 + tid] = s[tid];
-    part[(size_t)n * 2 * C1 + C1 + tid] = m2[tid];
+  if (tail.ticket == nullptr) {
+    if (tid < C1) {
+      part[(size_t)n * 2 * C1 + tid] = s[tid];
+      part[(size_t)n * 2 * C1 + C1 + tid] = m2[tid];
+    }
+    return;
   }
+  if (tid < C1) {
+    tail_store(part + (size_t)n * 2 * C1 + tid, s[tid]);
+    tail_store(part + (size_t)n * 2 * C1 + C1 + tid, m2[tid]);
+  }
+  bn_fwd_tail(tail, part, n, gridDim.x, C1);  // the last workgroup closes the BatchNorm2D statistics
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -346,15 +355,20 @@ __global__ __launch_bounds__(TPB) void k_eval_accumulate(const float *__restrict
 // ---------------------------------------------------------------------------------------------
 using namespace vt;
 
-extern "C" int vt_conv3x3_fwd(const float *x, const float *w, const float *b, float *conv_out, float *part, int N, int Ci,
-                              int H, int W, vt_stream s) {
+int vt::conv3x3_fwd_tail(const float *x, const float *w, const float *b, float *conv_out, float *part, int N, int Ci, int H,
+                         int W, const BnFwdTail &tail, hipStream_t s) {
   if (N < 1 || Ci < 1 || H * W > PPT * TPB || H < 1 || W < 1) return VT_EUNSUPPORTED;
   const size_t lds = (size_t)(((Ci * (H + 2) * (W + 2) + 3) & ~3) + NW * C1) * sizeof(float);
-  if (lds > 64 * 1024) return VT_EUNSUPPORTED;
-  hipLaunchKernelGGL(k_conv_fwd, dim3(N), dim3(TPB), lds, (hipStream_t)s, x, w, b, conv_out, part, Ci, H, W,
-                     (unsigned)(0x100000000ull / (unsigned)W + 1), (unsigned)(0x100000000ull / (unsigned)(W + 2) + 1));
+  if (lds > 56 * 1024) return VT_EUNSUPPORTED;  // the closing step adds static LDS of its own
+  hipLaunchKernelGGL(k_conv_fwd, dim3(N), dim3(TPB), lds, s, x, w, b, conv_out, part, Ci, H, W,
+                     (unsigned)(0x100000000ull / (unsigned)W + 1), (unsigned)(0x100000000ull / (unsigned)(W + 2) + 1),
+                     part ? tail : BnFwdTail{});
   VT_CHECK_LAUNCH();
   return 0;
+}
+extern "C" int vt_conv3x3_fwd(const float *x, const float *w, const float *b, float *conv_out, float *part, int N, int Ci,
+                              int H, int W, vt_stream s) {
+  return conv3x3_fwd_tail(x, w, b, conv_out, part, N, Ci, H, W, BnFwdTail{}, (hipStream_t)s);
 }
 
 extern "C" int vt_bn_stats_finalize(const float *part, int nblocks, int C, long rows_per_block, long rows_total,

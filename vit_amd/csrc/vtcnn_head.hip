@@ -9,6 +9,7 @@
 #include <algorithm>
 
 #include "vtcnn_common.h"
+#include "vtcnn_tail.h"
 
 namespace vt {
 
@@ -310,7 +311,8 @@ __global__ __launch_bounds__(TPB) void k_head_bwd_win(const float *__restrict__ 
                                                       const float *__restrict__ pooled, const float *__restrict__ z,
                                                       const float *__restrict__ st, const float *__restrict__ g,
                                                       const float *__restrict__ b, float *__restrict__ dlogits,
-                                                      float *__restrict__ dpair, float *__restrict__ part, int N, int nb) {
+                                                      float *__restrict__ dpair, float *__restrict__ part, int N, int nb,
+                                                      const BnBwdTail tail) {
   constexpr int W = 28, P = 784, Q = C2 * 196;
   __shared__ __attribute__((aligned(16))) float sbin[HW_B1 + TPB * HW_RS];  // [sum d | sum d*x_hat][thread][channel]
   __shared__ float sred[8][2 * C2];
@@ -419,8 +421,12 @@ __global__ __launch_bounds__(TPB) void k_head_bwd_win(const float *__restrict__ 
     float tot = 0.f;
 #pragma unroll
     for (int e8 = 0; e8 < 8; ++e8) tot += sred[e8][tid];
-    part[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 * C2 + tid] = tot;
+    float *dst = part + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 * C2 + tid;
+    if (tail.ticket == nullptr) *dst = tot;
+    else tail_store(dst, tot);
   }
+  // the last workgroup closes the projector BatchNorm1D backward reduction
+  bn_bwd_tail(tail, part, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, C2);
 }
 
 // dpair -> the dense [N,P,C2] delta (what k_head_bwd writes): for hosts and tests that want it
@@ -499,20 +505,27 @@ extern "C" int vt_head_bwd_windows_blocks(int N) {
   const int nb = head_win_chunk(N);
   return ((C2 * 196 + TPB - 1) / TPB) * ((N + nb - 1) / nb);
 }
-extern "C" int vt_head_bwd_windows(const float *probs, const int *labels, const float *wfc, const unsigned char *pool_idx,
-                                   const float *pooled, const float *z, const float *pn_stat, const float *pn_gamma,
-                                   const float *pn_beta, float *d_logits, float *dpair, float *part, int N, int H, int K,
-                                   vt_stream s) {
+int vt::head_bwd_windows_tail(const float *probs, const int *labels, const float *wfc, const unsigned char *pool_idx,
+                              const float *pooled, const float *z, const float *pn_stat, const float *pn_gamma,
+                              const float *pn_beta, float *d_logits, float *dpair, float *part, int N, int H, int K,
+                              const BnBwdTail &tail, hipStream_t s) {
   if (N < 1 || H != 28 || K < 1 || K > KMAX) return VT_EUNSUPPORTED;
   const int nb = head_win_chunk(N);
   const dim3 grid((C2 * 196 + TPB - 1) / TPB, (N + nb - 1) / nb);
-#define CALL(KK)                                                                                                        \
-  hipLaunchKernelGGL(k_head_bwd_win<KK>, grid, dim3(TPB), 0, (hipStream_t)s, probs, labels, wfc, pool_idx, pooled, z, \
-                     pn_stat, pn_gamma, pn_beta, d_logits, dpair, part, N, nb)
+#define CALL(KK)                                                                                                          \
+  hipLaunchKernelGGL(k_head_bwd_win<KK>, grid, dim3(TPB), 0, s, probs, labels, wfc, pool_idx, pooled, z, pn_stat, pn_gamma, \
+                     pn_beta, d_logits, dpair, part, N, nb, tail)
   VT_FOR_K(CALL)
 #undef CALL
   VT_CHECK_LAUNCH();
   return 0;
+}
+extern "C" int vt_head_bwd_windows(const float *probs, const int *labels, const float *wfc, const unsigned char *pool_idx,
+                                   const float *pooled, const float *z, const float *pn_stat, const float *pn_gamma,
+                                   const float *pn_beta, float *d_logits, float *dpair, float *part, int N, int H, int K,
+                                   vt_stream s) {
+  return head_bwd_windows_tail(probs, labels, wfc, pool_idx, pooled, z, pn_stat, pn_gamma, pn_beta, d_logits, dpair, part, N, H, K,
+                               BnBwdTail{}, (hipStream_t)s);
 }
 
 extern "C" int vt_head_expand_windows(const float *dpair, float *du, int N, int H, vt_stream s) {

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "vtcnn_common.h"
+#include "vtcnn_tail.h"
 #include "vtcnn_generic.h"
 
 using namespace vt;
@@ -65,6 +66,8 @@ struct vt_model {
   const float *last_images = nullptr;
   float *last_probs = nullptr;  // where the last forward left the probabilities (the caller's buffer or m->probs)
   // backward workspace
+  unsigned *tickets = nullptr;  // eight ticket sets of the BatchNorm closing steps that run inside their producer kernels
+  bool tails = false;           // those closing steps in place of the separate finalize launches (opt-in: measured no faster)
   float *dpair = nullptr;   // delta per element pair [N, P*C2/2]: what the head backward hands the projector on 28x28 inputs
   bool du_windows = false;  // the last backward left dpair, not the dense du
   float *dlogits, *du, *pdx, *pdt, *dv, *dk, *d0, *ds2, *dh, *da, *dr, *dc, *dT0, *dy, *qkv, *gslab, *gslab_conv;
@@ -207,6 +210,12 @@ extern "C" int vt_model_create(const vt_dims *dims, int max_batch, int device, f
   rc |= dalloc(m, &m->dlogits, N * K, "bwd.d_logits");
   rc |= dalloc(m, &m->du, N * P * C2, "bwd.du");
   rc |= dalloc(m, &m->dpair, N * P * C2 / 2, "bwd.dpair");
+  {
+    float *tk = nullptr;
+    rc |= dalloc(m, &tk, 8 * TAIL_WORDS);
+    m->tickets = (unsigned *)tk;
+    if (rc == 0 && hipMemset(tk, 0, 8 * TAIL_WORDS * sizeof(unsigned)) != hipSuccess) rc = VT_ENOMEM;
+  }
   rc |= dalloc(m, &m->pdx, N * P * C1, "bwd.proj_dx");
   rc |= dalloc(m, &m->pdt, NL * D, "bwd.proj_dt");
   rc |= dalloc(m, &m->dv, NL * C2, "bwd.proj_dv");
@@ -791,6 +800,13 @@ extern "C" int vt_model_set_matmul_precision(vt_model *m, int bf16) {
   return 0;
 }
 
+extern "C" int vt_model_set_fused_reductions(vt_model *m, int on) {
+  if (!m) return VT_EINVAL;
+  if (m->gen) return on ? VT_EUNSUPPORTED : 0;
+  m->tails = on != 0;
+  return 0;
+}
+
 extern "C" int vt_model_set_concurrency(vt_model *m, int on) {
   if (!m) return VT_EINVAL;
   m->concurrent = on != 0;
@@ -865,33 +881,60 @@ static int forward_impl(vt_model *m, const float *d_images, int n, int group, fl
   m->last_images = d_images;
   m->last_grouped = group > 0;
   // conv + BatchNorm2D statistics (training: batch stats; eval: running stats)
-  STEP("conv3x3_fwd", vt_conv3x3_fwd(d_images, m->P_("conv.W"), m->P_("conv.b"), m->conv, m->training ? m->part : nullptr, n, Ci, H, H, s));
-  if (m->training)
+  // With m->tails the last workgroup of each producer kernel closes the statistic it feeds (vtcnn_tail.h) and the
+  // separate finalize launch is skipped; grouped sweeps keep the launches (their statistics are per group).
+  const bool tails = m->tails && group == 0;
+  hipStream_t hs = (hipStream_t)s;
+  auto fwd_tail = [&](int site, const char *mean, const char *var, float *stat, long rows_per_block, long rows_total) {
+    BnFwdTail t;
+    if (tails) {
+      t.ticket = m->tickets + site * TAIL_WORDS;
+      t.run_mean = m->P_(mean);
+      t.run_var = m->P_(var);
+      t.stat = stat;
+      t.rows_per_block = rows_per_block;
+      t.rows_total = rows_total;
+    }
+    return t;
+  };
+  STEP("conv3x3_fwd", conv3x3_fwd_tail(d_images, m->P_("conv.W"), m->P_("conv.b"), m->conv, m->training ? m->part : nullptr, n, Ci, H, H,
+                                       fwd_tail(0, "bn.running_mean", "bn.running_var", m->stat_bn, P, (long)n * P), hs));
+  if (m->training && tails) {
+  } else if (m->training)
     STEP("bn_stats_finalize", vt_bn_stats_finalize(m->part, n, C1, P, (long)n * P, m->P_("bn.running_mean"), m->P_("bn.running_var"), m->stat_bn, s));
   else
     STEP("bn_stats_eval", vt_bn_stats_eval(m->P_("bn.running_mean"), m->P_("bn.running_var"), C1, m->stat_bn, s));
   // tokenizer; the three BatchNorm1D layers always use batch statistics (visual_transformer.hpp:221)
-  STEP("tokenizer_fwd", vt_tokenizer_fwd(m->conv, m->stat_bn, m->P_("bn.gamma"), m->P_("bn.beta"), m->P_("tok.linear1.W"),
+  STEP("tokenizer_fwd", tokenizer_fwd_tail(m->conv, m->stat_bn, m->P_("bn.gamma"), m->P_("bn.beta"), m->P_("tok.linear1.W"),
                          m->P_("tok.linear1.b"), m->P_("tok.linear2.W"), m->P_("tok.linear2.b"), m->keep_internals ? m->tokA : nullptr, m->tokstat,
-                         m->tok, m->part,
-                         n, P, s));
-  if (group > 0)
+                         m->tok, m->part, n, P,
+                         fwd_tail(1, "norm1.running_mean", "norm1.running_var", m->stat_n1, L, NL), hs));
+  if (tails) {
+  } else if (group > 0)
     STEP("bn_stats_finalize", vt_bn_stats_finalize_grouped(m->part, n, group, D, L, NL, m->P_("norm1.running_mean"), m->P_("norm1.running_var"), m->stat_n1, m->batch_mv, s));
   else
     STEP("bn_stats_finalize", vt_bn_stats_finalize(m->part, n, D, L, NL, m->P_("norm1.running_mean"), m->P_("norm1.running_var"), m->stat_n1, s));
-  STEP("transformer_ffn_fwd", vt_transformer_ffn_fwd_grouped(m->tok, m->stat_n1, m->P_("norm1.gamma"), m->P_("norm1.beta"), m->P_("ffn.linear1.W"),
-                               m->P_("ffn.linear1.b"), m->P_("ffn.linear2.W"), m->P_("ffn.linear2.b"), m->a, m->hdn, m->s2,
-                               m->part, NL, (long)group * L, s));
-  if (group > 0)
+  if (tails)
+    STEP("transformer_ffn_fwd", transformer_ffn_fwd_tail(m->tok, m->stat_n1, m->P_("norm1.gamma"), m->P_("norm1.beta"), m->P_("ffn.linear1.W"),
+                                 m->P_("ffn.linear1.b"), m->P_("ffn.linear2.W"), m->P_("ffn.linear2.b"), m->a, m->hdn, m->s2, m->part, NL,
+                                 fwd_tail(2, "norm2.running_mean", "norm2.running_var", m->stat_n2, RB, NL), hs));
+  else
+    STEP("transformer_ffn_fwd", vt_transformer_ffn_fwd_grouped(m->tok, m->stat_n1, m->P_("norm1.gamma"), m->P_("norm1.beta"), m->P_("ffn.linear1.W"),
+                                 m->P_("ffn.linear1.b"), m->P_("ffn.linear2.W"), m->P_("ffn.linear2.b"), m->a, m->hdn, m->s2,
+                                 m->part, NL, (long)group * L, s));
+  if (tails) {
+  } else if (group > 0)
     STEP("bn_stats_finalize", vt_bn_stats_finalize_grouped(m->part, nrb, group * L / RB, D, RB, NL, m->P_("norm2.running_mean"), m->P_("norm2.running_var"), m->stat_n2, m->batch_mv, s));
   else
     STEP("bn_stats_finalize", vt_bn_stats_finalize(m->part, nrb, D, RB, NL, m->P_("norm2.running_mean"), m->P_("norm2.running_var"), m->stat_n2, s));
   STEP("projector_tokens_fwd", vt_projector_tokens_fwd_grouped(m->s2, m->stat_n2, m->P_("norm2.gamma"), m->P_("norm2.beta"), m->P_("proj.linear1.W"),
                                 m->P_("proj.linear2.W"), m->P_("proj.linear3.W"), m->P_("proj.linear3.b"), m->o, m->pk, n, group, s));
-  STEP("projector_fwd", vt_projector_fwd(m->conv, m->stat_bn, m->P_("bn.gamma"), m->P_("bn.beta"), m->pk, m->P_("proj.downsample.W"),
+  STEP("projector_fwd", projector_fwd_tail(m->conv, m->stat_bn, m->P_("bn.gamma"), m->P_("bn.beta"), m->pk, m->P_("proj.downsample.W"),
                          m->P_("proj.downsample.b"), m->P_("proj.norm.running_mean"),
-                         m->keep_internals ? m->projA : nullptr, m->z, m->part, n, P, s));
-  if (group > 0)
+                         m->keep_internals ? m->projA : nullptr, m->z, m->part, n, P,
+                         fwd_tail(3, "proj.norm.running_mean", "proj.norm.running_var", m->stat_pn, P, (long)n * P), hs));
+  if (tails) {
+  } else if (group > 0)
     STEP("bn_stats_finalize", vt_bn_stats_finalize_grouped(m->part, n, group, C2, P, (long)n * P, m->P_("proj.norm.running_mean"), m->P_("proj.norm.running_var"),
                                m->stat_pn, m->batch_mv, s));
   else
@@ -950,13 +993,31 @@ static int backward_main(vt_model *m, const int *d_labels, vt_stream s) {
   }();
   const bool windows = H == 28 && !dense_delta;
   m->du_windows = windows;
-  if (windows)
+  auto bwd_tail = [&](int site, const char *gamma, const float *stat, const float *in_row0, float *coef, long rows_total) {
+    BnBwdTail t;
+    t.ticket = m->tickets + site * TAIL_WORDS;
+    t.gamma = m->P_(gamma);
+    t.stat = stat;
+    t.in_row0 = in_row0;
+    t.ggamma = m->G_(gamma);
+    t.gbeta = m->G_((std::string(gamma).substr(0, std::string(gamma).size() - 5) + "beta").c_str());
+    t.coef = coef;
+    t.rows_total = rows_total;
+    return t;
+  };
+  const bool tails = m->tails;
+  if (windows && tails)
+    STEP("head_bwd", head_bwd_windows_tail(m->last_probs, d_labels, m->P_("fc.W"), m->pool_idx, m->pooled, m->z, m->stat_pn,
+                      m->P_("proj.norm.gamma"), m->P_("proj.norm.beta"), m->dlogits, m->dpair, m->part, n, H, K,
+                      bwd_tail(4, "proj.norm.gamma", m->stat_pn, m->z, m->coef_pn, (long)n * P), hs));
+  else if (windows)
     STEP("head_bwd", vt_head_bwd_windows(m->last_probs, d_labels, m->P_("fc.W"), m->pool_idx, m->pooled, m->z, m->stat_pn,
                       m->P_("proj.norm.gamma"), m->P_("proj.norm.beta"), m->dlogits, m->dpair, m->part, n, H, K, s));
   else
     STEP("head_bwd", vt_head_bwd(m->last_probs, d_labels, m->P_("fc.W"), m->pool_idx, m->z, m->stat_pn, m->P_("proj.norm.gamma"),
                       m->P_("proj.norm.beta"), m->dlogits, m->du, m->part, n, H, K, s));
-  STEP("bn_bwd_finalize", vt_bn_bwd_finalize(m->part, windows ? vt_head_bwd_windows_blocks(n) : n, C2, (long)n * P, m->P_("proj.norm.gamma"), m->stat_pn, m->z,
+  if (!(windows && tails))
+    STEP("bn_bwd_finalize", vt_bn_bwd_finalize(m->part, windows ? vt_head_bwd_windows_blocks(n) : n, C2, (long)n * P, m->P_("proj.norm.gamma"), m->stat_pn, m->z,
                            m->G_("proj.norm.gamma"), m->G_("proj.norm.beta"), m->coef_pn, s));
   // projector
   if (windows)
@@ -970,9 +1031,9 @@ static int backward_main(vt_model *m, const int *d_labels, vt_stream s) {
   VTCHK(vt_reduce_rows(m->gslab + C1 * D, n, C1 * C2 + C2, 400, m->G_("proj.downsample.W"), s));
   // projector token side + transformer step a (targets = projector token delta, same bytes:
   // visual_transformer.hpp:153-157) in one launch
-  STEP("projector_tokens_bwd", vt_projector_tokens_bwd_transformer_a(m->o, m->dv, m->dk, m->P_("proj.linear3.W"), m->P_("proj.linear2.W"),
+  STEP("projector_tokens_bwd", projector_tokens_bwd_transformer_a_tail(m->o, m->dv, m->dk, m->P_("proj.linear3.W"), m->P_("proj.linear2.W"),
                                 m->pdt, m->G_("proj.linear2.W"), m->sc_pt, m->s2, m->stat_n2, m->P_("tok.linear2.W"), m->part,
-                                m->dT0, NL, s));
+                                m->dT0, NL, tails ? bwd_tail(5, "norm2.gamma", m->stat_n2, m->s2, m->coef_n2, NL) : BnBwdTail{}, hs));
   if (fork) {
     HIPCHK(hipEventRecord(m->ev_rows, hs));
     HIPCHK(hipStreamWaitEvent(m->side, m->ev_rows, 0));
@@ -980,21 +1041,26 @@ static int backward_main(vt_model *m, const int *d_labels, vt_stream s) {
   }
   // tokenizer.backward2(projector token delta, projector input delta) + BatchNorm2D + conv, with
   // partial sums of their own (norm2's are still waiting in m->part for their finalize)
-  STEP_ON("tokenizer_bwd", t, vt_tokenizer_bwd(m->conv, m->stat_bn, m->P_("bn.gamma"), m->P_("bn.beta"), m->tokstat, m->dT0,
-                         m->P_("tok.linear1.W"), m->P_("tok.linear1.b"), m->pdx, m->dy, m->part_side, n, P, t));
-  STEP_ON("bn_bwd_finalize", t, vt_bn_bwd_finalize(m->part_side, n, C1, (long)n * P, m->P_("bn.gamma"), m->stat_bn, m->conv,
+  STEP_ON("tokenizer_bwd", t, tokenizer_bwd_tail(m->conv, m->stat_bn, m->P_("bn.gamma"), m->P_("bn.beta"), m->tokstat, m->dT0,
+                         m->P_("tok.linear1.W"), m->P_("tok.linear1.b"), m->pdx, m->dy, m->part_side, n, P,
+                         tails ? bwd_tail(6, "bn.gamma", m->stat_bn, m->conv, m->coef_bn, (long)n * P) : BnBwdTail{}, (hipStream_t)t));
+  if (!tails)
+    STEP_ON("bn_bwd_finalize", t, vt_bn_bwd_finalize(m->part_side, n, C1, (long)n * P, m->P_("bn.gamma"), m->stat_bn, m->conv,
                            m->G_("bn.gamma"), m->G_("bn.beta"), m->coef_bn, t));
   STEP_ON("conv3x3_wgrad", t, vt_conv3x3_wgrad(m->last_images, m->dy, m->coef_bn, m->gslab_conv, n, Ci, H, H, t));
   VTCHK(vt_reduce_rows(m->gslab_conv, n, C1 * Ci * 9 + C1, C1 * Ci * 9 + C1, m->G_("conv.W"), s));  // queued
   // the fc weight gradient only needs the head's delta: it rides at the end of the shorter chain
   STEP_ON("fc_wgrad", t, vt_fc_wgrad(m->pooled, m->dlogits, m->G_("fc.W"), m->G_("fc.b"), m->sc_fc, n, Q, K, t));
   // feed-forward half of the transformer layer
-  STEP("bn_bwd_finalize", vt_bn_bwd_finalize(m->part, nrb, D, NL, m->P_("norm2.gamma"), m->stat_n2, m->s2, m->G_("norm2.gamma"),
-                           m->G_("norm2.beta"), m->coef_n2, s));
-  STEP("transformer_bwd_b", vt_transformer_bwd_b(m->o, m->pdt, m->coef_n2, m->hdn, m->a, m->tok, m->stat_n1, m->P_("ffn.linear1.W"),
-                             m->P_("ffn.linear2.W"), m->ds2, m->da, m->G_("ffn.linear1.W"), m->sc_ffn, m->part, NL, s));
-  STEP("bn_bwd_finalize", vt_bn_bwd_finalize(m->part, nrb, D, NL, m->P_("norm1.gamma"), m->stat_n1, m->tok, m->G_("norm1.gamma"),
-                           m->G_("norm1.beta"), m->coef_n1, s));
+  if (!tails)
+    STEP("bn_bwd_finalize", vt_bn_bwd_finalize(m->part, nrb, D, NL, m->P_("norm2.gamma"), m->stat_n2, m->s2, m->G_("norm2.gamma"),
+                             m->G_("norm2.beta"), m->coef_n2, s));
+  STEP("transformer_bwd_b", transformer_bwd_b_tail(m->o, m->pdt, m->coef_n2, m->hdn, m->a, m->tok, m->stat_n1, m->P_("ffn.linear1.W"),
+                             m->P_("ffn.linear2.W"), m->ds2, m->da, m->G_("ffn.linear1.W"), m->sc_ffn, m->part, NL,
+                             tails ? bwd_tail(7, "norm1.gamma", m->stat_n1, m->tok, m->coef_n1, NL) : BnBwdTail{}, hs));
+  if (!tails)
+    STEP("bn_bwd_finalize", vt_bn_bwd_finalize(m->part, nrb, D, NL, m->P_("norm1.gamma"), m->stat_n1, m->tok, m->G_("norm1.gamma"),
+                             m->G_("norm1.beta"), m->coef_n1, s));
   // the output projection's cached input is the zero concat: its gradient is exactly zero
   // (a reduction over zero slab rows writes the zeros: it rides in the fused reduction launch and keeps
   // memset nodes, which did not replay reliably, out of the captured step graph)

@@ -19,6 +19,7 @@
 // "T layout" below: lane = pixel j, registers = features 4g+v.  "N layout": lane = feature j,
 // registers = pixels 4g+v (what a contraction over pixels needs).
 #include "vtcnn_common.h"
+#include "vtcnn_tail.h"
 
 namespace vt {
 
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(TPB) void k_proj_fwd(const float *__restrict__ conv
                                                   const float *__restrict__ pk, const float *__restrict__ Wd,
                                                   const float *__restrict__ bd, const float *__restrict__ piv,
                                                   float *__restrict__ projA, float *__restrict__ z,
-                                                  float *__restrict__ part_pn, int P) {
+                                                  float *__restrict__ part_pn, int P, const BnFwdTail tail) {
   __shared__ float red[NW][2 * C2];
   const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, gq = lane >> 4;
   const float *__restrict__ mq = pk + (size_t)n * PK_STRIDE;
@@ -249,9 +250,16 @@ __global__ __launch_bounds__(TPB) void k_proj_fwd(const float *__restrict__ conv
       d1 += red[w][tid];
       d2 += red[w][C2 + tid];
     }
-    part_pn[(size_t)n * 2 * C2 + tid] = d1 + (float)P * piv[tid];
-    part_pn[(size_t)n * 2 * C2 + C2 + tid] = fmaxf(d2 - d1 * d1 / (float)P, 0.f);
+    const float rs = d1 + (float)P * piv[tid], rq = fmaxf(d2 - d1 * d1 / (float)P, 0.f);
+    if (tail.ticket == nullptr) {
+      part_pn[(size_t)n * 2 * C2 + tid] = rs;
+      part_pn[(size_t)n * 2 * C2 + C2 + tid] = rq;
+    } else {
+      tail_store(part_pn + (size_t)n * 2 * C2 + tid, rs);
+      tail_store(part_pn + (size_t)n * 2 * C2 + C2 + tid, rq);
+    }
   }
+  bn_fwd_tail(tail, part_pn, n, gridDim.x, C2);  // the last workgroup closes the projector BatchNorm1D statistics
 }
 
 
@@ -465,7 +473,8 @@ __global__ __launch_bounds__(TPB, 4) void k_tokenizer_fwd(const float *__restric
                                                        const float *__restrict__ W1, const float *__restrict__ b1,
                                                        const float *__restrict__ W2, const float *__restrict__ b2,
                                                        float *__restrict__ tokA, float *__restrict__ tok_stat,
-                                                       float *__restrict__ tok, float *__restrict__ part_n1, int P) {
+                                                       float *__restrict__ tok, float *__restrict__ part_n1, int P,
+                                                       const BnFwdTail tail) {
   __shared__ float redm[NW][L], reds[NW][L];
   __shared__ float sT[NW][256];
   __shared__ float sT0[L * C1];
@@ -589,9 +598,15 @@ __global__ __launch_bounds__(TPB, 4) void k_tokenizer_fwd(const float *__restric
       const float dlt = st_[l * D + tid] - mu;
       q += dlt * dlt;
     }
-    part_n1[(size_t)n * 2 * D + tid] = s;
-    part_n1[(size_t)n * 2 * D + D + tid] = q;
+    if (tail.ticket == nullptr) {
+      part_n1[(size_t)n * 2 * D + tid] = s;
+      part_n1[(size_t)n * 2 * D + D + tid] = q;
+    } else {
+      tail_store(part_n1 + (size_t)n * 2 * D + tid, s);
+      tail_store(part_n1 + (size_t)n * 2 * D + D + tid, q);
+    }
   }
+  if (part_n1 != nullptr) bn_fwd_tail(tail, part_n1, n, gridDim.x, D);  // the last workgroup closes norm1's statistics
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -611,7 +626,7 @@ __global__ __launch_bounds__(TPB) void k_tokenizer_bwd(const float *__restrict__
                                                        const float *__restrict__ tok_stat, const float *__restrict__ dT0,
                                                        const float *__restrict__ W1, const float *__restrict__ b1,
                                                        const float *__restrict__ pdx, float *__restrict__ dy,
-                                                       float *__restrict__ part, int P) {
+                                                       float *__restrict__ part, int P, const BnBwdTail tail) {
   __shared__ float red[NW][2 * C1];
   const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, gq = lane >> 4;
   const float *__restrict__ dt = dT0 + (size_t)n * L * C1;
@@ -692,7 +707,12 @@ __global__ __launch_bounds__(TPB) void k_tokenizer_bwd(const float *__restrict__
     }
   }
   __syncthreads();
-  if (tid < 2 * C1) part[(size_t)n * 2 * C1 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+  if (tid < 2 * C1) {
+    const float r = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    if (tail.ticket == nullptr) part[(size_t)n * 2 * C1 + tid] = r;
+    else tail_store(part + (size_t)n * 2 * C1 + tid, r);
+  }
+  bn_bwd_tail(tail, part, n, gridDim.x, C1);  // the last workgroup closes the BatchNorm2D backward reduction
 }
 
 
@@ -864,14 +884,20 @@ __global__ __launch_bounds__(TPB) void k_fc_wgrad(const float *__restrict__ pool
 
 using namespace vt;
 
+int vt::projector_fwd_tail(const float *conv_out, const float *bn_stat, const float *bn_gamma, const float *bn_beta,
+                           const float *pk, const float *wd, const float *bd, const float *pivot, float *proj_a, float *z,
+                           float *part_pn, int N, int P, const BnFwdTail &tail, hipStream_t s) {
+  if (N < 1 || P < 1 || P > 16 * NW * TK_MAXT || !pivot) return VT_EUNSUPPORTED;
+  hipLaunchKernelGGL(k_proj_fwd, dim3(N), dim3(TPB), 0, s, conv_out, bn_stat, bn_gamma, bn_beta, pk, wd, bd, pivot, proj_a, z,
+                     part_pn, P, part_pn ? tail : BnFwdTail{});
+  VT_CHECK_LAUNCH();
+  return 0;
+}
 extern "C" int vt_projector_fwd(const float *conv_out, const float *bn_stat, const float *bn_gamma, const float *bn_beta,
                                 const float *pk, const float *wd, const float *bd, const float *pivot, float *proj_a,
                                 float *z, float *part_pn, int N, int P, vt_stream s) {
-  if (N < 1 || P < 1 || P > 16 * NW * TK_MAXT || !pivot) return VT_EUNSUPPORTED;
-  hipLaunchKernelGGL(k_proj_fwd, dim3(N), dim3(TPB), 0, (hipStream_t)s, conv_out, bn_stat, bn_gamma, bn_beta, pk, wd,
-                     bd, pivot, proj_a, z, part_pn, P);
-  VT_CHECK_LAUNCH();
-  return 0;
+  return projector_fwd_tail(conv_out, bn_stat, bn_gamma, bn_beta, pk, wd, bd, pivot, proj_a, z, part_pn, N, P, BnFwdTail{},
+                            (hipStream_t)s);
 }
 
 
@@ -898,28 +924,41 @@ extern "C" int vt_projector_bwd_windows(const float *dpair, const float *pn_coef
 }
 
 
-extern "C" int vt_tokenizer_fwd(const float *conv_out, const float *bn_stat, const float *bn_gamma, const float *bn_beta,
-                                const float *w1, const float *b1, const float *w2, const float *b2, float *tok_A,
-                                float *tok_stat, float *tokens, float *part_n1, int N, int P, vt_stream s) {
+int vt::tokenizer_fwd_tail(const float *conv_out, const float *bn_stat, const float *bn_gamma, const float *bn_beta,
+                           const float *w1, const float *b1, const float *w2, const float *b2, float *tok_A, float *tok_stat,
+                           float *tokens, float *part_n1, int N, int P, const BnFwdTail &tail, hipStream_t s) {
   if (N < 1 || P < 1 || P > 16 * NW * TK_MAXT || !tok_stat) return VT_EUNSUPPORTED;
+  const BnFwdTail t = part_n1 ? tail : BnFwdTail{};
   if (tok_A != nullptr)
-    hipLaunchKernelGGL(k_tokenizer_fwd<true>, dim3(N), dim3(TPB), 0, (hipStream_t)s, conv_out, bn_stat, bn_gamma, bn_beta,
-                       w1, b1, w2, b2, tok_A, tok_stat, tokens, part_n1, P);
+    hipLaunchKernelGGL(k_tokenizer_fwd<true>, dim3(N), dim3(TPB), 0, s, conv_out, bn_stat, bn_gamma, bn_beta, w1, b1, w2, b2,
+                       tok_A, tok_stat, tokens, part_n1, P, t);
   else
-    hipLaunchKernelGGL(k_tokenizer_fwd<false>, dim3(N), dim3(TPB), 0, (hipStream_t)s, conv_out, bn_stat, bn_gamma, bn_beta,
-                       w1, b1, w2, b2, tok_A, tok_stat, tokens, part_n1, P);
+    hipLaunchKernelGGL(k_tokenizer_fwd<false>, dim3(N), dim3(TPB), 0, s, conv_out, bn_stat, bn_gamma, bn_beta, w1, b1, w2, b2,
+                       tok_A, tok_stat, tokens, part_n1, P, t);
   VT_CHECK_LAUNCH();
   return 0;
 }
+extern "C" int vt_tokenizer_fwd(const float *conv_out, const float *bn_stat, const float *bn_gamma, const float *bn_beta,
+                                const float *w1, const float *b1, const float *w2, const float *b2, float *tok_A,
+                                float *tok_stat, float *tokens, float *part_n1, int N, int P, vt_stream s) {
+  return tokenizer_fwd_tail(conv_out, bn_stat, bn_gamma, bn_beta, w1, b1, w2, b2, tok_A, tok_stat, tokens, part_n1, N, P,
+                            BnFwdTail{}, (hipStream_t)s);
+}
 
+int vt::tokenizer_bwd_tail(const float *conv_out, const float *bn_stat, const float *bn_gamma, const float *bn_beta,
+                           const float *tok_stat, const float *dT0, const float *w1, const float *b1, const float *pdx,
+                           float *dy, float *part, int N, int P, const BnBwdTail &tail, hipStream_t s) {
+  if (N < 1 || P < 1 || !tok_stat) return VT_EUNSUPPORTED;
+  hipLaunchKernelGGL(k_tokenizer_bwd, dim3(N), dim3(TPB), 0, s, conv_out, bn_stat, bn_gamma, bn_beta, tok_stat, dT0, w1, b1,
+                     pdx, dy, part, P, tail);
+  VT_CHECK_LAUNCH();
+  return 0;
+}
 extern "C" int vt_tokenizer_bwd(const float *conv_out, const float *bn_stat, const float *bn_gamma, const float *bn_beta,
                                 const float *tok_stat, const float *dT0, const float *w1, const float *b1,
                                 const float *pdx, float *dy, float *part, int N, int P, vt_stream s) {
-  if (N < 1 || P < 1 || !tok_stat) return VT_EUNSUPPORTED;
-  hipLaunchKernelGGL(k_tokenizer_bwd, dim3(N), dim3(TPB), 0, (hipStream_t)s, conv_out, bn_stat, bn_gamma, bn_beta,
-                     tok_stat, dT0, w1, b1, pdx, dy, part, P);
-  VT_CHECK_LAUNCH();
-  return 0;
+  return tokenizer_bwd_tail(conv_out, bn_stat, bn_gamma, bn_beta, tok_stat, dT0, w1, b1, pdx, dy, part, N, P, BnBwdTail{},
+                            (hipStream_t)s);
 }
 
 

@@ -16,6 +16,7 @@
 // W[(16*tt + 4*g + v)*ldw + n0 + j]; for dx = dy.W^T it is W[(i0 + j)*ldw + 16*tt + 4*g + v]
 // (one 16-byte load per tt).
 #include "vtcnn_common.h"
+#include "vtcnn_tail.h"
 
 namespace vt {
 
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(TPB) void k_tr_ffn_fwd(const float *__restrict__ to
                                                     const float *__restrict__ W2, const float *__restrict__ b2,
                                                     float *__restrict__ a_out, float *__restrict__ hdn_out,
                                                     float *__restrict__ s2_out, float *__restrict__ part_n2,
-                                                    long rows, long group_rows) {
+                                                    long rows, long group_rows, const BnFwdTail tail) {
   __shared__ float sred[NW][D];
   const Lane ln;
   const int wave = threadIdx.x >> 6;
@@ -231,14 +232,21 @@ __global__ __launch_bounds__(TPB) void k_tr_ffn_fwd(const float *__restrict__ to
   if (threadIdx.x < D) {
     const int f = threadIdx.x;
     // every lane holds the workgroup sums of its own features; lanes (wave 0, j == 0) write them
-    part_n2[(size_t)blockIdx.x * 2 * D + D + f] = (sred[0][f] + sred[1][f]) + (sred[2][f] + sred[3][f]);
+    const float rq = (sred[0][f] + sred[1][f]) + (sred[2][f] + sred[3][f]);
+    if (tail.ticket == nullptr) part_n2[(size_t)blockIdx.x * 2 * D + D + f] = rq;
+    else tail_store(part_n2 + (size_t)blockIdx.x * 2 * D + D + f, rq);
   }
   if (wave == 0 && ln.j == 0) {
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-      for (int v = 0; v < 4; ++v) part_n2[(size_t)blockIdx.x * 2 * D + 16 * tt + 4 * ln.g + v] = sm[tt][v];
+      for (int v = 0; v < 4; ++v) {
+        float *dst = part_n2 + (size_t)blockIdx.x * 2 * D + 16 * tt + 4 * ln.g + v;
+        if (tail.ticket == nullptr) *dst = sm[tt][v];
+        else tail_store(dst, sm[tt][v]);
+      }
   }
+  bn_fwd_tail(tail, part_n2, blockIdx.x, gridDim.x, D);  // the last workgroup closes norm2's statistics
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -379,7 +387,8 @@ __global__ __launch_bounds__(TPB) void k_projtok_bwd(const float *__restrict__ o
 __device__ __forceinline__ void tr_bwd_a_body(const float *__restrict__ o, const TTile<2> &pt,
                                               const float *__restrict__ s2, const float *__restrict__ st2,
                                               const float *__restrict__ W2tok, float *__restrict__ part,
-                                              float *__restrict__ dT0, long rows, float (*sred)[2 * D]) {
+                                              float *__restrict__ dT0, long rows, float (*sred)[2 * D],
+                                              const BnBwdTail &tail) {
   const Lane ln;
   const int wave = threadIdx.x >> 6;
   const long row0 = ((long)blockIdx.x * NW + wave) * 16;
@@ -413,8 +422,11 @@ __device__ __forceinline__ void tr_bwd_a_body(const float *__restrict__ o, const
   __syncthreads();
   if (threadIdx.x < 2 * D) {
     const int f = threadIdx.x;
-    part[(size_t)blockIdx.x * 2 * D + f] = (sred[0][f] + sred[1][f]) + (sred[2][f] + sred[3][f]);
+    const float r = (sred[0][f] + sred[1][f]) + (sred[2][f] + sred[3][f]);
+    if (tail.ticket == nullptr) part[(size_t)blockIdx.x * 2 * D + f] = r;
+    else tail_store(part + (size_t)blockIdx.x * 2 * D + f, r);
   }
+  bn_bwd_tail(tail, part, blockIdx.x, gridDim.x, D);  // the last workgroup closes norm2's backward reduction
 }
 __global__ __launch_bounds__(TPB) void k_tr_bwd_a(const float *__restrict__ o, const float *__restrict__ pdt,
                                                   const float *__restrict__ s2, const float *__restrict__ st2,
@@ -425,7 +437,7 @@ __global__ __launch_bounds__(TPB) void k_tr_bwd_a(const float *__restrict__ o, c
   const long row0 = ((long)blockIdx.x * NW + (threadIdx.x >> 6)) * 16;
   TTile<2> pt;
   pt.load(pdt, row0, (int)max(0L, min(16L, rows - row0)), D, 0, ln);
-  tr_bwd_a_body(o, pt, s2, st2, W2tok, part, dT0, rows, sred);
+  tr_bwd_a_body(o, pt, s2, st2, W2tok, part, dT0, rows, sred, BnBwdTail{});
 }
 // Both of the above in one launch: step A only needs the token delta of its own rows, which the
 // projector's token-side backward has just formed in registers, so no device-wide ordering sits
@@ -435,12 +447,13 @@ __global__ __launch_bounds__(TPB) void k_projtok_bwd_tr_a(const float *__restric
                                                           const float *__restrict__ Wk, float *__restrict__ pdt,
                                                           float *__restrict__ scratch, const float *__restrict__ s2,
                                                           const float *__restrict__ st2, const float *__restrict__ W2tok,
-                                                          float *__restrict__ part, float *__restrict__ dT0, long rows) {
+                                                          float *__restrict__ part, float *__restrict__ dT0, long rows,
+                                                          const BnBwdTail tail) {
   __shared__ float sbuf[PT_SLOTS * TILE_SLOT];
   __shared__ float sred[NW][2 * D];
   TTile<2> pt;
   projtok_bwd_body(o, dv, dk, Wv, Wk, pdt, scratch, rows, sbuf, pt);
-  tr_bwd_a_body(o, pt, s2, st2, W2tok, part, dT0, rows, sred);
+  tr_bwd_a_body(o, pt, s2, st2, W2tok, part, dT0, rows, sred, tail);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -459,7 +472,7 @@ __global__ __launch_bounds__(TPB) void k_tr_bwd_b(const float *__restrict__ o, c
                                                   const float *__restrict__ st1, const float *__restrict__ W1,
                                                   const float *__restrict__ W2, float *__restrict__ ds2_out,
                                                   float *__restrict__ da_out, float *__restrict__ scratch,
-                                                  float *__restrict__ part, long rows) {
+                                                  float *__restrict__ part, long rows, const BnBwdTail tail) {
   __shared__ float sbuf[9 * TILE_SLOT];
   __shared__ float sred[NW][2 * D];
   const Lane ln;
@@ -562,8 +575,11 @@ __global__ __launch_bounds__(TPB) void k_tr_bwd_b(const float *__restrict__ o, c
     const float sm = (bs[f] + bs[64 + f]) + (bs[128 + f] + bs[192 + f]);
     if (f < D) row[D * D + f] = sm;
     else row[2 * D * D + D + (f - D)] = sm;
-    part[(size_t)blockIdx.x * 2 * D + f] = (sred[0][f] + sred[1][f]) + (sred[2][f] + sred[3][f]);
+    const float r = (sred[0][f] + sred[1][f]) + (sred[2][f] + sred[3][f]);
+    if (tail.ticket == nullptr) part[(size_t)blockIdx.x * 2 * D + f] = r;
+    else tail_store(part + (size_t)blockIdx.x * 2 * D + f, r);
   }
+  bn_bwd_tail(tail, part, blockIdx.x, gridDim.x, D);  // the last workgroup closes norm1's backward reduction
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -622,16 +638,27 @@ __global__ __launch_bounds__(TPB) void k_tr_bwd_c(const float *__restrict__ da, 
 // ---------------------------------------------------------------------------------------------
 using namespace vt;
 
+static int ffn_fwd_launch(const float *tokens, const float *n1_stat, const float *n1_gamma, const float *n1_beta,
+                          const float *w1, const float *b1, const float *w2, const float *b2, float *a, float *hdn, float *s2,
+                          float *part_n2, long rows, long group_rows, const BnFwdTail &tail, hipStream_t s) {
+  if (rows < 1 || group_rows < 0 || group_rows % RB != 0) return VT_EINVAL;
+  const int nb = (int)((rows + RB - 1) / RB);
+  hipLaunchKernelGGL(k_tr_ffn_fwd, dim3(nb), dim3(TPB), 0, s, tokens, n1_stat, n1_gamma, n1_beta, w1, b1, w2, b2, a, hdn, s2,
+                     part_n2, rows, group_rows, group_rows == 0 ? tail : BnFwdTail{});
+  VT_CHECK_LAUNCH();
+  return 0;
+}
+int vt::transformer_ffn_fwd_tail(const float *tokens, const float *n1_stat, const float *n1_gamma, const float *n1_beta,
+                                 const float *w1, const float *b1, const float *w2, const float *b2, float *a, float *hdn,
+                                 float *s2, float *part_n2, long rows, const BnFwdTail &tail, hipStream_t s) {
+  return ffn_fwd_launch(tokens, n1_stat, n1_gamma, n1_beta, w1, b1, w2, b2, a, hdn, s2, part_n2, rows, 0, tail, s);
+}
 extern "C" int vt_transformer_ffn_fwd_grouped(const float *tokens, const float *n1_stat, const float *n1_gamma,
                                               const float *n1_beta, const float *w1, const float *b1, const float *w2,
                                               const float *b2, float *a, float *hdn, float *s2, float *part_n2,
                                               long rows, long group_rows, vt_stream s) {
-  if (rows < 1 || group_rows < 0 || group_rows % RB != 0) return VT_EINVAL;
-  const int nb = (int)((rows + RB - 1) / RB);
-  hipLaunchKernelGGL(k_tr_ffn_fwd, dim3(nb), dim3(TPB), 0, (hipStream_t)s, tokens, n1_stat, n1_gamma, n1_beta, w1, b1,
-                     w2, b2, a, hdn, s2, part_n2, rows, group_rows);
-  VT_CHECK_LAUNCH();
-  return 0;
+  return ffn_fwd_launch(tokens, n1_stat, n1_gamma, n1_beta, w1, b1, w2, b2, a, hdn, s2, part_n2, rows, group_rows, BnFwdTail{},
+                        (hipStream_t)s);
 }
 extern "C" int vt_transformer_ffn_fwd(const float *tokens, const float *n1_stat, const float *n1_gamma,
                                       const float *n1_beta, const float *w1, const float *b1, const float *w2,
@@ -676,29 +703,42 @@ extern "C" int vt_transformer_bwd_a(const float *o, const float *pdt, const floa
 }
 
 // vt_projector_tokens_bwd followed by vt_transformer_bwd_a as one launch (same results, bit for bit).
+int vt::projector_tokens_bwd_transformer_a_tail(const float *o, const float *dv, const float *dk, const float *wv,
+                                                const float *wk, float *pdt, float *g_wk_wv_bv, float *scratch,
+                                                const float *s2, const float *n2_stat, const float *tok_w2, float *part,
+                                                float *dT0, long rows, const BnBwdTail &tail, hipStream_t s) {
+  if (rows < 1) return VT_EINVAL;
+  const int nb = (int)((rows + RB - 1) / RB);
+  hipLaunchKernelGGL(k_projtok_bwd_tr_a, dim3(nb), dim3(TPB), 0, s, o, dv, dk, wv, wk, pdt, scratch, s2, n2_stat, tok_w2, part,
+                     dT0, rows, tail);
+  VT_CHECK_LAUNCH();
+  return reduce_rows(scratch, nb, PT_STRIDE, PT_STRIDE, g_wk_wv_bv, s);
+}
 extern "C" int vt_projector_tokens_bwd_transformer_a(const float *o, const float *dv, const float *dk, const float *wv,
                                                      const float *wk, float *pdt, float *g_wk_wv_bv, float *scratch,
                                                      const float *s2, const float *n2_stat, const float *tok_w2,
                                                      float *part, float *dT0, long rows, vt_stream s) {
-  if (rows < 1) return VT_EINVAL;
-  const int nb = (int)((rows + RB - 1) / RB);
-  hipLaunchKernelGGL(k_projtok_bwd_tr_a, dim3(nb), dim3(TPB), 0, (hipStream_t)s, o, dv, dk, wv, wk, pdt, scratch, s2,
-                     n2_stat, tok_w2, part, dT0, rows);
-  VT_CHECK_LAUNCH();
-  return reduce_rows(scratch, nb, PT_STRIDE, PT_STRIDE, g_wk_wv_bv, (hipStream_t)s);
+  return projector_tokens_bwd_transformer_a_tail(o, dv, dk, wv, wk, pdt, g_wk_wv_bv, scratch, s2, n2_stat, tok_w2, part, dT0,
+                                                 rows, BnBwdTail{}, (hipStream_t)s);
 }
 
 // g_ffn: gradient block [gW1 | gb1 | gW2 | gb2] (2112 floats, arena order); scratch >= nb*2112.
+int vt::transformer_bwd_b_tail(const float *o, const float *pdt, const float *n2_coef, const float *hdn, const float *a,
+                               const float *tok, const float *n1_stat, const float *w1, const float *w2, float *ds2, float *da,
+                               float *g_ffn, float *scratch, float *part, long rows, const BnBwdTail &tail, hipStream_t s) {
+  if (rows < 1) return VT_EINVAL;
+  const int nb = (int)((rows + RB - 1) / RB);
+  hipLaunchKernelGGL(k_tr_bwd_b, dim3(nb), dim3(TPB), 0, s, o, pdt, n2_coef, hdn, a, tok, n1_stat, w1, w2, ds2, da, scratch,
+                     part, rows, tail);
+  VT_CHECK_LAUNCH();
+  return reduce_rows(scratch, nb, FF_STRIDE, FF_STRIDE, g_ffn, s);
+}
 extern "C" int vt_transformer_bwd_b(const float *o, const float *pdt, const float *n2_coef, const float *hdn,
                                     const float *a, const float *tok, const float *n1_stat, const float *w1,
                                     const float *w2, float *ds2, float *da, float *g_ffn, float *scratch, float *part,
                                     long rows, vt_stream s) {
-  if (rows < 1) return VT_EINVAL;
-  const int nb = (int)((rows + RB - 1) / RB);
-  hipLaunchKernelGGL(k_tr_bwd_b, dim3(nb), dim3(TPB), 0, (hipStream_t)s, o, pdt, n2_coef, hdn, a, tok, n1_stat, w1, w2,
-                     ds2, da, scratch, part, rows);
-  VT_CHECK_LAUNCH();
-  return reduce_rows(scratch, nb, FF_STRIDE, FF_STRIDE, g_ffn, (hipStream_t)s);
+  return transformer_bwd_b_tail(o, pdt, n2_coef, hdn, a, tok, n1_stat, w1, w2, ds2, da, g_ffn, scratch, part, rows, BnBwdTail{},
+                                (hipStream_t)s);
 }
 
 extern "C" int vt_transformer_bwd_c(const float *da, const float *n1_coef, const float *wo, const float *tok,

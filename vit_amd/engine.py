@@ -107,6 +107,11 @@ class VTCNN:
         (vt_model_set_concurrency); same bytes either way."""
         check(lib.vt_model_set_concurrency(self._h, int(bool(on))), "vt_model_set_concurrency")
 
+    def set_fused_reductions(self, on):
+        """BatchNorm reductions closed inside their producer kernels (opt-in; measured no faster) or by separate
+        finalize launches, the default (vt_model_set_fused_reductions)."""
+        check(lib.vt_model_set_fused_reductions(self._h, 1 if on else 0), "vt_model_set_fused_reductions")
+
     def set_matmul_precision(self, bf16):
         """General-shape models only: route the forward-type products through bf16 operands
         (vt_model_set_matmul_precision); parity drops from 1e-4 to 1e-2."""
