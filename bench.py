@@ -9,7 +9,9 @@ A "step" is one reference training iteration (utils/trainer.hpp:39-54) per GPU: 
 gradient all-reduce (N > 1), SGD update, on one resident mini-batch of `--batch` 1x28x28 images,
 8 classes.  Weak scaling: every rank trains its own mini-batches (one reference mini-batch is a
 semantic unit because of BatchNorm), gradients are summed over ranks with one RCCL all-reduce of
-the flat gradient arena and divided by world*batch.  Rank 0 prints ONE JSON line.
+the flat gradient arena and divided by world*batch.  Rank 0 prints ONE JSON line: the contract's fields, `roofline`
+(whole-step HBM form: algorithmic layer-boundary bytes per step over the measured step time, with the per-launcher
+table and the event-timed dominant launcher beside it) and `cpu_baseline` (the real reference on the host cores).
 """
 import argparse
 import json
