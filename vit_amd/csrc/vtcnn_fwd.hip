@@ -19,6 +19,7 @@ namespace vt {
 // ---------------------------------------------------------------------------------------------
 // Index arithmetic without integer division: rmagic = 2^32 / d + 1 gives n / d = umulhi(n, rmagic)
 // exactly for the sizes here (n < 2^13, d < 2^11: checked exhaustively).
+template <bool TAIL>  // TAIL: the last workgroup closes the BatchNorm2D statistics (vtcnn_tail.h)
 __global__ __launch_bounds__(TPB) void k_conv_fwd(const float *__restrict__ X, const float *__restrict__ Wc,
                                                   const float *__restrict__ bc, float *__restrict__ conv,
                                                   float *__restrict__ part, int Ci, int H, int W, unsigned w_magic,
@@ -110,18 +111,18 @@ __global__ __launch_bounds__(TPB) void k_conv_fwd(const float *__restrict__ X, c
     m2[co] = q;
   }
   block_sum<C1>(m2, red);
-  if (tail.ticket == nullptr) {
+  if constexpr (!TAIL) {
     if (tid < C1) {
       part[(size_t)n * 2 * C1 + tid] = s[tid];
       part[(size_t)n * 2 * C1 + C1 + tid] = m2[tid];
     }
-    return;
+  } else {
+    if (tid < C1) {
+      tail_store(part + (size_t)n * 2 * C1 + tid, s[tid]);
+      tail_store(part + (size_t)n * 2 * C1 + C1 + tid, m2[tid]);
+    }
+    bn_fwd_tail(tail, part, n, gridDim.x, C1);
   }
-  if (tid < C1) {
-    tail_store(part + (size_t)n * 2 * C1 + tid, s[tid]);
-    tail_store(part + (size_t)n * 2 * C1 + C1 + tid, m2[tid]);
-  }
-  bn_fwd_tail(tail, part, n, gridDim.x, C1);  // the last workgroup closes the BatchNorm2D statistics
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -360,9 +361,11 @@ int vt::conv3x3_fwd_tail(const float *x, const float *w, const float *b, float *
   if (N < 1 || Ci < 1 || H * W > PPT * TPB || H < 1 || W < 1) return VT_EUNSUPPORTED;
   const size_t lds = (size_t)(((Ci * (H + 2) * (W + 2) + 3) & ~3) + NW * C1) * sizeof(float);
   if (lds > 56 * 1024) return VT_EUNSUPPORTED;  // the closing step adds static LDS of its own
-  hipLaunchKernelGGL(k_conv_fwd, dim3(N), dim3(TPB), lds, s, x, w, b, conv_out, part, Ci, H, W,
-                     (unsigned)(0x100000000ull / (unsigned)W + 1), (unsigned)(0x100000000ull / (unsigned)(W + 2) + 1),
-                     part ? tail : BnFwdTail{});
+  const unsigned wm = (unsigned)(0x100000000ull / (unsigned)W + 1), twm = (unsigned)(0x100000000ull / (unsigned)(W + 2) + 1);
+  if (part && tail.ticket)
+    hipLaunchKernelGGL(k_conv_fwd<true>, dim3(N), dim3(TPB), lds, s, x, w, b, conv_out, part, Ci, H, W, wm, twm, tail);
+  else
+    hipLaunchKernelGGL(k_conv_fwd<false>, dim3(N), dim3(TPB), lds, s, x, w, b, conv_out, part, Ci, H, W, wm, twm, BnFwdTail{});
   VT_CHECK_LAUNCH();
   return 0;
 }

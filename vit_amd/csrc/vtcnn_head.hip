@@ -304,7 +304,7 @@ __global__ __launch_bounds__(TPB) void k_head_bwd(const float *__restrict__ prob
 constexpr int HW_NB = 16;   // most images per workgroup
 constexpr int HW_RS = 16;   // LDS row stride of the per-thread channel bins
 constexpr int HW_B1 = TPB * HW_RS + 16;  // start of the second bin array: half the banks away from the first
-template <int K>
+template <int K, bool TAIL>  // TAIL: the last workgroup closes the projector BatchNorm1D backward reduction
 __global__ __launch_bounds__(TPB) void k_head_bwd_win(const float *__restrict__ probs, const int *__restrict__ labels,
                                                       const float *__restrict__ Wfc,
                                                       const unsigned char *__restrict__ pool_idx,
@@ -422,11 +422,10 @@ __global__ __launch_bounds__(TPB) void k_head_bwd_win(const float *__restrict__ 
 #pragma unroll
     for (int e8 = 0; e8 < 8; ++e8) tot += sred[e8][tid];
     float *dst = part + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 * C2 + tid;
-    if (tail.ticket == nullptr) *dst = tot;
+    if constexpr (!TAIL) *dst = tot;
     else tail_store(dst, tot);
   }
-  // the last workgroup closes the projector BatchNorm1D backward reduction
-  bn_bwd_tail(tail, part, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, C2);
+  if constexpr (TAIL) bn_bwd_tail(tail, part, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, C2);
 }
 
 // dpair -> the dense [N,P,C2] delta (what k_head_bwd writes): for hosts and tests that want it
@@ -512,9 +511,13 @@ int vt::head_bwd_windows_tail(const float *probs, const int *labels, const float
   if (N < 1 || H != 28 || K < 1 || K > KMAX) return VT_EUNSUPPORTED;
   const int nb = head_win_chunk(N);
   const dim3 grid((C2 * 196 + TPB - 1) / TPB, (N + nb - 1) / nb);
-#define CALL(KK)                                                                                                          \
-  hipLaunchKernelGGL(k_head_bwd_win<KK>, grid, dim3(TPB), 0, s, probs, labels, wfc, pool_idx, pooled, z, pn_stat, pn_gamma, \
-                     pn_beta, d_logits, dpair, part, N, nb, tail)
+#define CALL(KK)                                                                                                        \
+  if (tail.ticket)                                                                                                      \
+    hipLaunchKernelGGL((k_head_bwd_win<KK, true>), grid, dim3(TPB), 0, s, probs, labels, wfc, pool_idx, pooled, z, pn_stat, \
+                       pn_gamma, pn_beta, d_logits, dpair, part, N, nb, tail);                                          \
+  else                                                                                                                  \
+    hipLaunchKernelGGL((k_head_bwd_win<KK, false>), grid, dim3(TPB), 0, s, probs, labels, wfc, pool_idx, pooled, z, pn_stat, \
+                       pn_gamma, pn_beta, d_logits, dpair, part, N, nb, tail)
   VT_FOR_K(CALL)
 #undef CALL
   VT_CHECK_LAUNCH();

@@ -147,6 +147,7 @@ struct BnPair {
 // projA (the attention map) is written only when the pointer is non-null (debug / tests); the
 // backward pass recomputes it.
 // ---------------------------------------------------------------------------------------------
+template <bool TAIL>  // TAIL: the last workgroup closes the projector BatchNorm1D statistics
 __global__ __launch_bounds__(TPB) void k_proj_fwd(const float *__restrict__ conv, const float *__restrict__ st,
                                                   const float *__restrict__ g, const float *__restrict__ b,
                                                   const float *__restrict__ pk, const float *__restrict__ Wd,
@@ -251,7 +252,7 @@ __global__ __launch_bounds__(TPB) void k_proj_fwd(const float *__restrict__ conv
       d2 += red[w][C2 + tid];
     }
     const float rs = d1 + (float)P * piv[tid], rq = fmaxf(d2 - d1 * d1 / (float)P, 0.f);
-    if (tail.ticket == nullptr) {
+    if constexpr (!TAIL) {
       part_pn[(size_t)n * 2 * C2 + tid] = rs;
       part_pn[(size_t)n * 2 * C2 + C2 + tid] = rq;
     } else {
@@ -259,7 +260,7 @@ __global__ __launch_bounds__(TPB) void k_proj_fwd(const float *__restrict__ conv
       tail_store(part_pn + (size_t)n * 2 * C2 + C2 + tid, rq);
     }
   }
-  bn_fwd_tail(tail, part_pn, n, gridDim.x, C2);  // the last workgroup closes the projector BatchNorm1D statistics
+  if constexpr (TAIL) bn_fwd_tail(tail, part_pn, n, gridDim.x, C2);
 }
 
 
@@ -467,7 +468,7 @@ __global__ __launch_bounds__(TPB) void k_proj_bwd(const float *__restrict__ du, 
 // tok_stat[n] = (max_l[L], sum_l[L]) lets the backward pass rebuild A in a single sweep; tokA is
 // written only when non-null (debug / tests), by a third sweep.
 // ---------------------------------------------------------------------------------------------
-template <bool WITH_MAP>  // also write the attention map tokA (tests); its stores cost registers the step cannot spare
+template <bool WITH_MAP, bool TAIL>  // WITH_MAP: also write the attention map tokA (tests); its stores cost registers the step cannot spare.  TAIL: the last workgroup closes norm1's statistics
 __global__ __launch_bounds__(TPB, 4) void k_tokenizer_fwd(const float *__restrict__ conv, const float *__restrict__ st,
                                                        const float *__restrict__ g, const float *__restrict__ b,
                                                        const float *__restrict__ W1, const float *__restrict__ b1,
@@ -598,7 +599,7 @@ __global__ __launch_bounds__(TPB, 4) void k_tokenizer_fwd(const float *__restric
       const float dlt = st_[l * D + tid] - mu;
       q += dlt * dlt;
     }
-    if (tail.ticket == nullptr) {
+    if constexpr (!TAIL) {
       part_n1[(size_t)n * 2 * D + tid] = s;
       part_n1[(size_t)n * 2 * D + D + tid] = q;
     } else {
@@ -606,7 +607,7 @@ __global__ __launch_bounds__(TPB, 4) void k_tokenizer_fwd(const float *__restric
       tail_store(part_n1 + (size_t)n * 2 * D + D + tid, q);
     }
   }
-  if (part_n1 != nullptr) bn_fwd_tail(tail, part_n1, n, gridDim.x, D);  // the last workgroup closes norm1's statistics
+  if constexpr (TAIL) bn_fwd_tail(tail, part_n1, n, gridDim.x, D);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -621,6 +622,7 @@ __global__ __launch_bounds__(TPB, 4) void k_tokenizer_fwd(const float *__restric
 // the two token contractions onto the projector's input delta loaded as the accumulator (8).
 // A is rebuilt from the per-sample (max, sum) the forward pass left in tok_stat.
 // ---------------------------------------------------------------------------------------------
+template <bool TAIL>  // TAIL: the last workgroup closes the BatchNorm2D backward reduction
 __global__ __launch_bounds__(TPB) void k_tokenizer_bwd(const float *__restrict__ conv, const float *__restrict__ st,
                                                        const float *__restrict__ g, const float *__restrict__ b,
                                                        const float *__restrict__ tok_stat, const float *__restrict__ dT0,
@@ -709,10 +711,10 @@ __global__ __launch_bounds__(TPB) void k_tokenizer_bwd(const float *__restrict__
   __syncthreads();
   if (tid < 2 * C1) {
     const float r = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
-    if (tail.ticket == nullptr) part[(size_t)n * 2 * C1 + tid] = r;
+    if constexpr (!TAIL) part[(size_t)n * 2 * C1 + tid] = r;
     else tail_store(part + (size_t)n * 2 * C1 + tid, r);
   }
-  bn_bwd_tail(tail, part, n, gridDim.x, C1);  // the last workgroup closes the BatchNorm2D backward reduction
+  if constexpr (TAIL) bn_bwd_tail(tail, part, n, gridDim.x, C1);
 }
 
 
@@ -888,8 +890,12 @@ int vt::projector_fwd_tail(const float *conv_out, const float *bn_stat, const fl
                            const float *pk, const float *wd, const float *bd, const float *pivot, float *proj_a, float *z,
                            float *part_pn, int N, int P, const BnFwdTail &tail, hipStream_t s) {
   if (N < 1 || P < 1 || P > 16 * NW * TK_MAXT || !pivot) return VT_EUNSUPPORTED;
-  hipLaunchKernelGGL(k_proj_fwd, dim3(N), dim3(TPB), 0, s, conv_out, bn_stat, bn_gamma, bn_beta, pk, wd, bd, pivot, proj_a, z,
-                     part_pn, P, part_pn ? tail : BnFwdTail{});
+  if (part_pn && tail.ticket)
+    hipLaunchKernelGGL(k_proj_fwd<true>, dim3(N), dim3(TPB), 0, s, conv_out, bn_stat, bn_gamma, bn_beta, pk, wd, bd, pivot, proj_a,
+                       z, part_pn, P, tail);
+  else
+    hipLaunchKernelGGL(k_proj_fwd<false>, dim3(N), dim3(TPB), 0, s, conv_out, bn_stat, bn_gamma, bn_beta, pk, wd, bd, pivot, proj_a,
+                       z, part_pn, P, BnFwdTail{});
   VT_CHECK_LAUNCH();
   return 0;
 }
@@ -928,13 +934,15 @@ int vt::tokenizer_fwd_tail(const float *conv_out, const float *bn_stat, const fl
                            const float *w1, const float *b1, const float *w2, const float *b2, float *tok_A, float *tok_stat,
                            float *tokens, float *part_n1, int N, int P, const BnFwdTail &tail, hipStream_t s) {
   if (N < 1 || P < 1 || P > 16 * NW * TK_MAXT || !tok_stat) return VT_EUNSUPPORTED;
-  const BnFwdTail t = part_n1 ? tail : BnFwdTail{};
-  if (tok_A != nullptr)
-    hipLaunchKernelGGL(k_tokenizer_fwd<true>, dim3(N), dim3(TPB), 0, s, conv_out, bn_stat, bn_gamma, bn_beta, w1, b1, w2, b2,
-                       tok_A, tok_stat, tokens, part_n1, P, t);
-  else
-    hipLaunchKernelGGL(k_tokenizer_fwd<false>, dim3(N), dim3(TPB), 0, s, conv_out, bn_stat, bn_gamma, bn_beta, w1, b1, w2, b2,
-                       tok_A, tok_stat, tokens, part_n1, P, t);
+  const bool tl = part_n1 != nullptr && tail.ticket != nullptr;
+#define VT_TOKFWD(MAP, TL)                                                                                                  \
+  hipLaunchKernelGGL((k_tokenizer_fwd<MAP, TL>), dim3(N), dim3(TPB), 0, s, conv_out, bn_stat, bn_gamma, bn_beta, w1, b1, w2, \
+                     b2, tok_A, tok_stat, tokens, part_n1, P, TL ? tail : BnFwdTail{})
+  if (tok_A != nullptr && tl) VT_TOKFWD(true, true);
+  else if (tok_A != nullptr) VT_TOKFWD(true, false);
+  else if (tl) VT_TOKFWD(false, true);
+  else VT_TOKFWD(false, false);
+#undef VT_TOKFWD
   VT_CHECK_LAUNCH();
   return 0;
 }
@@ -949,8 +957,12 @@ int vt::tokenizer_bwd_tail(const float *conv_out, const float *bn_stat, const fl
                            const float *tok_stat, const float *dT0, const float *w1, const float *b1, const float *pdx,
                            float *dy, float *part, int N, int P, const BnBwdTail &tail, hipStream_t s) {
   if (N < 1 || P < 1 || !tok_stat) return VT_EUNSUPPORTED;
-  hipLaunchKernelGGL(k_tokenizer_bwd, dim3(N), dim3(TPB), 0, s, conv_out, bn_stat, bn_gamma, bn_beta, tok_stat, dT0, w1, b1,
-                     pdx, dy, part, P, tail);
+  if (tail.ticket)
+    hipLaunchKernelGGL(k_tokenizer_bwd<true>, dim3(N), dim3(TPB), 0, s, conv_out, bn_stat, bn_gamma, bn_beta, tok_stat, dT0, w1,
+                       b1, pdx, dy, part, P, tail);
+  else
+    hipLaunchKernelGGL(k_tokenizer_bwd<false>, dim3(N), dim3(TPB), 0, s, conv_out, bn_stat, bn_gamma, bn_beta, tok_stat, dT0, w1,
+                       b1, pdx, dy, part, P, tail);
   VT_CHECK_LAUNCH();
   return 0;
 }

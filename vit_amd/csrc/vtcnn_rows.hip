@@ -137,6 +137,7 @@ __device__ __forceinline__ void tile_flush(const float *sbuf, int slot, float *_
 //   a = BN1(tok);  hdn = a.W1 + b1;  s2 = a + relu(hdn).W2 + b2   (+ partial stats of s2)
 // RB = 64 rows per workgroup = one 16-row tile per wave; 32 MFMAs per tile.
 // ---------------------------------------------------------------------------------------------
+template <bool TAIL>  // TAIL: the last workgroup closes norm2's statistics (vtcnn_tail.h)
 __global__ __launch_bounds__(TPB) void k_tr_ffn_fwd(const float *__restrict__ tok, const float *__restrict__ st,
                                                     const float *__restrict__ g, const float *__restrict__ b,
                                                     const float *__restrict__ W1, const float *__restrict__ b1,
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(TPB) void k_tr_ffn_fwd(const float *__restrict__ to
     const int f = threadIdx.x;
     // every lane holds the workgroup sums of its own features; lanes (wave 0, j == 0) write them
     const float rq = (sred[0][f] + sred[1][f]) + (sred[2][f] + sred[3][f]);
-    if (tail.ticket == nullptr) part_n2[(size_t)blockIdx.x * 2 * D + D + f] = rq;
+    if constexpr (!TAIL) part_n2[(size_t)blockIdx.x * 2 * D + D + f] = rq;
     else tail_store(part_n2 + (size_t)blockIdx.x * 2 * D + D + f, rq);
   }
   if (wave == 0 && ln.j == 0) {
@@ -242,11 +243,11 @@ __global__ __launch_bounds__(TPB) void k_tr_ffn_fwd(const float *__restrict__ to
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         float *dst = part_n2 + (size_t)blockIdx.x * 2 * D + 16 * tt + 4 * ln.g + v;
-        if (tail.ticket == nullptr) *dst = sm[tt][v];
+        if constexpr (!TAIL) *dst = sm[tt][v];
         else tail_store(dst, sm[tt][v]);
       }
   }
-  bn_fwd_tail(tail, part_n2, blockIdx.x, gridDim.x, D);  // the last workgroup closes norm2's statistics
+  if constexpr (TAIL) bn_fwd_tail(tail, part_n2, blockIdx.x, gridDim.x, D);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -384,6 +385,7 @@ __global__ __launch_bounds__(TPB) void k_projtok_bwd(const float *__restrict__ o
 // reads the same rows.
 // ---------------------------------------------------------------------------------------------
 // pt: this wave's tile of the projector token delta (T layout).  sred: NW x 2D floats of LDS.
+template <bool TAIL>
 __device__ __forceinline__ void tr_bwd_a_body(const float *__restrict__ o, const TTile<2> &pt,
                                               const float *__restrict__ s2, const float *__restrict__ st2,
                                               const float *__restrict__ W2tok, float *__restrict__ part,
@@ -423,10 +425,10 @@ __device__ __forceinline__ void tr_bwd_a_body(const float *__restrict__ o, const
   if (threadIdx.x < 2 * D) {
     const int f = threadIdx.x;
     const float r = (sred[0][f] + sred[1][f]) + (sred[2][f] + sred[3][f]);
-    if (tail.ticket == nullptr) part[(size_t)blockIdx.x * 2 * D + f] = r;
+    if constexpr (!TAIL) part[(size_t)blockIdx.x * 2 * D + f] = r;
     else tail_store(part + (size_t)blockIdx.x * 2 * D + f, r);
   }
-  bn_bwd_tail(tail, part, blockIdx.x, gridDim.x, D);  // the last workgroup closes norm2's backward reduction
+  if constexpr (TAIL) bn_bwd_tail(tail, part, blockIdx.x, gridDim.x, D);
 }
 __global__ __launch_bounds__(TPB) void k_tr_bwd_a(const float *__restrict__ o, const float *__restrict__ pdt,
                                                   const float *__restrict__ s2, const float *__restrict__ st2,
@@ -437,11 +439,12 @@ __global__ __launch_bounds__(TPB) void k_tr_bwd_a(const float *__restrict__ o, c
   const long row0 = ((long)blockIdx.x * NW + (threadIdx.x >> 6)) * 16;
   TTile<2> pt;
   pt.load(pdt, row0, (int)max(0L, min(16L, rows - row0)), D, 0, ln);
-  tr_bwd_a_body(o, pt, s2, st2, W2tok, part, dT0, rows, sred, BnBwdTail{});
+  tr_bwd_a_body<false>(o, pt, s2, st2, W2tok, part, dT0, rows, sred, BnBwdTail{});
 }
 // Both of the above in one launch: step A only needs the token delta of its own rows, which the
 // projector's token-side backward has just formed in registers, so no device-wide ordering sits
 // between them.  Same arithmetic in the same order: bit-identical to the two separate launches.
+template <bool TAIL>  // TAIL: the last workgroup closes norm2's backward reduction
 __global__ __launch_bounds__(TPB) void k_projtok_bwd_tr_a(const float *__restrict__ o, const float *__restrict__ dv,
                                                           const float *__restrict__ dk, const float *__restrict__ Wv,
                                                           const float *__restrict__ Wk, float *__restrict__ pdt,
@@ -453,7 +456,7 @@ __global__ __launch_bounds__(TPB) void k_projtok_bwd_tr_a(const float *__restric
   __shared__ float sred[NW][2 * D];
   TTile<2> pt;
   projtok_bwd_body(o, dv, dk, Wv, Wk, pdt, scratch, rows, sbuf, pt);
-  tr_bwd_a_body(o, pt, s2, st2, W2tok, part, dT0, rows, sred, tail);
+  tr_bwd_a_body<TAIL>(o, pt, s2, st2, W2tok, part, dT0, rows, sred, tail);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -466,6 +469,7 @@ __global__ __launch_bounds__(TPB) void k_projtok_bwd_tr_a(const float *__restric
 // the operand roles swapped; nothing is transposed through memory.
 // ---------------------------------------------------------------------------------------------
 constexpr int FF_STRIDE = 2 * (D * D + D);  // 2112
+template <bool TAIL>  // TAIL: the last workgroup closes norm1's backward reduction
 __global__ __launch_bounds__(TPB) void k_tr_bwd_b(const float *__restrict__ o, const float *__restrict__ pdt,
                                                   const float *__restrict__ coef2, const float *__restrict__ hdn,
                                                   const float *__restrict__ a, const float *__restrict__ tok,
@@ -576,10 +580,10 @@ __global__ __launch_bounds__(TPB) void k_tr_bwd_b(const float *__restrict__ o, c
     if (f < D) row[D * D + f] = sm;
     else row[2 * D * D + D + (f - D)] = sm;
     const float r = (sred[0][f] + sred[1][f]) + (sred[2][f] + sred[3][f]);
-    if (tail.ticket == nullptr) part[(size_t)blockIdx.x * 2 * D + f] = r;
+    if constexpr (!TAIL) part[(size_t)blockIdx.x * 2 * D + f] = r;
     else tail_store(part + (size_t)blockIdx.x * 2 * D + f, r);
   }
-  bn_bwd_tail(tail, part, blockIdx.x, gridDim.x, D);  // the last workgroup closes norm1's backward reduction
+  if constexpr (TAIL) bn_bwd_tail(tail, part, blockIdx.x, gridDim.x, D);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -643,8 +647,12 @@ static int ffn_fwd_launch(const float *tokens, const float *n1_stat, const float
                           float *part_n2, long rows, long group_rows, const BnFwdTail &tail, hipStream_t s) {
   if (rows < 1 || group_rows < 0 || group_rows % RB != 0) return VT_EINVAL;
   const int nb = (int)((rows + RB - 1) / RB);
-  hipLaunchKernelGGL(k_tr_ffn_fwd, dim3(nb), dim3(TPB), 0, s, tokens, n1_stat, n1_gamma, n1_beta, w1, b1, w2, b2, a, hdn, s2,
-                     part_n2, rows, group_rows, group_rows == 0 ? tail : BnFwdTail{});
+  if (group_rows == 0 && part_n2 && tail.ticket)
+    hipLaunchKernelGGL(k_tr_ffn_fwd<true>, dim3(nb), dim3(TPB), 0, s, tokens, n1_stat, n1_gamma, n1_beta, w1, b1, w2, b2, a, hdn,
+                       s2, part_n2, rows, group_rows, tail);
+  else
+    hipLaunchKernelGGL(k_tr_ffn_fwd<false>, dim3(nb), dim3(TPB), 0, s, tokens, n1_stat, n1_gamma, n1_beta, w1, b1, w2, b2, a, hdn,
+                       s2, part_n2, rows, group_rows, BnFwdTail{});
   VT_CHECK_LAUNCH();
   return 0;
 }
@@ -709,8 +717,12 @@ int vt::projector_tokens_bwd_transformer_a_tail(const float *o, const float *dv,
                                                 float *dT0, long rows, const BnBwdTail &tail, hipStream_t s) {
   if (rows < 1) return VT_EINVAL;
   const int nb = (int)((rows + RB - 1) / RB);
-  hipLaunchKernelGGL(k_projtok_bwd_tr_a, dim3(nb), dim3(TPB), 0, s, o, dv, dk, wv, wk, pdt, scratch, s2, n2_stat, tok_w2, part,
-                     dT0, rows, tail);
+  if (tail.ticket)
+    hipLaunchKernelGGL(k_projtok_bwd_tr_a<true>, dim3(nb), dim3(TPB), 0, s, o, dv, dk, wv, wk, pdt, scratch, s2, n2_stat, tok_w2,
+                       part, dT0, rows, tail);
+  else
+    hipLaunchKernelGGL(k_projtok_bwd_tr_a<false>, dim3(nb), dim3(TPB), 0, s, o, dv, dk, wv, wk, pdt, scratch, s2, n2_stat, tok_w2,
+                       part, dT0, rows, tail);
   VT_CHECK_LAUNCH();
   return reduce_rows(scratch, nb, PT_STRIDE, PT_STRIDE, g_wk_wv_bv, s);
 }
@@ -728,8 +740,12 @@ int vt::transformer_bwd_b_tail(const float *o, const float *pdt, const float *n2
                                float *g_ffn, float *scratch, float *part, long rows, const BnBwdTail &tail, hipStream_t s) {
   if (rows < 1) return VT_EINVAL;
   const int nb = (int)((rows + RB - 1) / RB);
-  hipLaunchKernelGGL(k_tr_bwd_b, dim3(nb), dim3(TPB), 0, s, o, pdt, n2_coef, hdn, a, tok, n1_stat, w1, w2, ds2, da, scratch,
-                     part, rows, tail);
+  if (tail.ticket)
+    hipLaunchKernelGGL(k_tr_bwd_b<true>, dim3(nb), dim3(TPB), 0, s, o, pdt, n2_coef, hdn, a, tok, n1_stat, w1, w2, ds2, da, scratch,
+                       part, rows, tail);
+  else
+    hipLaunchKernelGGL(k_tr_bwd_b<false>, dim3(nb), dim3(TPB), 0, s, o, pdt, n2_coef, hdn, a, tok, n1_stat, w1, w2, ds2, da, scratch,
+                       part, rows, tail);
   VT_CHECK_LAUNCH();
   return reduce_rows(scratch, nb, FF_STRIDE, FF_STRIDE, g_ffn, s);
 }
