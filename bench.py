@@ -197,11 +197,31 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("VT_BENCH_FAULT_TIMEOUT"):  # debugging aid: dump every thread's stack and exit if the run stalls
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["VT_BENCH_FAULT_TIMEOUT"]), exit=True)
+    # rehearsal aid: with fewer GPUs than ranks (one-GPU box) ranks share devices, which RCCL refuses, so the
+    # exchange can then be rehearsed over gloo (VT_BENCH_BACKEND=gloo); a real run has one GPU per rank and RCCL
+    local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        backend = os.environ.get("VT_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
+            _all_reduce = dist.all_reduce
+
+            def staged_all_reduce(t, *args, **kw):  # gloo rehearsal: device tensors travel through the host
+                if not t.is_cuda:
+                    return _all_reduce(t, *args, **kw)
+                h = t.cpu()
+                _all_reduce(h, *args, **{k: v for k, v in kw.items() if k != "async_op"})
+                t.copy_(h)
+                return None
+            dist.all_reduce = staged_all_reduce
     elif a.exchange_alone:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
