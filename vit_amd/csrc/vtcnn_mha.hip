@@ -417,11 +417,15 @@ __global__ __launch_bounds__(64 * MR_WAVES) void k_mha_rows(const float *__restr
 typedef float f4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f4 mfma16(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
+// NSPLIT: the number of j ranges, a compile-time constant so that the loops over them unroll and every load
+// of the kernel can be in flight at once (with one range its shift factors are exactly 1 and drop out).
+template <int NSPLIT>
 __global__ __launch_bounds__(TPB) void k_mha_wgrad(const float *__restrict__ yz, const float *__restrict__ st,
                                                    const float *__restrict__ qkv, const float *__restrict__ dc,
                                                    const float *__restrict__ tok, const float *__restrict__ Wqkv,
                                                    float *__restrict__ slab, const float *__restrict__ xbar, long rows,
-                                                   int nsplit, int single_key, int T) {
+                                                   int single_key, int T) {
+  constexpr int nsplit = NSPLIT;
   __shared__ float sbuf[6][NW * 256];  // the six gradient tiles of the four waves, summed in one phase
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4, h = blockIdx.y;
   const long row0 = ((long)blockIdx.x * NW + wave) * 16;
@@ -435,27 +439,37 @@ __global__ __launch_bounds__(TPB) void k_mha_wgrad(const float *__restrict__ yz,
   // (exactly 1 with a single split; 0 for a split that saw no tile, whose r is -inf)
   f4 rm4 = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
   float rmj = -INFINITY;
-  for (int sp = 0; sp < nsplit; ++sp) {
-    const float *s2 = st + (((size_t)h * nsplit + sp) * 3 + 2) * rows;
+  if constexpr (NSPLIT > 1) {
 #pragma unroll
-    for (int v = 0; v < 4; ++v)
-      if (4 * g + v < nv) rm4[v] = fmaxf(rm4[v], s2[row0 + 4 * g + v]);
-    if (j < nv) rmj = fmaxf(rmj, s2[row0 + j]);
+    for (int sp = 0; sp < nsplit; ++sp) {
+      const float *s2 = st + (((size_t)h * nsplit + sp) * 3 + 2) * rows;
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        if (4 * g + v < nv) rm4[v] = fmaxf(rm4[v], s2[row0 + 4 * g + v]);
+      if (j < nv) rmj = fmaxf(rmj, s2[row0 + j]);
+    }
   }
   auto fac4 = [&](int sp) {
-    const float *s2 = st + (((size_t)h * nsplit + sp) * 3 + 2) * rows;
     f4 f = zero;
+    if constexpr (NSPLIT == 1) {  // exp2(r - r) = 1 exactly
 #pragma unroll
-    for (int v = 0; v < 4; ++v)
-      if (4 * g + v < nv) f[v] = exp2f(s2[row0 + 4 * g + v] - rm4[v]);
+      for (int v = 0; v < 4; ++v) f[v] = 4 * g + v < nv ? 1.f : 0.f;
+    } else {
+      const float *s2 = st + (((size_t)h * nsplit + sp) * 3 + 2) * rows;
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        if (4 * g + v < nv) f[v] = exp2f(s2[row0 + 4 * g + v] - rm4[v]);
+    }
     return f;
   };
   auto facj = [&](int sp) {
-    return j < nv ? exp2f(st[(((size_t)h * nsplit + sp) * 3 + 2) * rows + row0 + j] - rmj) : 0.f;
+    if constexpr (NSPLIT == 1) return j < nv ? 1.f : 0.f;
+    else return j < nv ? exp2f(st[(((size_t)h * nsplit + sp) * 3 + 2) * rows + row0 + j] - rmj) : 0.f;
   };
   {
     f4 s4 = zero, t4 = zero;
     float sj = 0.f, tj = 0.f;
+#pragma unroll
     for (int sp = 0; sp < nsplit; ++sp) {
       const float *s0 = st + (((size_t)h * nsplit + sp) * 3 + 0) * rows, *s1 = s0 + rows;
       const f4 f = fac4(sp);
@@ -487,6 +501,7 @@ __global__ __launch_bounds__(TPB) void k_mha_wgrad(const float *__restrict__ yz,
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     f4 y = zero, w = zero;
+#pragma unroll
     for (int sp = 0; sp < nsplit; ++sp) {
       const float *yb = yz + ((((size_t)h * nsplit + sp) * 2 + 0) * D + (j + 16 * t)) * rows + row0 + 4 * g;
       const float *wb = yb + (size_t)D * rows;
@@ -518,6 +533,7 @@ __global__ __launch_bounds__(TPB) void k_mha_wgrad(const float *__restrict__ yz,
     for (int v = 0; v < 4; ++v) {
       float y1 = 0.f, w1 = 0.f;
       if (j < nv)
+#pragma unroll
         for (int sp = 0; sp < nsplit; ++sp) {
           const size_t o = ((((size_t)h * nsplit + sp) * 2 + 0) * D + (16 * t + 4 * g + v)) * rows + row0 + j;
           const float fj = facj(sp);
@@ -582,6 +598,11 @@ using namespace vt;
 // split adds a set of partial sums that it must read and merge.
 static int mha_splits(int N, int groups) {
   const int itiles = (N + 31) / 32;
+  static const int forced = [] {  // measurement aid: VT_MHA_SPLITS=n forces the number of j ranges (1..4)
+    const char *e = getenv("VT_MHA_SPLITS");
+    return e ? atoi(e) : 0;
+  }();
+  if (forced >= 1 && forced <= 4) return forced < itiles ? forced : itiles;
   const long waves = (long)HEADS * groups * ((itiles + MR_WAVES - 1) / MR_WAVES) * MR_WAVES;
   int ns = (int)((1024 + waves - 1) / waves);
   if (ns > 4) ns = 4;
@@ -636,8 +657,16 @@ extern "C" int vt_mha_bwd_wgrad(const float *qkv, const float *dc, const float *
   float *yz = scratch;
   float *st = yz + (size_t)HEADS * ns * 2 * D * rows;
   float *slab = st + (size_t)HEADS * ns * 3 * rows;
-  hipLaunchKernelGGL(k_mha_wgrad, dim3(nrb, HEADS), dim3(TPB), 0, (hipStream_t)s, yz, st, qkv, dc, tok, wqkv, slab,
-                     mha_xbar(scratch, rows), rows, ns, N == 1 ? 1 : 0, N);
+#define VT_WGRAD(NS)                                                                                               \
+  hipLaunchKernelGGL(k_mha_wgrad<NS>, dim3(nrb, HEADS), dim3(TPB), 0, (hipStream_t)s, yz, st, qkv, dc, tok, wqkv, slab, \
+                     mha_xbar(scratch, rows), rows, N == 1 ? 1 : 0, N)
+  switch (ns) {
+    case 1: VT_WGRAD(1); break;
+    case 2: VT_WGRAD(2); break;
+    case 3: VT_WGRAD(3); break;
+    default: VT_WGRAD(4); break;
+  }
+#undef VT_WGRAD
   VT_CHECK_LAUNCH();
   for (int h = 0; h < HEADS; ++h) {
     const int rc = reduce_rows(slab + (size_t)h * nrb * MH_STRIDE, nrb, MH_STRIDE, MH_STRIDE,
