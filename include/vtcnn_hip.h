@@ -465,6 +465,15 @@ int vt_gemm_f32(int transA, int transB, int M, int N, int K, float alpha, const 
 int vt_gemm_bf16_mfma(int transA, int transB, int M, int N, int K, float alpha, const float *A, int lda, long strideA,
                       const float *B, int ldb, long strideB, int accumulate, float *C, int ldc, long strideC,
                       const float *bias, int batch, float *workspace, long workspace_floats, vt_stream s);
+/* The same product at fp32 accuracy on the bf16 pipe: each operand is carried as hi = bf16(x) and
+ * lo = bf16(x - hi), a product is lo.hi + hi.lo + hi.hi (three v_mfma_f32_16x16x16_bf16 with fp32
+ * accumulation; relative error about 2^-17 per product, random in sign) instead of four fp32 matrix
+ * instructions of four times the duration.  What the general-shape step uses for its activation x weight and
+ * delta x weight products of depth >= 32 (not for products that feed an exponential, nor for the gradient
+ * contractions over the batch's rows); VT_GEMM_EXACT=1 in the environment keeps every product on vt_gemm_f32. */
+int vt_gemm_f32x3(int transA, int transB, int M, int N, int K, float alpha, const float *A, int lda, long strideA,
+                  const float *B, int ldb, long strideB, int accumulate, float *C, int ldc, long strideC,
+                  const float *bias, int batch, float *workspace, long workspace_floats, vt_stream s);
 /* Tensor::softmax over the last axis (tensor_cpu.hpp:894-944), in place on S [rows, width], and
  * Tensor::softmax_backward (tensor_cpu.hpp:946-950): da <- a * (da - sum_last(a * da)), in place on da. */
 int vt_softmax_rows(float *S, long rows, int width, vt_stream s);

@@ -11,7 +11,7 @@ from conftest import rel_err
 pytestmark = pytest.mark.gpu
 
 
-def _run(ta, tb, M, N, K, batch=1, alpha=1.0, bias=False, acc=False, pad=0, ws_floats=0, seed=0, tol=2e-6):
+def _run(ta, tb, M, N, K, batch=1, alpha=1.0, bias=False, acc=False, pad=0, ws_floats=0, seed=0, tol=2e-6, fn="vt_gemm_f32"):
     import torch
     from vit_amd._lib import check, lib
     rng = np.random.default_rng(seed)
@@ -26,10 +26,10 @@ def _run(ta, tb, M, N, K, batch=1, alpha=1.0, bias=False, acc=False, pad=0, ws_f
     dbias = torch.from_numpy(bv).cuda() if bias else None
     ws = torch.zeros(max(ws_floats, 1), dtype=torch.float32, device="cuda")
     s = torch.cuda.current_stream().cuda_stream
-    check(lib.vt_gemm_f32(int(ta), int(tb), M, N, K, alpha, C.c_void_p(dA.data_ptr()), lda, ar * lda,
-                          C.c_void_p(dB.data_ptr()), ldb, br * ldb, int(acc), C.c_void_p(dC.data_ptr()), ldc, M * ldc,
-                          C.c_void_p(dbias.data_ptr()) if bias else None, batch,
-                          C.c_void_p(ws.data_ptr()) if ws_floats else None, ws_floats, C.c_void_p(s)), "vt_gemm_f32")
+    check(getattr(lib, fn)(int(ta), int(tb), M, N, K, alpha, C.c_void_p(dA.data_ptr()), lda, ar * lda,
+                           C.c_void_p(dB.data_ptr()), ldb, br * ldb, int(acc), C.c_void_p(dC.data_ptr()), ldc, M * ldc,
+                           C.c_void_p(dbias.data_ptr()) if bias else None, batch,
+                           C.c_void_p(ws.data_ptr()) if ws_floats else None, ws_floats, C.c_void_p(s)), fn)
     got = dC.cpu().numpy()
     a = A[:, :, :ac].astype(np.float64)
     b = B[:, :, :bc].astype(np.float64)
@@ -64,6 +64,22 @@ def test_gemm_sliced_contraction():
     _run(1, 0, 27, 64, 9001, ws_floats=1 << 20, seed=6)
     # without a workspace the same product runs unsliced: 50 000 sequential fp32 additions per element
     _run(1, 0, 64, 16, 50000, seed=7, tol=5e-5)
+
+
+@pytest.mark.parametrize("ta", [0, 1])
+@pytest.mark.parametrize("tb", [0, 1])
+def test_gemm_split_products_keep_fp32_accuracy(ta, tb):
+    """vt_gemm_f32x3 (operands as bf16 hi + lo, three partial products, fp32 accumulation): every case of the exact
+    kernel's test, against numpy in double precision at 2e-5 of the largest element (2^-17 per product, random in
+    sign, over sums of Gaussian terms), including a 512-deep product of the wide configuration's shape."""
+    kw = dict(fn="vt_gemm_f32x3", tol=2e-5)
+    _run(ta, tb, 64, 64, 16, **kw)
+    _run(ta, tb, 1, 1, 1, **kw)
+    _run(ta, tb, 130, 75, 37, pad=3, seed=1, **kw)
+    _run(ta, tb, 100, 16, 200, batch=5, alpha=0.25, bias=True, seed=2, **kw)
+    _run(ta, tb, 33, 129, 64, batch=3, acc=True, pad=1, seed=3, **kw)
+    _run(ta, tb, 3136, 512, 512, seed=8, **kw)
+    _run(ta, tb, 256, 196, 512, batch=4, seed=9, **kw)
 
 
 def _bf16_round(a):

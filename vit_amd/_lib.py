@@ -124,6 +124,7 @@ SIGNATURES = {
     "vt_reduce_rows": (i, [p, l, i, i, p, p]),
     "vt_gemm_f32": (i, [i, i, i, i, i, f, p, i, C.c_long, p, i, C.c_long, i, p, i, C.c_long, p, i, p, C.c_long, p]),
     "vt_gemm_bf16_mfma": (i, [i, i, i, i, i, f, p, i, C.c_long, p, i, C.c_long, i, p, i, C.c_long, p, i, p, C.c_long, p]),
+    "vt_gemm_f32x3": (i, [i, i, i, i, i, f, p, i, C.c_long, p, i, C.c_long, i, p, i, C.c_long, p, i, p, C.c_long, p]),
     "vt_batchnorm_scratch_floats": (l, [i]),
     "vt_batchnorm_fwd": (i, [p, l, i, p, p, p, p, i, p, p, p, l, p]),
     "vt_batchnorm_bwd": (i, [p, p, p, p, l, i, p, p, p, p, l, p]),

@@ -10,6 +10,11 @@
 // LDS.  A long K with a small C (weight gradients: K = rows of the batch) is cut into `ksplit`
 // slices whose partial tiles go to a workspace and are summed in a fixed order by a second kernel
 // (no float atomics: the result does not depend on scheduling).
+// Three arithmetic forms of the same kernel (template parameter PR): 0 = exact fp32 matrix instructions;
+// 1 = operands rounded to bf16 (v_mfma_f32_16x16x16_bf16, fp32 accumulation); 2 = fp32-accurate products on
+// the bf16 pipe: every operand is carried as hi = bf16(x), lo = bf16(x - hi) and a product is
+// lo.hi + hi.lo + hi.hi (relative error about 2^-17 per product, fp32 accumulation), three matrix
+// instructions of a quarter of the fp32 instruction's duration each in place of four fp32 ones.
 #include <hip/hip_runtime.h>
 
 #include "../../include/vtcnn_hip.h"
@@ -95,6 +100,47 @@ __device__ __forceinline__ unsigned short to_bf16(float x) {
   u += 0x7fffu + ((u >> 16) & 1u);
   return (unsigned short)(u >> 16);
 }
+__device__ __forceinline__ float from_bf16(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+// the same tile as hi / lo halves (form 2)
+template <bool ALONG_K, int R>
+__device__ __forceinline__ void store_tile_split(unsigned short (*Th)[GBK + HPAD], unsigned short (*Tl)[GBK + HPAD], bool vec,
+                                                 int tid, const float (&reg)[R / 16]) {
+  unsigned short h[R / 16], l[R / 16];
+#pragma unroll
+  for (int e = 0; e < R / 16; ++e) {
+    h[e] = to_bf16(reg[e]);
+    l[e] = to_bf16(reg[e] - from_bf16(h[e]));
+  }
+  if (vec) {
+#pragma unroll
+    for (int hb = 0; hb < R / 64; ++hb) {
+      if (ALONG_K) {
+        const int r = (tid >> 2) + 64 * hb, k = (tid & 3) * 4;
+        *reinterpret_cast<uint2 *>(&Th[r][k]) = make_uint2(h[4 * hb] | ((unsigned)h[4 * hb + 1] << 16), h[4 * hb + 2] | ((unsigned)h[4 * hb + 3] << 16));
+        *reinterpret_cast<uint2 *>(&Tl[r][k]) = make_uint2(l[4 * hb] | ((unsigned)l[4 * hb + 1] << 16), l[4 * hb + 2] | ((unsigned)l[4 * hb + 3] << 16));
+      } else {
+        const int k = tid >> 4, r = (tid & 15) * 4 + 64 * hb;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          Th[r + e][k] = h[4 * hb + e];
+          Tl[r + e][k] = l[4 * hb + e];
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < R / 16; ++e) {
+      const int idx = tid + e * 256;
+      if (ALONG_K) {
+        Th[idx >> 4][idx & (GBK - 1)] = h[e];
+        Tl[idx >> 4][idx & (GBK - 1)] = l[e];
+      } else {
+        Th[idx & (R - 1)][idx / R] = h[e];
+        Tl[idx & (R - 1)][idx / R] = l[e];
+      }
+    }
+  }
+}
 template <bool ALONG_K, int R>
 __device__ __forceinline__ void store_tile_bf16(unsigned short (*T)[GBK + HPAD], bool vec, int tid, const float (&reg)[R / 16]) {
   if (vec) {
@@ -123,13 +169,16 @@ __device__ __forceinline__ void store_tile_bf16(unsigned short (*T)[GBK + HPAD],
 // BM x BN: the workgroup's tile of C (64x64 for narrow or small products, 64x128 when only N is
 // wide, 128x128 for the wide shapes: each wave then owns 64x64 = 4x4 MFMA tiles and an LDS operand
 // read feeds four matrix instructions instead of two).
-template <bool TA, bool TB, bool BF, int BM, int BN>
+template <bool TA, bool TB, int PR, int BM, int BN>
 __global__ __launch_bounds__(256) void k_gemm(GemmP p) {
+  constexpr bool BF = PR != 0;
   constexpr int TM = BM / 32, TN = BN / 32;  // 16x16 tiles per wave along M and N (waves are laid out 2 x 2)
   __shared__ float As[BF ? 1 : GBK][BM + GPAD];
   __shared__ float Bs[BF ? 1 : GBK][BN + GPAD];
   __shared__ __attribute__((aligned(8))) unsigned short Ah[BF ? BM : 1][GBK + HPAD];
   __shared__ __attribute__((aligned(8))) unsigned short Bh[BF ? BN : 1][GBK + HPAD];
+  __shared__ __attribute__((aligned(8))) unsigned short Al[PR == 2 ? BM : 1][GBK + HPAD];
+  __shared__ __attribute__((aligned(8))) unsigned short Bl[PR == 2 ? BN : 1][GBK + HPAD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.z / p.ksplit, ks = blockIdx.z - b * p.ksplit;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;  // rows on x: the batch's pixel rows run into the millions
@@ -150,7 +199,10 @@ __global__ __launch_bounds__(256) void k_gemm(GemmP p) {
   load_tile<TB, BN>(B, p.ldb, n0, p.N, kbeg, kend, vecB, tid, rb);
   for (int k0 = kbeg; k0 < kend; k0 += GBK) {
     __syncthreads();  // the previous step's tile reads are over
-    if constexpr (BF) {
+    if constexpr (PR == 2) {
+      store_tile_split<!TA, BM>(Ah, Al, vecA, tid, ra);
+      store_tile_split<TB, BN>(Bh, Bl, vecB, tid, rb);
+    } else if constexpr (BF) {
       store_tile_bf16<!TA, BM>(Ah, vecA, tid, ra);
       store_tile_bf16<TB, BN>(Bh, vecB, tid, rb);
     } else {
@@ -162,7 +214,28 @@ __global__ __launch_bounds__(256) void k_gemm(GemmP p) {
       load_tile<!TA, BM>(A, p.lda, m0, p.M, k0 + GBK, kend, vecA, tid, ra);
       load_tile<TB, BN>(B, p.ldb, n0, p.N, k0 + GBK, kend, vecB, tid, rb);
     }
-    if constexpr (BF) {
+    if constexpr (PR == 2) {
+      const int kq = 4 * (lane >> 4), c = lane & 15;
+      s16x4 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        ah[i] = *reinterpret_cast<const s16x4 *>(&Ah[wm + 16 * i + c][kq]);
+        al[i] = *reinterpret_cast<const s16x4 *>(&Al[wm + 16 * i + c][kq]);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        bh[j] = *reinterpret_cast<const s16x4 *>(&Bh[wn + 16 * j + c][kq]);
+        bl[j] = *reinterpret_cast<const s16x4 *>(&Bl[wn + 16 * j + c][kq]);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {  // the two small terms first
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    } else if constexpr (BF) {
       const int kq = 4 * (lane >> 4), c = lane & 15;
       s16x4 av[TM], bv[TN];
 #pragma unroll
@@ -230,7 +303,7 @@ __global__ __launch_bounds__(256) void k_gemm_splitk_reduce(GemmP p, int batch) 
 
 using namespace vt;
 
-static int gemm_launch(bool bf16, int transA, int transB, int M, int N, int K, float alpha, const float *A, int lda,
+static int gemm_launch(int form, int transA, int transB, int M, int N, int K, float alpha, const float *A, int lda,
                        long strideA, const float *B, int ldb, long strideB, int accumulate, float *C, int ldc, long strideC,
                        const float *bias, int batch, float *workspace, long workspace_floats, vt_stream s) {
   if (M < 1 || N < 1 || K < 1 || batch < 1 || !A || !B || !C) return VT_EINVAL;
@@ -252,8 +325,11 @@ static int gemm_launch(bool bf16, int transA, int transB, int M, int N, int K, f
   const long tiles = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN) * batch;
   // a contraction that is long for the few output tiles it feeds: slice K so that several hundred
   // workgroups exist (a lone workgroup walking 1024 rows costs 50 us of pure latency)
-  if (workspace && K >= 256 && tiles < 256) {
-    long want = (1024 + tiles - 1) / tiles;
+  // (a very long one, e.g. a per-image contraction over 50176 pixels, is sliced up to twice as many tiles: 256
+  // workgroups walking 3136 K steps each leave three quarters of the chip's wave slots empty)
+  const long target = K >= 4096 ? 2048 : 1024;
+  if (workspace && K >= 256 && tiles * 4 <= target) {
+    long want = (target + tiles - 1) / tiles;
     const long most = K >= 4096 ? (K + 511) / 512 : K / 64;
     want = want < most ? want : most;
     const long fit = workspace_floats / ((long)M * N * batch);
@@ -276,17 +352,17 @@ static int gemm_launch(bool bf16, int transA, int transB, int M, int N, int K, f
     else if (BN == 128) hipLaunchKernelGGL((k_gemm<TA_, TB_, BF_, 64, 128>), grid, dim3(256), 0, hs, p);              \
     else hipLaunchKernelGGL((k_gemm<TA_, TB_, BF_, 64, 64>), grid, dim3(256), 0, hs, p);                             \
   } while (0)
-  if (bf16) {
-    if (transA && transB) VT_GEMM_LAUNCH(true, true, true);
-    else if (transA) VT_GEMM_LAUNCH(true, false, true);
-    else if (transB) VT_GEMM_LAUNCH(false, true, true);
-    else VT_GEMM_LAUNCH(false, false, true);
-  } else {
-    if (transA && transB) VT_GEMM_LAUNCH(true, true, false);
-    else if (transA) VT_GEMM_LAUNCH(true, false, false);
-    else if (transB) VT_GEMM_LAUNCH(false, true, false);
-    else VT_GEMM_LAUNCH(false, false, false);
-  }
+#define VT_GEMM_FORM(PR_)                                      \
+  do {                                                         \
+    if (transA && transB) VT_GEMM_LAUNCH(true, true, PR_);     \
+    else if (transA) VT_GEMM_LAUNCH(true, false, PR_);         \
+    else if (transB) VT_GEMM_LAUNCH(false, true, PR_);         \
+    else VT_GEMM_LAUNCH(false, false, PR_);                    \
+  } while (0)
+  if (form == 2) VT_GEMM_FORM(2);
+  else if (form == 1) VT_GEMM_FORM(1);
+  else VT_GEMM_FORM(0);
+#undef VT_GEMM_FORM
 #undef VT_GEMM_LAUNCH
   VT_CHECK_LAUNCH();
   if (p.ksplit > 1 && !bias && !accumulate && ldc == N && (batch == 1 || strideC == (long)M * N) &&
@@ -306,7 +382,7 @@ static int gemm_launch(bool bf16, int transA, int transB, int M, int N, int K, f
 extern "C" int vt_gemm_f32(int transA, int transB, int M, int N, int K, float alpha, const float *A, int lda, long strideA,
                            const float *B, int ldb, long strideB, int accumulate, float *C, int ldc, long strideC,
                            const float *bias, int batch, float *workspace, long workspace_floats, vt_stream s) {
-  return gemm_launch(false, transA, transB, M, N, K, alpha, A, lda, strideA, B, ldb, strideB, accumulate, C, ldc, strideC, bias,
+  return gemm_launch(0, transA, transB, M, N, K, alpha, A, lda, strideA, B, ldb, strideB, accumulate, C, ldc, strideC, bias,
                      batch, workspace, workspace_floats, s);
 }
 
@@ -314,6 +390,13 @@ extern "C" int vt_gemm_bf16_mfma(int transA, int transB, int M, int N, int K, fl
                                  long strideA, const float *B, int ldb, long strideB, int accumulate, float *C, int ldc,
                                  long strideC, const float *bias, int batch, float *workspace, long workspace_floats,
                                  vt_stream s) {
-  return gemm_launch(true, transA, transB, M, N, K, alpha, A, lda, strideA, B, ldb, strideB, accumulate, C, ldc, strideC, bias,
+  return gemm_launch(1, transA, transB, M, N, K, alpha, A, lda, strideA, B, ldb, strideB, accumulate, C, ldc, strideC, bias,
+                     batch, workspace, workspace_floats, s);
+}
+
+extern "C" int vt_gemm_f32x3(int transA, int transB, int M, int N, int K, float alpha, const float *A, int lda, long strideA,
+                             const float *B, int ldb, long strideB, int accumulate, float *C, int ldc, long strideC,
+                             const float *bias, int batch, float *workspace, long workspace_floats, vt_stream s) {
+  return gemm_launch(2, transA, transB, M, N, K, alpha, A, lda, strideA, B, ldb, strideB, accumulate, C, ldc, strideC, bias,
                      batch, workspace, workspace_floats, s);
 }

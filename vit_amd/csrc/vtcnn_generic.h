@@ -32,5 +32,7 @@ int gen_forward(GenModel *g, const float *arena, const vt_layout *lo, float *are
 // phase bit 0: everything but the attention block; bit 1: the attention block (mha.q*/k*/v* gradients)
 int gen_backward(GenModel *g, const float *arena, const vt_layout *lo, float *grads, const float *X, const int *labels, int n,
                  int phase, hipStream_t s);
+// fills g->du (the dense delta behind the pooling layer) from the last backward's window records
+int gen_expand_du(GenModel *g, const float *arena, const vt_layout *lo, int n, hipStream_t s);
 
 }  // namespace vt

@@ -486,6 +486,117 @@ __global__ __launch_bounds__(GT) void k_pool_bwd(const float *__restrict__ z, co
   }
 }
 
+// The same delta without the dense array: the projector's BatchNorm backward reads it twice (its two column
+// sums, then din = delta * scale + shift), and only one element per pooling window is not zero, so both passes
+// form the delta on the fly from the window records (delta, arg-max offset, pooled maximum; the ReLU let the
+// arg-max through exactly when the pooled maximum is positive).  Threads are laid out as in the other column
+// kernels over the row matrix [R, C2]: VEC adjacent columns per thread, walking down the rows; element (r, c)
+// is flat position F = r * C2 + c of the [N, C2, H, W] reinterpretation, i.e. plane F / P at offset F % P,
+// which the walk carries along instead of dividing.
+struct PoolGeo {
+  int P, W, pk, quad;  // quad: W and pk multiples of 4, so four adjacent flat positions share a window
+};
+template <int VEC>
+__device__ __forceinline__ void window_delta(long nc, int pos, const PoolGeo pg, const float *__restrict__ dpool,
+                                             const float *__restrict__ pooled, const int *__restrict__ pool_idx,
+                                             float (&d)[VEC]) {
+  if (VEC == 4 && pg.quad) {
+    const int h = pos / pg.W, w = pos - h * pg.W;
+    const long win = nc * 196 + (h / pg.pk) * 14 + w / pg.pk;
+    const unsigned off = (unsigned)(pool_idx[win] - pos);
+    float v = 0.f;
+    if (off < 4u && pooled[win] > 0.f) v = dpool[win];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) d[e] = off == (unsigned)e ? v : 0.f;
+    return;
+  }
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    long n2 = nc;
+    int p2 = pos + e;
+    if (p2 >= pg.P) {  // VEC <= 4 <= P: at most one plane further
+      p2 -= pg.P;
+      ++n2;
+    }
+    const int h = p2 / pg.W, w = p2 - h * pg.W;
+    const long win = n2 * 196 + (h / pg.pk) * 14 + w / pg.pk;
+    d[e] = (pool_idx[win] == p2 && pooled[win] > 0.f) ? dpool[win] : 0.f;
+  }
+}
+
+// MODE 0: part[b][0][c] = sum delta, part[b][1][c] = sum delta * xhat (the record k_bnbwd_partial writes);
+// MODE 1: dz = delta * coef[c] + coef[C2 + c]
+template <int VEC, int MODE>
+__global__ __launch_bounds__(GT) void k_pool_delta(const float *__restrict__ z, const float *__restrict__ stat_or_coef,
+                                                   const float *__restrict__ dpool, const float *__restrict__ pooled,
+                                                   const int *__restrict__ pool_idx, long R, int C2, int rpb, ColGeo geo,
+                                                   PoolGeo pg, float *__restrict__ out) {
+  __shared__ float sh[MODE == 0 ? 2 : 1][MODE == 0 ? GT * VEC : 1];
+  const int tx = threadIdx.x % geo.tx_n, ty = threadIdx.x / geo.tx_n;
+  const long r0 = (long)blockIdx.x * rpb, r1 = r0 + rpb < R ? r0 + rpb : R;
+  const bool lane_on = ty < geo.ty_n;
+  const int step = geo.ty_n * C2;
+  for (int g0 = 0; g0 < geo.groups; g0 += geo.tx_n) {
+    const int grp = g0 + tx;
+    const bool on = lane_on && grp < geo.groups;
+    float s1[VEC], s2[VEC], pa[VEC], pb[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      s1[e] = s2[e] = 0.f;
+      pa[e] = on ? stat_or_coef[grp * VEC + e] : 0.f;       // mean | scale
+      pb[e] = on ? stat_or_coef[C2 + grp * VEC + e] : 0.f;  // 1/sigma | shift
+    }
+    if (on) {
+      const long F0 = (r0 + ty) * C2 + (long)grp * VEC;
+      long nc = F0 / pg.P;
+      int pos = (int)(F0 - nc * pg.P);
+      for (long r = r0 + ty; r < r1; r += geo.ty_n) {
+        float d[VEC];
+        window_delta<VEC>(nc, pos, pg, dpool, pooled, pool_idx, d);
+        if (MODE == 0) {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e)
+            if (d[e] != 0.f) {
+              s1[e] += d[e];
+              s2[e] += d[e] * ((z[r * C2 + grp * VEC + e] - pa[e]) * pb[e]);
+            }
+        } else {
+          Vecf<VEC> o;
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) o.v[e] = d[e] * pa[e] + pb[e];
+          stv<VEC>(out + r * C2 + (size_t)grp * VEC, o);
+        }
+        pos += step;
+        while (pos >= pg.P) {
+          pos -= pg.P;
+          ++nc;
+        }
+      }
+    }
+    if (MODE == 0) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        sh[0][threadIdx.x * VEC + e] = s1[e];
+        sh[1][threadIdx.x * VEC + e] = s2[e];
+      }
+      __syncthreads();
+      if (on && ty == 0) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          float t1 = 0.f, t2 = 0.f;
+          for (int k = 0; k < geo.ty_n; ++k) {
+            t1 += sh[0][(k * geo.tx_n + tx) * VEC + e];
+            t2 += sh[1][(k * geo.tx_n + tx) * VEC + e];
+          }
+          out[(size_t)blockIdx.x * 2 * C2 + grp * VEC + e] = t1;
+          out[(size_t)blockIdx.x * 2 * C2 + C2 + grp * VEC + e] = t2;
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
 // SoftmaxLayer::backward with targets (layers/softmax_layer.hpp:29): probs - onehot
 __global__ __launch_bounds__(GT) void k_dlogits(const float *__restrict__ probs, const int *__restrict__ labels,
                                                 float *__restrict__ dl, int total, int K) {
@@ -508,6 +619,7 @@ struct Gemm {
   vt::GenModel *g;
   hipStream_t s;
   bool reduced_ok = true;  // false: every product of this pass stays fp32 even in the reduced-precision mode
+  bool exact = false;      // true: exact fp32 matrix instructions (the product feeds an exponential)
   // C = alpha * op(A).op(B) (+bias) (+C)
   int operator()(bool ta, bool tb, int M, int N, int K, const float *A, int lda, const float *B, int ldb, float *C, int ldc,
                  const float *bias = nullptr, bool acc = false, float alpha = 1.f, int batch = 1, long sA = 0, long sB = 0,
@@ -517,7 +629,15 @@ struct Gemm {
     // the backward pass and the gradient contractions over the batch's rows stay in fp32: bf16 noise on the
     // deltas is amplified by the BatchNorm backward differences on its way to the first layers (conv.W ended
     // 6e-2 from exact arithmetic with them in bf16, against the 1e-2 stated for the mode)
-    auto fn = (g->bf16 && reduced_ok && !ta) ? vt_gemm_bf16_mfma : vt_gemm_f32;
+    // fp32 mode: products at least 32 deep that contract over features (not over the batch's rows) and do not feed
+    // an exponential run as bf16 hi/lo split products (fp32 accuracy to about 2^-17 per product, a third of the
+    // matrix-pipe time); everything else on exact fp32 matrix instructions
+    static const bool all_exact = [] {
+      const char *e = getenv("VT_GEMM_EXACT");
+      return e && *e && *e != '0';
+    }();
+    auto fn = (g->bf16 && reduced_ok && !ta) ? vt_gemm_bf16_mfma
+              : (!exact && !all_exact && K >= 32) ? vt_gemm_f32x3 : vt_gemm_f32;
     return fn(ta, tb, M, N, K, alpha, A, lda, sA, B, ldb, sB, acc, C, ldc, sC, bias, batch, g->ws, g->ws_floats, (vt_stream)s);
   }
 };
@@ -593,6 +713,36 @@ int col_sums(vt::GenModel *g, const float *dY, long R, int C, float *out, hipStr
   int nb = 0;
   VTG(bnbwd_partial(g, dY, nullptr, nullptr, R, C, &nb, s));
   return vt_reduce_rows(g->part, nb, C, 2 * C, out, (vt_stream)s);
+}
+
+// max-pool scatter + ReLU mask (pooling_layer.hpp:68-97, relu_layer.hpp:20-33) and the projector's BatchNorm
+// backward (batch_normalization_layer.hpp:172-200) without the dense delta in between: two passes over the
+// window records (column sums, then din), the second writing dz
+int pool_bn_backward(vt::GenModel *g, const float *gamma, float *ggamma, float *gbeta, int n, hipStream_t s) {
+  const int C2 = g->C2;
+  const long R = (long)n * g->P;
+  const ColGeo geo = col_geo(C2);
+  const PoolGeo pg{g->P, g->H, g->pk, (g->H % 4 == 0 && g->pk % 4 == 0) ? 1 : 0};
+  const int rpb = rows_per_block(R), nb = (int)((R + rpb - 1) / rpb);
+  if ((long)nb * 2 * C2 > g->part_floats) return VT_EUNSUPPORTED;
+  if (geo.vec == 4)
+    hipLaunchKernelGGL((k_pool_delta<4, 0>), dim3(nb), dim3(GT), 0, s, g->z, g->stat_pn, g->dpool, g->pooled, g->pool_idx, R, C2,
+                       rpb, geo, pg, g->part);
+  else
+    hipLaunchKernelGGL((k_pool_delta<1, 0>), dim3(nb), dim3(GT), 0, s, g->z, g->stat_pn, g->dpool, g->pooled, g->pool_idx, R, C2,
+                       rpb, geo, pg, g->part);
+  VT_CHECK_LAUNCH();
+  VTG(vt_bn_bwd_finalize(g->part, nb, C2, R, gamma, g->stat_pn, g->z, ggamma, gbeta, g->coef, (vt_stream)s));
+  const int arpb = stream_rpb(C2, geo);
+  const dim3 grid((unsigned)((R + arpb - 1) / arpb));
+  if (geo.vec == 4)
+    hipLaunchKernelGGL((k_pool_delta<4, 1>), grid, dim3(GT), 0, s, g->z, g->coef, g->dpool, g->pooled, g->pool_idx, R, C2, arpb,
+                       geo, pg, g->dz);
+  else
+    hipLaunchKernelGGL((k_pool_delta<1, 1>), grid, dim3(GT), 0, s, g->z, g->coef, g->dpool, g->pooled, g->pool_idx, R, C2, arpb,
+                       geo, pg, g->dz);
+  VT_CHECK_LAUNCH();
+  return 0;
 }
 
 int ewise(const float *a, const float *b, float *out, long total, int op, hipStream_t s) {
@@ -721,7 +871,9 @@ int gen_forward(GenModel *g, const float *arena, const vt_layout *lo, float *are
   // mm_bf: the dense-layer products the reduced-precision mode sends through bf16 (feed-forward block, projector
   // linear1 / linear2 / linear3, classifier); everything else (the convolution, products that feed an
   // exponential, activation x activation products) stays fp32
-  const Gemm mm{g, s, false}, mm_exact{g, s, false}, mm_bf{g, s, true};
+  // mm_bf_exact: bf16 in the reduced-precision mode, exact fp32 otherwise (queries and keys of the projector: their
+  // scores feed an exponential)
+  const Gemm mm{g, s, false}, mm_exact{g, s, false, true}, mm_bf{g, s, true}, mm_bf_exact{g, s, true, true};
   // Conv2DLayer::forward as im2col x W^T (conv2d_layer.hpp:35-87); output pixel-major [N*P, C1]
   hipLaunchKernelGGL(k_im2col, dim3(nblk(NP * CK)), dim3(GT), 0, s, X, g->col, NP * CK, g->Ci, g->H, g->H);
   VT_CHECK_LAUNCH();
@@ -746,8 +898,8 @@ int gen_forward(GenModel *g, const float *arena, const vt_layout *lo, float *are
   VTG(bn_stats(g, g->s2, NL, D, RW("norm2.running_mean"), RW("norm2.running_var"), g->stat_n2, false, s));
   VTG(col_affine(0, g->s2, g->stat_n2, W("norm2.gamma"), W("norm2.beta"), g->o, NL, D, s));
   // ProjectorLayer::forward (projector_layer.hpp:43-116)
-  VTG(mm_bf(false, false, (int)NP, D, C1, g->x, C1, W("proj.linear1.W"), D, g->q, D));
-  VTG(mm_bf(false, false, (int)NL, D, D, g->o, D, W("proj.linear2.W"), D, g->k, D));
+  VTG(mm_bf_exact(false, false, (int)NP, D, C1, g->x, C1, W("proj.linear1.W"), D, g->q, D));
+  VTG(mm_bf_exact(false, false, (int)NL, D, D, g->o, D, W("proj.linear2.W"), D, g->k, D));
   VTG(mm_bf(false, false, (int)NL, C2, D, g->o, D, W("proj.linear3.W"), C2, g->v, C2, W("proj.linear3.b")));
   VTG(mm(false, false, (int)NP, C2, C1, g->x, C1, W("proj.downsample.W"), C2, g->z, C2, W("proj.downsample.b")));
   VTG(mm_exact(false, true, P, L, D, g->q, D, g->k, D, g->pa, L, nullptr, false, 1.f, n, (long)P * D, (long)L * D, (long)P * L));
@@ -778,7 +930,7 @@ int gen_backward(GenModel *g, const float *arena, const vt_layout *lo, float *gr
   const long NP = (long)n * P, NL = (long)n * L;
   auto W = [&](const char *name) { return arena + lo->t[vt_find(lo, name)].offset; };
   auto G = [&](const char *name) { return grads + lo->t[vt_find(lo, name)].offset; };
-  const Gemm mm{g, s, false}, mm_fwd{g, s, true};
+  const Gemm mm{g, s, false}, mm_fwd{g, s, true}, mm_exact{g, s, false, true}, mm_fwd_exact{g, s, true, true};
   if (phase & 1) {
     // softmax - onehot, fc (softmax_layer.hpp:29, dense_layer.hpp:92-99)
     hipLaunchKernelGGL(k_dlogits, dim3((n * K + GT - 1) / GT), dim3(GT), 0, s, g->probs, labels, g->dlogits, n * K, K);
@@ -786,16 +938,10 @@ int gen_backward(GenModel *g, const float *arena, const vt_layout *lo, float *gr
     VTG(mm(true, false, Q, K, n, g->pooled, Q, g->dlogits, K, G("fc.W"), K));
     VTG(col_sums(g, g->dlogits, n, K, G("fc.b"), s));
     VTG(mm(false, true, n, Q, K, g->dlogits, K, W("fc.W"), K, g->dpool, Q));
-    // max-pool scatter + ReLU mask (pooling_layer.hpp:68-97, relu_layer.hpp:20-33)
-    {
-      const long rows = (long)n * C2 * g->H;
-      hipLaunchKernelGGL(k_pool_bwd, dim3((unsigned)((rows + 3) / 4)), dim3(GT), 0, s, g->z, g->stat_pn, W("proj.norm.gamma"),
-                         W("proj.norm.beta"), g->dpool, g->pool_idx, g->du, rows, C2, g->H, g->pk);
-      VT_CHECK_LAUNCH();
-    }
+    // max-pool scatter + ReLU mask and the projector's BatchNorm backward; the dense delta of the pooling layer
+    // is only formed on request (gen_expand_du)
     // ProjectorLayer::backward (projector_layer.hpp:118-214)
-    VTG(bn_backward(g, g->du, g->z, g->stat_pn, W("proj.norm.gamma"), NP, C2, G("proj.norm.gamma"), G("proj.norm.beta"),
-                    g->coef, g->dz, s));
+    VTG(pool_bn_backward(g, W("proj.norm.gamma"), G("proj.norm.gamma"), G("proj.norm.beta"), n, s));
     VTG(mm(true, false, C1, C2, (int)NP, g->x, C1, g->dz, C2, G("proj.downsample.W"), C2));
     VTG(col_sums(g, g->dz, NP, C2, G("proj.downsample.b"), s));
     VTG(mm(false, true, (int)NP, C1, C2, g->dz, C2, W("proj.downsample.W"), C2, g->pdx, C1));
@@ -858,10 +1004,11 @@ int gen_backward(GenModel *g, const float *arena, const vt_layout *lo, float *gr
     for (int h = 0; h < g->heads; ++h) {
       const std::string hs = std::to_string(h);
       const std::string nq = "mha.q" + hs + ".W", nk = "mha.k" + hs + ".W", nv = "mha.v" + hs + ".W";
-      VTG(mm_fwd(false, false, (int)NL, hd, D, g->tok, D, W(nq.c_str()), hd, g->Qm, hd));
-      VTG(mm_fwd(false, false, (int)NL, hd, D, g->tok, D, W(nk.c_str()), hd, g->Km, hd));
+      // queries, keys and their scores feed the softmax's exponential: exact fp32
+      VTG(mm_fwd_exact(false, false, (int)NL, hd, D, g->tok, D, W(nq.c_str()), hd, g->Qm, hd));
+      VTG(mm_fwd_exact(false, false, (int)NL, hd, D, g->tok, D, W(nk.c_str()), hd, g->Km, hd));
       VTG(mm_fwd(false, false, (int)NL, hd, D, g->tok, D, W(nv.c_str()), hd, g->Vm, hd));
-      VTG(mm(false, true, n, n, hd, g->Km, hd, g->Qm, hd, g->attn, n, nullptr, false, scale, L, sG, sG, sS));
+      VTG(mm_exact(false, true, n, n, hd, g->Km, hd, g->Qm, hd, g->attn, n, nullptr, false, scale, L, sG, sG, sS));
       VTG(softmax_rows(g->attn, NL, n, s));
       const float *dhd = g->dc + h * hd;  // this head's columns of the concat delta, row stride D
       VTG(mm(false, true, n, n, hd, dhd, D, g->Vm, hd, g->dat, n, nullptr, false, 1.f, L, (long)n * D, sG, sS));
@@ -875,6 +1022,17 @@ int gen_backward(GenModel *g, const float *arena, const vt_layout *lo, float *gr
     }
   }
   (void)X;
+  return 0;
+}
+
+// MaxPool2DLayer::backward + ReLU mask as the dense array [n*P, C2] the reference holds between the pooling
+// layer and the projector (vit_cnn.hpp:225-233); the step itself never needs it
+int gen_expand_du(GenModel *g, const float *arena, const vt_layout *lo, int n, hipStream_t s) {
+  auto W = [&](const char *name) { return arena + lo->t[vt_find(lo, name)].offset; };
+  const long rows = (long)n * g->C2 * g->H;
+  hipLaunchKernelGGL(k_pool_bwd, dim3((unsigned)((rows + 3) / 4)), dim3(GT), 0, s, g->z, g->stat_pn, W("proj.norm.gamma"),
+                     W("proj.norm.beta"), g->dpool, g->pool_idx, g->du, rows, g->C2, g->H, g->pk);
+  VT_CHECK_LAUNCH();
   return 0;
 }
 

@@ -1276,6 +1276,9 @@ extern "C" long vt_model_read(vt_model *m, const char *name, float *host, long c
         hipDeviceSynchronize() != hipSuccess)
       return VT_EINVAL;
   }
+  if (m->gen && src == m->gen->du && m->lastN > 0) {  // likewise for the general-shape step
+    if (gen_expand_du(m->gen, m->arena, &m->lo, m->lastN, nullptr) != 0 || hipDeviceSynchronize() != hipSuccess) return VT_EINVAL;
+  }
   if (hipMemcpy(host, src, cnt * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return VT_EINVAL;
   return cnt;
 }
