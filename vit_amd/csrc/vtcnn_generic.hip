@@ -77,59 +77,78 @@ __global__ __launch_bounds__(GT) void k_im2col(const float *__restrict__ X, floa
 }
 
 // ---- per-column partial statistics of a row matrix: part[b][0][c] = sum, part[b][1][c] = sum of
-// squared distances from the block's own mean (merged by vt_bn_stats_finalize) ---------------------
+// squared distances from the block's own mean (merged by vt_bn_stats_finalize).  One pass over the rows: a
+// thread accumulates sum and sum of squares of (x - pivot), pivot = the first value it meets (so the squares
+// stay of the order of the variance, not of the mean), and the row lanes of a column group are then merged
+// pairwise-exactly (Chan's update) in lane order. ------------------------------------------------------------
 template <int VEC>
 __global__ __launch_bounds__(GT) void k_colstats(const float *__restrict__ in, long R, int C, int rpb, ColGeo geo,
                                                  float *__restrict__ part) {
-  __shared__ float sh[GT * VEC];
+  __shared__ float sh[2][GT * VEC];
   const int tx = threadIdx.x % geo.tx_n, ty = threadIdx.x / geo.tx_n;
   const long r0 = (long)blockIdx.x * rpb, r1 = r0 + rpb < R ? r0 + rpb : R;
-  const float inv_cnt = 1.0f / (float)(r1 - r0);
+  const long cnt = r1 - r0;
   const bool lane_on = ty < geo.ty_n;
   for (int g0 = 0; g0 < geo.groups; g0 += geo.tx_n) {
     const int grp = g0 + tx;
     const bool on = lane_on && grp < geo.groups;
     const float *__restrict__ base = in + (size_t)grp * VEC;
-    float s[VEC], q[VEC];
+    float s[VEC], q[VEC], pv[VEC];
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) s[e] = q[e] = 0.f;
-    if (on)
-      for (long r = r0 + ty; r < r1; r += geo.ty_n) {
-        const Vecf<VEC> x = ldv<VEC>(base + r * C);
+    for (int e = 0; e < VEC; ++e) s[e] = q[e] = pv[e] = 0.f;
+    if (on && r0 + ty < r1) {
+      const Vecf<VEC> x0 = ldv<VEC>(base + (r0 + ty) * C);
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) s[e] += x.v[e];
+      for (int e = 0; e < VEC; ++e) pv[e] = x0.v[e];
+      long r = r0 + ty;
+      for (; r + 3L * geo.ty_n < r1; r += 4L * geo.ty_n) {  // four loads in flight
+        Vecf<VEC> x[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) x[k] = ldv<VEC>(base + (r + (long)k * geo.ty_n) * C);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+            const float d = x[k].v[e] - pv[e];
+            s[e] += d;
+            q[e] += d * d;
+          }
       }
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) sh[threadIdx.x * VEC + e] = s[e];
-    __syncthreads();
-    float mu[VEC];
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) {  // every thread of a column group forms the group's block sum
-      float t = 0.f;
-      for (int k = 0; k < geo.ty_n; ++k) t += sh[(k * geo.tx_n + tx) * VEC + e];
-      s[e] = t;
-      mu[e] = t * inv_cnt;
-    }
-    __syncthreads();
-    if (on)
-      for (long r = r0 + ty; r < r1; r += geo.ty_n) {
+      for (; r < r1; r += geo.ty_n) {
         const Vecf<VEC> x = ldv<VEC>(base + r * C);
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
-          const float d = x.v[e] - mu[e];
+          const float d = x.v[e] - pv[e];
+          s[e] += d;
           q[e] += d * d;
         }
       }
+    }
+    // the lane's own rows: r0 + ty, r0 + ty + ty_n, ...
+    const long nl = ty < cnt ? (cnt - ty + geo.ty_n - 1) / geo.ty_n : 0;
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) sh[threadIdx.x * VEC + e] = q[e];
+    for (int e = 0; e < VEC; ++e) {
+      const float m2 = nl > 0 ? q[e] - s[e] * s[e] / (float)nl : 0.f;  // about the lane's own mean
+      sh[0][threadIdx.x * VEC + e] = s[e] + (float)nl * pv[e];         // the lane's sum
+      sh[1][threadIdx.x * VEC + e] = m2 > 0.f ? m2 : 0.f;
+    }
     __syncthreads();
     if (on && ty == 0) {
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
-        float t = 0.f;
-        for (int k = 0; k < geo.ty_n; ++k) t += sh[(k * geo.tx_n + tx) * VEC + e];
-        part[(size_t)blockIdx.x * 2 * C + grp * VEC + e] = s[e];
-        part[(size_t)blockIdx.x * 2 * C + C + grp * VEC + e] = t;
+        float tot = 0.f;
+        for (int k = 0; k < geo.ty_n; ++k) tot += sh[0][(k * geo.tx_n + tx) * VEC + e];
+        const float mean = tot / (float)cnt;
+        float m2 = 0.f;
+        for (int k = 0; k < geo.ty_n; ++k) {
+          const long nk = k < cnt ? (cnt - k + geo.ty_n - 1) / geo.ty_n : 0;
+          if (nk > 0) {
+            const float dm = sh[0][(k * geo.tx_n + tx) * VEC + e] / (float)nk - mean;
+            m2 += sh[1][(k * geo.tx_n + tx) * VEC + e] + (float)nk * dm * dm;
+          }
+        }
+        part[(size_t)blockIdx.x * 2 * C + grp * VEC + e] = tot;
+        part[(size_t)blockIdx.x * 2 * C + C + grp * VEC + e] = m2;
       }
     }
     __syncthreads();
@@ -597,6 +616,20 @@ __global__ __launch_bounds__(GT) void k_pool_delta(const float *__restrict__ z, 
   }
 }
 
+// Column sums of a BatchNorm backward's output (the bias gradient of the DenseLayer or convolution in front of
+// it, dense_layer.hpp:95-96) without reading it: with din = delta * gamma * inv + k1 + k2 as in
+// vt_bn_bwd_finalize, the first and the last term cancel over the rows (R * k2 = -gamma * inv * sum delta) and
+// what is left is R * k1 = 2 * dvar * (x[row 0] - mean), dvar = -0.5 * gamma * inv^2 * sum(delta * xhat).
+__global__ __launch_bounds__(GT) void k_bn_din_colsum(const float *__restrict__ gamma, const float *__restrict__ stat,
+                                                      const float *__restrict__ in_row0, const float *__restrict__ ggamma,
+                                                      int C, float *__restrict__ out) {
+  const int c = blockIdx.x * GT + threadIdx.x;
+  if (c >= C) return;
+  const float inv = stat[C + c];
+  const float dvar = -0.5f * gamma[c] * inv * inv * ggamma[c];
+  out[c] = (dvar * 2.0f) * (in_row0[c] - stat[c]);
+}
+
 // SoftmaxLayer::backward with targets (layers/softmax_layer.hpp:29): probs - onehot
 __global__ __launch_bounds__(GT) void k_dlogits(const float *__restrict__ probs, const int *__restrict__ labels,
                                                 float *__restrict__ dl, int total, int K) {
@@ -700,11 +733,19 @@ int bn_stats(vt::GenModel *g, const float *in, long R, int C, float *run_mean, f
 
 // BatchNormLayer1D / BatchNorm2DLayer::backward (batch_normalization_layer.hpp:172-200, 300-327):
 // gradients of gamma / beta and din = delta * scale + shift with the row-0 variance term
+// din_colsum (may be NULL): the column sums of din, i.e. the bias gradient of the layer that produced `in`
+int bn_din_colsum(const float *gamma, const float *stat, const float *in, const float *ggamma, int C, float *out, hipStream_t s) {
+  hipLaunchKernelGGL(k_bn_din_colsum, dim3((C + GT - 1) / GT), dim3(GT), 0, s, gamma, stat, in, ggamma, C, out);
+  VT_CHECK_LAUNCH();
+  return 0;
+}
+
 int bn_backward(vt::GenModel *g, const float *delta, const float *in, const float *stat, const float *gamma, long R, int C,
-                float *ggamma, float *gbeta, float *coef, float *din, hipStream_t s) {
+                float *ggamma, float *gbeta, float *coef, float *din, hipStream_t s, float *din_colsum = nullptr) {
   int nb = 0;
   VTG(bnbwd_partial(g, delta, in, stat, R, C, &nb, s));
   VTG(vt_bn_bwd_finalize(g->part, nb, C, R, gamma, stat, in, ggamma, gbeta, coef, (vt_stream)s));
+  if (din_colsum) VTG(bn_din_colsum(gamma, stat, in, ggamma, C, din_colsum, s));
   return col_affine(1, delta, coef, nullptr, nullptr, din, R, C, s);
 }
 
@@ -718,7 +759,8 @@ int col_sums(vt::GenModel *g, const float *dY, long R, int C, float *out, hipStr
 // max-pool scatter + ReLU mask (pooling_layer.hpp:68-97, relu_layer.hpp:20-33) and the projector's BatchNorm
 // backward (batch_normalization_layer.hpp:172-200) without the dense delta in between: two passes over the
 // window records (column sums, then din), the second writing dz
-int pool_bn_backward(vt::GenModel *g, const float *gamma, float *ggamma, float *gbeta, int n, hipStream_t s) {
+int pool_bn_backward(vt::GenModel *g, const float *gamma, float *ggamma, float *gbeta, float *din_colsum, int n,
+                     hipStream_t s) {
   const int C2 = g->C2;
   const long R = (long)n * g->P;
   const ColGeo geo = col_geo(C2);
@@ -733,6 +775,7 @@ int pool_bn_backward(vt::GenModel *g, const float *gamma, float *ggamma, float *
                        rpb, geo, pg, g->part);
   VT_CHECK_LAUNCH();
   VTG(vt_bn_bwd_finalize(g->part, nb, C2, R, gamma, g->stat_pn, g->z, ggamma, gbeta, g->coef, (vt_stream)s));
+  VTG(bn_din_colsum(gamma, g->stat_pn, g->z, ggamma, C2, din_colsum, s));
   const int arpb = stream_rpb(C2, geo);
   const dim3 grid((unsigned)((R + arpb - 1) / arpb));
   if (geo.vec == 4)
@@ -941,9 +984,9 @@ int gen_backward(GenModel *g, const float *arena, const vt_layout *lo, float *gr
     // max-pool scatter + ReLU mask and the projector's BatchNorm backward; the dense delta of the pooling layer
     // is only formed on request (gen_expand_du)
     // ProjectorLayer::backward (projector_layer.hpp:118-214)
-    VTG(pool_bn_backward(g, W("proj.norm.gamma"), G("proj.norm.gamma"), G("proj.norm.beta"), n, s));
+    // (the downsample bias gradient, the column sums of dz, comes out of the BatchNorm backward's own sums)
+    VTG(pool_bn_backward(g, W("proj.norm.gamma"), G("proj.norm.gamma"), G("proj.norm.beta"), G("proj.downsample.b"), n, s));
     VTG(mm(true, false, C1, C2, (int)NP, g->x, C1, g->dz, C2, G("proj.downsample.W"), C2));
-    VTG(col_sums(g, g->dz, NP, C2, G("proj.downsample.b"), s));
     VTG(mm(false, true, (int)NP, C1, C2, g->dz, C2, W("proj.downsample.W"), C2, g->pdx, C1));
     // delta of the attention map, softmax backward over tokens, deltas of q / k / v
     VTG(mm(false, true, P, L, C2, g->dz, C2, g->v, C2, g->dsa, L, nullptr, false, 1.f, n, (long)P * C2, (long)L * C2,
@@ -966,9 +1009,8 @@ int gen_backward(GenModel *g, const float *arena, const vt_layout *lo, float *gr
     // (visual_transformer.hpp:153-157, transformer_layer.hpp:133-207); no ReLU derivative (:174-181)
     VTG(ewise(g->o, g->pdt, g->d0, NL * D, 1, s));
     VTG(bn_backward(g, g->d0, g->s2, g->stat_n2, W("norm2.gamma"), NL, D, G("norm2.gamma"), G("norm2.beta"), g->coef, g->ds2,
-                    s));
+                    s, G("ffn.linear2.b")));
     VTG(mm(true, false, D, D, (int)NL, g->rl, D, g->ds2, D, G("ffn.linear2.W"), D));
-    VTG(col_sums(g, g->ds2, NL, D, G("ffn.linear2.b"), s));
     VTG(mm(false, true, (int)NL, D, D, g->ds2, D, W("ffn.linear2.W"), D, g->dh, D));
     VTG(mm(true, false, D, D, (int)NL, g->a, D, g->dh, D, G("ffn.linear1.W"), D));
     VTG(col_sums(g, g->dh, NL, D, G("ffn.linear1.b"), s));
@@ -991,9 +1033,9 @@ int gen_backward(GenModel *g, const float *arena, const vt_layout *lo, float *gr
     VTG(mm(false, true, (int)NP, C1, L, g->dsa, L, W("tok.linear1.W"), L, g->pdx, C1, nullptr, true));
     // BatchNorm2DLayer::backward + Conv2DLayer::backward gradients (batch_normalization_layer.hpp:300-327,
     // conv2d_layer.hpp:115-147); the conv input delta is never consumed
-    VTG(bn_backward(g, g->pdx, g->conv, g->stat_bn, W("bn.gamma"), NP, C1, G("bn.gamma"), G("bn.beta"), g->coef, g->tdx, s));
+    VTG(bn_backward(g, g->pdx, g->conv, g->stat_bn, W("bn.gamma"), NP, C1, G("bn.gamma"), G("bn.beta"), g->coef, g->tdx, s,
+                    G("conv.b")));
     VTG(mm(true, false, C1, CK, (int)NP, g->tdx, C1, g->col, CK, G("conv.W"), CK));
-    VTG(col_sums(g, g->tdx, NP, C1, G("conv.b"), s));
   }
   if (phase & 2) {
     // MultiHeadAttention::backward (multi_head_attention.hpp:109-193): L groups of n consecutive token
