@@ -469,11 +469,24 @@ int vt_gemm_bf16_mfma(int transA, int transB, int M, int N, int K, float alpha, 
  * lo = bf16(x - hi), a product is lo.hi + hi.lo + hi.hi (three v_mfma_f32_16x16x16_bf16 with fp32
  * accumulation; relative error about 2^-17 per product, random in sign) instead of four fp32 matrix
  * instructions of four times the duration.  What the general-shape step uses for its activation x weight and
- * delta x weight products of depth >= 32 (not for products that feed an exponential, nor for the gradient
- * contractions over the batch's rows); VT_GEMM_EXACT=1 in the environment keeps every product on vt_gemm_f32. */
+ * delta x weight products and its gradient contractions of depth >= 32 (not for products that feed an
+ * exponential); VT_GEMM_EXACT=1 in the environment keeps every product on vt_gemm_f32. */
 int vt_gemm_f32x3(int transA, int transB, int M, int N, int K, float alpha, const float *A, int lda, long strideA,
                   const float *B, int ldb, long strideB, int accumulate, float *C, int ldc, long strideC,
                   const float *bias, int batch, float *workspace, long workspace_floats, vt_stream s);
+/* A sum of up to four such products into one result, the partial sums staying in registers:
+ *   C[b] = alpha * sum_t A_t[b] . op(B_t[b]) (+ bias[n]) (+ C[b] if accumulate),  A_t [M, K_t], op(B_t) [K_t, N].
+ * The reference forms these sums with one Tensor::matmul and one operator+ per term (the projector output
+ * layers/projector_layer.hpp:93-100; the input delta that projector and tokenizer both contribute to,
+ * layers/visual_transformer.hpp:153-176); here every term's operands are read once and C is written once.
+ * form: 0 = exact fp32 (vt_gemm_f32's arithmetic), 1 = bf16 operands, 2 = hi/lo split (vt_gemm_f32x3's). */
+typedef struct vt_gemm_term {
+  const float *A, *B;
+  long strideA, strideB; /* elements between batch members (0: shared by all) */
+  int K, lda, ldb, transB;
+} vt_gemm_term;
+int vt_gemm_sum(int form, int nterms, const vt_gemm_term *terms, int M, int N, float alpha, int accumulate, float *C,
+                int ldc, long strideC, const float *bias, int batch, vt_stream s);
 /* Tensor::softmax over the last axis (tensor_cpu.hpp:894-944), in place on S [rows, width], and
  * Tensor::softmax_backward (tensor_cpu.hpp:946-950): da <- a * (da - sum_last(a * da)), in place on da. */
 int vt_softmax_rows(float *S, long rows, int width, vt_stream s);

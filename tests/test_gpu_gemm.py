@@ -82,6 +82,51 @@ def test_gemm_split_products_keep_fp32_accuracy(ta, tb):
     _run(ta, tb, 256, 196, 512, batch=4, seed=9, **kw)
 
 
+@pytest.mark.parametrize("form,tol", [(0, 2e-6), (2, 2e-5)])
+def test_gemm_sum_of_products(form, tol):
+    """vt_gemm_sum: up to four A_t . op(B_t) terms accumulated in registers into one C (bias, accumulate, per-term
+    transpose of B, operands shared by the batch through stride 0, ragged sizes) against numpy in double precision."""
+    import torch
+    from vit_amd._lib import VtGemmTerm, check, lib
+    rng = np.random.default_rng(11)
+    for (M, N, batch, ks, tbs, shared, bias, acc) in [
+        (200, 64, 3, (128, 64, 16, 16), (1, 1, 0, 1), (1, 1, 0, 1), False, False),  # the input-delta sum's shape
+        (300, 128, 2, (64, 16), (0, 0), (1, 0), True, False),                       # the projector output's
+        (77, 45, 2, (5, 33, 18), (0, 1, 0), (0, 0, 1), True, True),
+        (130, 200, 1, (300,), (1,), (0,), False, True),
+        (256, 256, 4, (256, 196), (0, 0), (1, 0), True, False),
+    ]:
+        terms = (VtGemmTerm * len(ks))()
+        keep = []
+        want = np.zeros((batch, M, N))
+        for t, (K, tb, sh) in enumerate(zip(ks, tbs, shared)):
+            A = rng.standard_normal((batch, M, K)).astype(np.float32)
+            Bshape = (1 if sh else batch,) + ((N, K) if tb else (K, N))
+            B = rng.standard_normal(Bshape).astype(np.float32)
+            dA, dB = torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda()
+            keep += [dA, dB]
+            terms[t] = VtGemmTerm(dA.data_ptr(), dB.data_ptr(), M * K, 0 if sh else N * K, K, K, K if tb else N, tb)
+            B64 = B.astype(np.float64)
+            want += A.astype(np.float64) @ (np.swapaxes(B64, 1, 2) if tb else B64)
+        want *= 0.5
+        c0 = rng.standard_normal((batch, M, N)).astype(np.float32)
+        bv = rng.standard_normal(N).astype(np.float32)
+        if bias:
+            want += bv
+        if acc:
+            want += c0
+        dC, dbias = torch.from_numpy(c0.copy()).cuda(), torch.from_numpy(bv).cuda()
+        check(lib.vt_gemm_sum(form, len(ks), terms, M, N, 0.5, int(acc), C.c_void_p(dC.data_ptr()), N, M * N,
+                              C.c_void_p(dbias.data_ptr()) if bias else None, batch,
+                              C.c_void_p(torch.cuda.current_stream().cuda_stream)), "vt_gemm_sum")
+        torch.cuda.synchronize()
+        assert rel_err(dC.cpu().numpy(), want) < tol, (M, N, ks)
+    # argument checks
+    bad = (VtGemmTerm * 1)()
+    assert lib.vt_gemm_sum(0, 5, bad, 4, 4, 1.0, 0, C.c_void_p(dC.data_ptr()), 4, 16, None, 1, None) != 0
+    assert lib.vt_gemm_sum(0, 1, bad, 4, 4, 1.0, 0, C.c_void_p(dC.data_ptr()), 4, 16, None, 1, None) != 0  # NULL operands
+
+
 def _bf16_round(a):
     u = a.astype(np.float32).view(np.uint32).astype(np.uint64)
     u = (u + 0x7FFF + ((u >> 16) & 1)) >> 16 << 16

@@ -29,6 +29,11 @@ class VtTrainState(C.Structure):
                 ("loader_resets", C.c_int)]
 
 
+class VtGemmTerm(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("strideA", C.c_long), ("strideB", C.c_long), ("K", C.c_int),
+                ("lda", C.c_int), ("ldb", C.c_int), ("transB", C.c_int)]
+
+
 class VtLayout(C.Structure):
     _fields_ = [("n_tensors", C.c_int), ("n_trainable", C.c_int), ("n_total", C.c_int),
                 ("n_trainable_exact", C.c_int), ("t", VtTensorInfo * VT_MAX_TENSORS)]
@@ -125,6 +130,7 @@ SIGNATURES = {
     "vt_gemm_f32": (i, [i, i, i, i, i, f, p, i, C.c_long, p, i, C.c_long, i, p, i, C.c_long, p, i, p, C.c_long, p]),
     "vt_gemm_bf16_mfma": (i, [i, i, i, i, i, f, p, i, C.c_long, p, i, C.c_long, i, p, i, C.c_long, p, i, p, C.c_long, p]),
     "vt_gemm_f32x3": (i, [i, i, i, i, i, f, p, i, C.c_long, p, i, C.c_long, i, p, i, C.c_long, p, i, p, C.c_long, p]),
+    "vt_gemm_sum": (i, [i, i, C.POINTER(VtGemmTerm), i, i, f, i, p, i, C.c_long, p, i, p]),
     "vt_batchnorm_scratch_floats": (l, [i]),
     "vt_batchnorm_fwd": (i, [p, l, i, p, p, p, p, i, p, p, p, l, p]),
     "vt_batchnorm_bwd": (i, [p, p, p, p, l, i, p, p, p, p, l, p]),

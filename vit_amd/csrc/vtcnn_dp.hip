@@ -86,7 +86,7 @@ int vt_dp_init(int ranks, const int *device_ids, vt_dp **out) {
   std::call_once(g_rccl_once, open_rccl);
   if (!g_rccl.ok) return VT_EUNSUPPORTED;
   int keep = 0;
-  hipGetDevice(&keep);
+  (void)hipGetDevice(&keep);
   vt_dp *dp = nullptr;
   try {
     dp = new vt_dp;
@@ -101,18 +101,18 @@ int vt_dp_init(int ranks, const int *device_ids, vt_dp **out) {
   int rc = g_rccl.CommInitAll(dp->comms.data(), ranks, dp->devices.data());
   if (rc != NCCL_SUCCESS) {
     delete dp;
-    hipSetDevice(keep);
+    (void)hipSetDevice(keep);
     return rccl_fail("ncclCommInitAll", rc);
   }
   for (int r = 0; r < ranks; ++r) {
     if (hipSetDevice(dp->devices[r]) != hipSuccess ||
         hipEventCreateWithFlags(&dp->done[r], hipEventDisableTiming) != hipSuccess) {
-      hipSetDevice(keep);
+      (void)hipSetDevice(keep);
       vt_dp_destroy(dp);
       return VT_ENOMEM;
     }
   }
-  hipSetDevice(keep);
+  (void)hipSetDevice(keep);
   *out = dp;
   return 0;
 }
@@ -120,14 +120,14 @@ int vt_dp_init(int ranks, const int *device_ids, vt_dp **out) {
 int vt_dp_destroy(vt_dp *dp) {
   if (!dp) return 0;
   int keep = 0;
-  hipGetDevice(&keep);
+  (void)hipGetDevice(&keep);
   for (size_t r = 0; r < dp->devices.size(); ++r) {
-    hipSetDevice(dp->devices[r]);
-    hipDeviceSynchronize();
-    if (dp->done[r]) hipEventDestroy(dp->done[r]);
+    (void)hipSetDevice(dp->devices[r]);
+    (void)hipDeviceSynchronize();
+    if (dp->done[r]) (void)hipEventDestroy(dp->done[r]);
     if (dp->comms[r]) g_rccl.CommDestroy(dp->comms[r]);
   }
-  hipSetDevice(keep);
+  (void)hipSetDevice(keep);
   delete dp;
   return 0;
 }
@@ -141,7 +141,7 @@ int vt_dp_allreduce_async(vt_dp *dp, float *const *d_bufs, long first, long coun
     if (!d_bufs[r]) return VT_EINVAL;
   if (count == 0) return 0;
   int keep = 0;
-  hipGetDevice(&keep);
+  (void)hipGetDevice(&keep);
   int rc = g_rccl.GroupStart();
   if (rc != NCCL_SUCCESS) return rccl_fail("ncclGroupStart", rc);
   int bad = NCCL_SUCCESS;
@@ -153,13 +153,13 @@ int vt_dp_allreduce_async(vt_dp *dp, float *const *d_bufs, long first, long coun
   if (bad != NCCL_SUCCESS) return rccl_fail("ncclAllReduce", bad);
   if (rc != NCCL_SUCCESS) return rccl_fail("ncclGroupEnd", rc);
   for (int r = 0; r < ranks; ++r) {
-    hipSetDevice(dp->devices[r]);
+    (void)hipSetDevice(dp->devices[r]);
     if (hipEventRecord(dp->done[r], (hipStream_t)streams[r]) != hipSuccess) {
-      hipSetDevice(keep);
+      (void)hipSetDevice(keep);
       return VT_EIO;
     }
   }
-  hipSetDevice(keep);
+  (void)hipSetDevice(keep);
   for (int r = 0; r < ranks; ++r) dp->issued[r] = 1;
   return 0;
 }
@@ -168,12 +168,12 @@ int vt_dp_allreduce_rank_async(vt_dp *dp, int rank, float *d_buf, long first, lo
   if (!dp || rank < 0 || rank >= (int)dp->devices.size() || !d_buf || first < 0 || count < 0) return VT_EINVAL;
   if (count == 0) return 0;
   int keep = 0;
-  hipGetDevice(&keep);
+  (void)hipGetDevice(&keep);
   if (keep != dp->devices[rank] && hipSetDevice(dp->devices[rank]) != hipSuccess) return VT_EINVAL;
   float *p = d_buf + first;
   const int rc = g_rccl.AllReduce(p, p, (size_t)count, NCCL_FLOAT32, NCCL_SUM, dp->comms[rank], (hipStream_t)stream);
   const hipError_t ev = rc == NCCL_SUCCESS ? hipEventRecord(dp->done[rank], (hipStream_t)stream) : hipSuccess;
-  if (keep != dp->devices[rank]) hipSetDevice(keep);
+  if (keep != dp->devices[rank]) (void)hipSetDevice(keep);
   if (rc != NCCL_SUCCESS) return rccl_fail("ncclAllReduce", rc);
   if (ev != hipSuccess) return VT_EIO;
   dp->issued[rank] = 1;

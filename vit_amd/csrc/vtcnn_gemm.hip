@@ -166,66 +166,60 @@ __device__ __forceinline__ void store_tile_bf16(unsigned short (*T)[GBK + HPAD],
   }
 }
 
-// BM x BN: the workgroup's tile of C (64x64 for narrow or small products, 64x128 when only N is
-// wide, 128x128 for the wide shapes: each wave then owns 64x64 = 4x4 MFMA tiles and an LDS operand
-// read feeds four matrix instructions instead of two).
-template <bool TA, bool TB, int PR, int BM, int BN>
-__global__ __launch_bounds__(256) void k_gemm(GemmP p) {
-  constexpr bool BF = PR != 0;
-  constexpr int TM = BM / 32, TN = BN / 32;  // 16x16 tiles per wave along M and N (waves are laid out 2 x 2)
-  __shared__ float As[BF ? 1 : GBK][BM + GPAD];
-  __shared__ float Bs[BF ? 1 : GBK][BN + GPAD];
-  __shared__ __attribute__((aligned(8))) unsigned short Ah[BF ? BM : 1][GBK + HPAD];
-  __shared__ __attribute__((aligned(8))) unsigned short Bh[BF ? BN : 1][GBK + HPAD];
-  __shared__ __attribute__((aligned(8))) unsigned short Al[PR == 2 ? BM : 1][GBK + HPAD];
-  __shared__ __attribute__((aligned(8))) unsigned short Bl[PR == 2 ? BN : 1][GBK + HPAD];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b = blockIdx.z / p.ksplit, ks = blockIdx.z - b * p.ksplit;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;  // rows on x: the batch's pixel rows run into the millions
-  const int kbeg = ks * p.kchunk, kend = min(p.K, kbeg + p.kchunk);
-  const float *__restrict__ A = p.A + (long)b * p.sA;
-  const float *__restrict__ B = p.B + (long)b * p.sB;
-  const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
-  const bool vecA = p.vecA != 0, vecB = p.vecB != 0;
-  f32x4 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+// LDS tiles of one workgroup (only the arrays of the kernel's arithmetic form have a size)
+template <int PR, int BM, int BN>
+struct GemmLds {
+  float As[PR != 0 ? 1 : GBK][BM + GPAD];
+  float Bs[PR != 0 ? 1 : GBK][BN + GPAD];
+  __attribute__((aligned(8))) unsigned short Ah[PR != 0 ? BM : 1][GBK + HPAD];
+  __attribute__((aligned(8))) unsigned short Bh[PR != 0 ? BN : 1][GBK + HPAD];
+  __attribute__((aligned(8))) unsigned short Al[PR == 2 ? BM : 1][GBK + HPAD];
+  __attribute__((aligned(8))) unsigned short Bl[PR == 2 ? BN : 1][GBK + HPAD];
+};
 
+// acc += op(A)[m0.., kbeg..kend) . op(B)[kbeg..kend), n0..) for the workgroup's BM x BN tile: each of the four
+// waves owns (BM/2) x (BN/2) as 16x16 matrix-instruction tiles (waves laid out 2 x 2).
+template <bool TA, bool TB, int PR, int BM, int BN>
+__device__ __forceinline__ void gemm_walk(GemmLds<PR, BM, BN> &L, const float *__restrict__ A, const float *__restrict__ B,
+                                          int lda, int ldb, int M, int N, int m0, int n0, int kbeg, int kend, bool vecA,
+                                          bool vecB, f32x4 (&acc)[BM / 32][BN / 32]) {
+  constexpr bool BF = PR != 0;
+  constexpr int TM = BM / 32, TN = BN / 32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
   // the next K step's tiles travel from memory while the matrix cores work on the current one
   float ra[BM / 16], rb[BN / 16];
-  load_tile<!TA, BM>(A, p.lda, m0, p.M, kbeg, kend, vecA, tid, ra);
-  load_tile<TB, BN>(B, p.ldb, n0, p.N, kbeg, kend, vecB, tid, rb);
+  load_tile<!TA, BM>(A, lda, m0, M, kbeg, kend, vecA, tid, ra);
+  load_tile<TB, BN>(B, ldb, n0, N, kbeg, kend, vecB, tid, rb);
   for (int k0 = kbeg; k0 < kend; k0 += GBK) {
     __syncthreads();  // the previous step's tile reads are over
     if constexpr (PR == 2) {
-      store_tile_split<!TA, BM>(Ah, Al, vecA, tid, ra);
-      store_tile_split<TB, BN>(Bh, Bl, vecB, tid, rb);
+      store_tile_split<!TA, BM>(L.Ah, L.Al, vecA, tid, ra);
+      store_tile_split<TB, BN>(L.Bh, L.Bl, vecB, tid, rb);
     } else if constexpr (BF) {
-      store_tile_bf16<!TA, BM>(Ah, vecA, tid, ra);
-      store_tile_bf16<TB, BN>(Bh, vecB, tid, rb);
+      store_tile_bf16<!TA, BM>(L.Ah, vecA, tid, ra);
+      store_tile_bf16<TB, BN>(L.Bh, vecB, tid, rb);
     } else {
-      store_tile<!TA, BM>(As, vecA, tid, ra);
-      store_tile<TB, BN>(Bs, vecB, tid, rb);
+      store_tile<!TA, BM>(L.As, vecA, tid, ra);
+      store_tile<TB, BN>(L.Bs, vecB, tid, rb);
     }
     __syncthreads();
     if (k0 + GBK < kend) {
-      load_tile<!TA, BM>(A, p.lda, m0, p.M, k0 + GBK, kend, vecA, tid, ra);
-      load_tile<TB, BN>(B, p.ldb, n0, p.N, k0 + GBK, kend, vecB, tid, rb);
+      load_tile<!TA, BM>(A, lda, m0, M, k0 + GBK, kend, vecA, tid, ra);
+      load_tile<TB, BN>(B, ldb, n0, N, k0 + GBK, kend, vecB, tid, rb);
     }
     if constexpr (PR == 2) {
       const int kq = 4 * (lane >> 4), c = lane & 15;
       s16x4 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        ah[i] = *reinterpret_cast<const s16x4 *>(&Ah[wm + 16 * i + c][kq]);
-        al[i] = *reinterpret_cast<const s16x4 *>(&Al[wm + 16 * i + c][kq]);
+        ah[i] = *reinterpret_cast<const s16x4 *>(&L.Ah[wm + 16 * i + c][kq]);
+        al[i] = *reinterpret_cast<const s16x4 *>(&L.Al[wm + 16 * i + c][kq]);
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        bh[j] = *reinterpret_cast<const s16x4 *>(&Bh[wn + 16 * j + c][kq]);
-        bl[j] = *reinterpret_cast<const s16x4 *>(&Bl[wn + 16 * j + c][kq]);
+        bh[j] = *reinterpret_cast<const s16x4 *>(&L.Bh[wn + 16 * j + c][kq]);
+        bl[j] = *reinterpret_cast<const s16x4 *>(&L.Bl[wn + 16 * j + c][kq]);
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -239,9 +233,9 @@ __global__ __launch_bounds__(256) void k_gemm(GemmP p) {
       const int kq = 4 * (lane >> 4), c = lane & 15;
       s16x4 av[TM], bv[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) av[i] = *reinterpret_cast<const s16x4 *>(&Ah[wm + 16 * i + c][kq]);
+      for (int i = 0; i < TM; ++i) av[i] = *reinterpret_cast<const s16x4 *>(&L.Ah[wm + 16 * i + c][kq]);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bv[j] = *reinterpret_cast<const s16x4 *>(&Bh[wn + 16 * j + c][kq]);
+      for (int j = 0; j < TN; ++j) bv[j] = *reinterpret_cast<const s16x4 *>(&L.Bh[wn + 16 * j + c][kq]);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -252,9 +246,9 @@ __global__ __launch_bounds__(256) void k_gemm(GemmP p) {
         const int kr = kk + (lane >> 4), c = lane & 15;
         float av[TM], bv[TN];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) av[i] = As[kr][wm + 16 * i + c];
+        for (int i = 0; i < TM; ++i) av[i] = L.As[kr][wm + 16 * i + c];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) bv[j] = Bs[kr][wn + 16 * j + c];
+        for (int j = 0; j < TN; ++j) bv[j] = L.Bs[kr][wn + 16 * j + c];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -262,25 +256,90 @@ __global__ __launch_bounds__(256) void k_gemm(GemmP p) {
       }
     }
   }
-  const bool direct = p.ksplit == 1;
-  float *__restrict__ C = direct ? p.C + (long)b * p.sC : p.part + ((long)ks * p.batch + b) * (long)p.M * p.N;
-  const int ldc = direct ? p.ldc : p.N;
+}
+
+// the tile's accumulators to memory: r = acc * alpha (+ bias[n]) (+ C); finish = false stores the bare products
+template <int BM, int BN>
+__device__ __forceinline__ void gemm_store(const f32x4 (&acc)[BM / 32][BN / 32], float *__restrict__ C, int ldc, int M, int N,
+                                           int m0, int n0, float alpha, const float *__restrict__ bias, bool accumulate,
+                                           bool finish) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+  for (int i = 0; i < BM / 32; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+    for (int j = 0; j < BN / 32; ++j)
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         const int gm = m0 + wm + i * 16 + 4 * (lane >> 4) + v, gn = n0 + wn + j * 16 + (lane & 15);
-        if (gm < p.M && gn < p.N) {
-          float r = acc[i][j][v] * p.alpha;
-          if (direct) {
-            if (p.bias) r += p.bias[gn];
-            if (p.accumulate) r += C[(long)gm * ldc + gn];
+        if (gm < M && gn < N) {
+          float r = acc[i][j][v] * alpha;
+          if (finish) {
+            if (bias) r += bias[gn];
+            if (accumulate) r += C[(long)gm * ldc + gn];
           }
           C[(long)gm * ldc + gn] = r;
         }
       }
+}
+
+// BM x BN: the workgroup's tile of C (64x64 for narrow or small products, 64x128 when only N is
+// wide, 128x128 for the wide shapes: each wave then owns 64x64 = 4x4 MFMA tiles and an LDS operand
+// read feeds four matrix instructions instead of two).
+template <bool TA, bool TB, int PR, int BM, int BN>
+__global__ __launch_bounds__(256) void k_gemm(GemmP p) {
+  __shared__ GemmLds<PR, BM, BN> L;
+  const int b = blockIdx.z / p.ksplit, ks = blockIdx.z - b * p.ksplit;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;  // rows on x: the batch's pixel rows run into the millions
+  const int kbeg = ks * p.kchunk, kend = min(p.K, kbeg + p.kchunk);
+  f32x4 acc[BM / 32][BN / 32];
+#pragma unroll
+  for (int i = 0; i < BM / 32; ++i)
+#pragma unroll
+    for (int j = 0; j < BN / 32; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  gemm_walk<TA, TB, PR, BM, BN>(L, p.A + (long)b * p.sA, p.B + (long)b * p.sB, p.lda, p.ldb, p.M, p.N, m0, n0, kbeg, kend,
+                                p.vecA != 0, p.vecB != 0, acc);
+  const bool direct = p.ksplit == 1;
+  float *__restrict__ C = direct ? p.C + (long)b * p.sC : p.part + ((long)ks * p.batch + b) * (long)p.M * p.N;
+  gemm_store<BM, BN>(acc, C, direct ? p.ldc : p.N, p.M, p.N, m0, n0, p.alpha, p.bias, p.accumulate != 0, direct);
+}
+
+// A sum of up to four products into one tile of C without the partial results travelling through memory:
+//   C[b] = alpha * sum_t A_t[b] . op(B_t[b]) (+ bias) (+ C[b])
+// (the projector output x.Wd + attention.values; the input delta that four layers contribute to).  A is never
+// transposed here; B is per term.
+struct GemmTerm {
+  const float *A, *B;
+  long sA, sB;
+  int K, lda, ldb, tb, vecA, vecB;
+};
+struct GemmSumP {
+  GemmTerm t[4];
+  int nterms;
+  float *C;
+  const float *bias;
+  int M, N, ldc;
+  long sC;
+  float alpha;
+  int accumulate;
+};
+template <int PR, int BM, int BN>
+__global__ __launch_bounds__(256) void k_gemm_sum(GemmSumP p) {
+  __shared__ GemmLds<PR, BM, BN> L;
+  const int b = blockIdx.z;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  f32x4 acc[BM / 32][BN / 32];
+#pragma unroll
+  for (int i = 0; i < BM / 32; ++i)
+#pragma unroll
+    for (int j = 0; j < BN / 32; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int ti = 0; ti < p.nterms; ++ti) {
+    const GemmTerm &t = p.t[ti];
+    const float *A = t.A + (long)b * t.sA, *B = t.B + (long)b * t.sB;
+    if (t.tb) gemm_walk<false, true, PR, BM, BN>(L, A, B, t.lda, t.ldb, p.M, p.N, m0, n0, 0, t.K, t.vecA != 0, t.vecB != 0, acc);
+    else gemm_walk<false, false, PR, BM, BN>(L, A, B, t.lda, t.ldb, p.M, p.N, m0, n0, 0, t.K, t.vecA != 0, t.vecB != 0, acc);
+  }
+  gemm_store<BM, BN>(acc, p.C + (long)b * p.sC, p.ldc, p.M, p.N, m0, n0, p.alpha, p.bias, p.accumulate != 0, true);
 }
 
 // C[b][m][n] = sum over slices of part[s][b][m][n] (+ bias) (+ C), slices in ascending order.
@@ -399,4 +458,43 @@ extern "C" int vt_gemm_f32x3(int transA, int transB, int M, int N, int K, float 
                              const float *bias, int batch, float *workspace, long workspace_floats, vt_stream s) {
   return gemm_launch(2, transA, transB, M, N, K, alpha, A, lda, strideA, B, ldb, strideB, accumulate, C, ldc, strideC, bias,
                      batch, workspace, workspace_floats, s);
+}
+
+extern "C" int vt_gemm_sum(int form, int nterms, const vt_gemm_term *terms, int M, int N, float alpha, int accumulate,
+                           float *C, int ldc, long strideC, const float *bias, int batch, vt_stream s) {
+  if (form < 0 || form > 2 || nterms < 1 || nterms > 4 || !terms || M < 1 || N < 1 || batch < 1 || !C || ldc < N) return VT_EINVAL;
+  GemmSumP p{};
+  auto aligned = [](const float *q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  long ktot = 0;
+  for (int i = 0; i < nterms; ++i) {
+    const vt_gemm_term &t = terms[i];
+    if (!t.A || !t.B || t.K < 1 || t.lda < t.K || t.ldb < (t.transB ? t.K : N)) return VT_EINVAL;
+    GemmTerm &d = p.t[i];
+    d.A = t.A; d.B = t.B; d.sA = t.strideA; d.sB = t.strideB; d.K = t.K; d.lda = t.lda; d.ldb = t.ldb; d.tb = t.transB ? 1 : 0;
+    d.vecA = aligned(t.A) && t.lda % 4 == 0 && t.strideA % 4 == 0 && t.K % 4 == 0;
+    d.vecB = aligned(t.B) && t.ldb % 4 == 0 && t.strideB % 4 == 0 && (t.transB ? t.K % 4 == 0 : N % 4 == 0);
+    ktot += t.K;
+  }
+  p.nterms = nterms; p.C = C; p.bias = bias; p.M = M; p.N = N; p.ldc = ldc; p.sC = strideC; p.alpha = alpha;
+  p.accumulate = accumulate ? 1 : 0;
+  int BM = 64, BN = 64;
+  if (N > 64) {
+    BN = 128;
+    if (ktot >= 256 && M >= 128 && (long)((M + 127) / 128) * ((N + 127) / 128) * batch >= 512) BM = 128;
+  }
+  if (batch > 65535 || (N + BN - 1) / BN > 65535) return VT_EUNSUPPORTED;
+  const dim3 grid((M + BM - 1) / BM, (N + BN - 1) / BN, (unsigned)batch);
+  hipStream_t hs = (hipStream_t)s;
+#define VT_SUM_LAUNCH(PR_)                                                                               \
+  do {                                                                                                   \
+    if (BM == 128) hipLaunchKernelGGL((k_gemm_sum<PR_, 128, 128>), grid, dim3(256), 0, hs, p);          \
+    else if (BN == 128) hipLaunchKernelGGL((k_gemm_sum<PR_, 64, 128>), grid, dim3(256), 0, hs, p);       \
+    else hipLaunchKernelGGL((k_gemm_sum<PR_, 64, 64>), grid, dim3(256), 0, hs, p);                       \
+  } while (0)
+  if (form == 2) VT_SUM_LAUNCH(2);
+  else if (form == 1) VT_SUM_LAUNCH(1);
+  else VT_SUM_LAUNCH(0);
+#undef VT_SUM_LAUNCH
+  VT_CHECK_LAUNCH();
+  return 0;
 }

@@ -675,6 +675,15 @@ struct Gemm {
   }
 };
 
+// arithmetic form of the sums of products (vt_gemm_sum): hi/lo split unless VT_GEMM_EXACT asks for fp32 instructions
+int sum_form() {
+  static const int form = [] {
+    const char *e = getenv("VT_GEMM_EXACT");
+    return (e && *e && *e != '0') ? 0 : 2;
+  }();
+  return form;
+}
+
 int rows_per_block(long R) {
   // enough blocks to fill the chip, few enough that the finalize kernels stay short
   long rpb = (R + 4095) / 4096;
@@ -944,11 +953,13 @@ int gen_forward(GenModel *g, const float *arena, const vt_layout *lo, float *are
   VTG(mm_bf_exact(false, false, (int)NP, D, C1, g->x, C1, W("proj.linear1.W"), D, g->q, D));
   VTG(mm_bf_exact(false, false, (int)NL, D, D, g->o, D, W("proj.linear2.W"), D, g->k, D));
   VTG(mm_bf(false, false, (int)NL, C2, D, g->o, D, W("proj.linear3.W"), C2, g->v, C2, W("proj.linear3.b")));
-  VTG(mm(false, false, (int)NP, C2, C1, g->x, C1, W("proj.downsample.W"), C2, g->z, C2, W("proj.downsample.b")));
   VTG(mm_exact(false, true, P, L, D, g->q, D, g->k, D, g->pa, L, nullptr, false, 1.f, n, (long)P * D, (long)L * D, (long)P * L));
   VTG(softmax_rows(g->pa, NP, L, s));
-  VTG(mm(false, false, P, C2, L, g->pa, L, g->v, C2, g->z, C2, nullptr, true, 1.f, n, (long)P * L, (long)L * C2,
-         (long)P * C2));
+  {  // z = downsample(x) + attention . values (projector_layer.hpp:93-100), one pass, z written once
+    const vt_gemm_term t[2] = {{g->x, W("proj.downsample.W"), (long)P * C1, 0, C1, C1, C2, 0},
+                               {g->pa, g->v, (long)P * L, (long)L * C2, L, L, C2, 0}};
+    VTG(vt_gemm_sum(sum_form(), 2, t, P, C2, 1.f, 0, g->z, C2, (long)P * C2, W("proj.downsample.b"), n, (vt_stream)s));
+  }
   VTG(bn_stats(g, g->z, NP, C2, RW("proj.norm.running_mean"), RW("proj.norm.running_var"), g->stat_pn, false, s));
   // reshape, max-pool, fc, softmax (vit_cnn.hpp:179-203)
   {
@@ -987,7 +998,6 @@ int gen_backward(GenModel *g, const float *arena, const vt_layout *lo, float *gr
     // (the downsample bias gradient, the column sums of dz, comes out of the BatchNorm backward's own sums)
     VTG(pool_bn_backward(g, W("proj.norm.gamma"), G("proj.norm.gamma"), G("proj.norm.beta"), G("proj.downsample.b"), n, s));
     VTG(mm(true, false, C1, C2, (int)NP, g->x, C1, g->dz, C2, G("proj.downsample.W"), C2));
-    VTG(mm(false, true, (int)NP, C1, C2, g->dz, C2, W("proj.downsample.W"), C2, g->pdx, C1));
     // delta of the attention map, softmax backward over tokens, deltas of q / k / v
     VTG(mm(false, true, P, L, C2, g->dz, C2, g->v, C2, g->dsa, L, nullptr, false, 1.f, n, (long)P * C2, (long)L * C2,
            (long)P * L));
@@ -1004,7 +1014,6 @@ int gen_backward(GenModel *g, const float *arena, const vt_layout *lo, float *gr
     VTG(mm(true, false, D, D, (int)NL, g->o, D, g->dk, D, G("proj.linear2.W"), D));
     VTG(mm(false, true, (int)NL, D, D, g->dk, D, W("proj.linear2.W"), D, g->pdt, D, nullptr, true));
     VTG(mm(true, false, C1, D, (int)NP, g->x, C1, g->dq, D, G("proj.linear1.W"), D));
-    VTG(mm(false, true, (int)NP, C1, D, g->dq, D, W("proj.linear1.W"), D, g->pdx, C1, nullptr, true));
     // TransformerLayer::backward with targets = projector token delta: seed = out - delta
     // (visual_transformer.hpp:153-157, transformer_layer.hpp:133-207); no ReLU derivative (:174-181)
     VTG(ewise(g->o, g->pdt, g->d0, NL * D, 1, s));
@@ -1026,11 +1035,16 @@ int gen_backward(GenModel *g, const float *arena, const vt_layout *lo, float *gr
     VTG(mm(false, true, P, L, C1, g->x, C1, g->dT0, C1, g->dsa, L, nullptr, false, 1.f, n, (long)P * C1, (long)L * C1,
            (long)P * L));
     VTG(softmax_bwd_rows(g->tokA, g->dsa, NP, L, s));
-    // the three input deltas (tokenizer a^T path, tokenizer score path, projector) are summed in place
-    // in the projector's delta buffer
-    VTG(mm(false, false, P, C1, L, g->tokA, L, g->dT0, C1, g->pdx, C1, nullptr, true, 1.f, n, (long)P * L, (long)L * C1,
-           (long)P * C1));
-    VTG(mm(false, true, (int)NP, C1, L, g->dsa, L, W("tok.linear1.W"), L, g->pdx, C1, nullptr, true));
+    // the input deltas of the projector (through the downsample and through the queries) and of the tokenizer
+    // (a^T path, score path) are one sum of four products, written once (projector_layer.hpp:196-213,
+    // tokenizer.hpp:93-106)
+    {
+      const vt_gemm_term t[4] = {{g->dz, W("proj.downsample.W"), (long)P * C2, 0, C2, C2, C2, 1},
+                                 {g->dq, W("proj.linear1.W"), (long)P * D, 0, D, D, D, 1},
+                                 {g->tokA, g->dT0, (long)P * L, (long)L * C1, L, L, C1, 0},
+                                 {g->dsa, W("tok.linear1.W"), (long)P * L, 0, L, L, L, 1}};
+      VTG(vt_gemm_sum(sum_form(), 4, t, P, C1, 1.f, 0, g->pdx, C1, (long)P * C1, nullptr, n, (vt_stream)s));
+    }
     // BatchNorm2DLayer::backward + Conv2DLayer::backward gradients (batch_normalization_layer.hpp:300-327,
     // conv2d_layer.hpp:115-147); the conv input delta is never consumed
     VTG(bn_backward(g, g->pdx, g->conv, g->stat_bn, W("bn.gamma"), NP, C1, G("bn.gamma"), G("bn.beta"), g->coef, g->tdx, s,
