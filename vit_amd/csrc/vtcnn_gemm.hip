@@ -17,6 +17,8 @@
 // instructions of a quarter of the fp32 instruction's duration each in place of four fp32 ones.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "../../include/vtcnn_hip.h"
 #include "vtcnn_common.h"
 
@@ -177,83 +179,67 @@ struct GemmLds {
   __attribute__((aligned(8))) unsigned short Bl[PR == 2 ? BN : 1][GBK + HPAD];
 };
 
-// acc += op(A)[m0.., kbeg..kend) . op(B)[kbeg..kend), n0..) for the workgroup's BM x BN tile: each of the four
-// waves owns (BM/2) x (BN/2) as 16x16 matrix-instruction tiles (waves laid out 2 x 2).
-template <bool TA, bool TB, int PR, int BM, int BN>
-__device__ __forceinline__ void gemm_walk(GemmLds<PR, BM, BN> &L, const float *__restrict__ A, const float *__restrict__ B,
-                                          int lda, int ldb, int M, int N, int m0, int n0, int kbeg, int kend, bool vecA,
-                                          bool vecB, f32x4 (&acc)[BM / 32][BN / 32]) {
-  constexpr bool BF = PR != 0;
+// registers -> LDS in the kernel's arithmetic form
+template <bool ALONG_K, int PR, int R>
+__device__ __forceinline__ void stage_tile(float (*Tf)[R + GPAD], unsigned short (*Th)[GBK + HPAD],
+                                           unsigned short (*Tl)[GBK + HPAD], bool vec, int tid, const float (&reg)[R / 16]) {
+  if constexpr (PR == 2) store_tile_split<ALONG_K, R>(Th, Tl, vec, tid, reg);
+  else if constexpr (PR == 1) store_tile_bf16<ALONG_K, R>(Th, vec, tid, reg);
+  else store_tile<ALONG_K, R>(Tf, vec, tid, reg);
+}
+
+// acc += (the BM x 16 tile of A in LDS) . (the 16 x BN tile of B in LDS): each of the four waves owns
+// (BM/2) x (BN/2) as 16x16 matrix-instruction tiles (waves laid out 2 x 2)
+template <int PR, int BM, int BN>
+__device__ __forceinline__ void gemm_step(const GemmLds<PR, BM, BN> &L, f32x4 (&acc)[BM / 32][BN / 32]) {
   constexpr int TM = BM / 32, TN = BN / 32;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
-  // the next K step's tiles travel from memory while the matrix cores work on the current one
-  float ra[BM / 16], rb[BN / 16];
-  load_tile<!TA, BM>(A, lda, m0, M, kbeg, kend, vecA, tid, ra);
-  load_tile<TB, BN>(B, ldb, n0, N, kbeg, kend, vecB, tid, rb);
-  for (int k0 = kbeg; k0 < kend; k0 += GBK) {
-    __syncthreads();  // the previous step's tile reads are over
-    if constexpr (PR == 2) {
-      store_tile_split<!TA, BM>(L.Ah, L.Al, vecA, tid, ra);
-      store_tile_split<TB, BN>(L.Bh, L.Bl, vecB, tid, rb);
-    } else if constexpr (BF) {
-      store_tile_bf16<!TA, BM>(L.Ah, vecA, tid, ra);
-      store_tile_bf16<TB, BN>(L.Bh, vecB, tid, rb);
-    } else {
-      store_tile<!TA, BM>(L.As, vecA, tid, ra);
-      store_tile<TB, BN>(L.Bs, vecB, tid, rb);
-    }
-    __syncthreads();
-    if (k0 + GBK < kend) {
-      load_tile<!TA, BM>(A, lda, m0, M, k0 + GBK, kend, vecA, tid, ra);
-      load_tile<TB, BN>(B, ldb, n0, N, k0 + GBK, kend, vecB, tid, rb);
-    }
-    if constexpr (PR == 2) {
-      const int kq = 4 * (lane >> 4), c = lane & 15;
-      s16x4 ah[TM], al[TM], bh[TN], bl[TN];
+  if constexpr (PR == 2) {
+    const int kq = 4 * (lane >> 4), c = lane & 15;
+    s16x4 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        ah[i] = *reinterpret_cast<const s16x4 *>(&L.Ah[wm + 16 * i + c][kq]);
-        al[i] = *reinterpret_cast<const s16x4 *>(&L.Al[wm + 16 * i + c][kq]);
-      }
+    for (int i = 0; i < TM; ++i) {
+      ah[i] = *reinterpret_cast<const s16x4 *>(&L.Ah[wm + 16 * i + c][kq]);
+      al[i] = *reinterpret_cast<const s16x4 *>(&L.Al[wm + 16 * i + c][kq]);
+    }
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        bh[j] = *reinterpret_cast<const s16x4 *>(&L.Bh[wn + 16 * j + c][kq]);
-        bl[j] = *reinterpret_cast<const s16x4 *>(&L.Bl[wn + 16 * j + c][kq]);
+    for (int j = 0; j < TN; ++j) {
+      bh[j] = *reinterpret_cast<const s16x4 *>(&L.Bh[wn + 16 * j + c][kq]);
+      bl[j] = *reinterpret_cast<const s16x4 *>(&L.Bl[wn + 16 * j + c][kq]);
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {  // the two small terms first
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al[i], bh[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah[i], bl[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah[i], bh[j], acc[i][j], 0, 0, 0);
       }
+  } else if constexpr (PR == 1) {
+    const int kq = 4 * (lane >> 4), c = lane & 15;
+    s16x4 av[TM], bv[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) av[i] = *reinterpret_cast<const s16x4 *>(&L.Ah[wm + 16 * i + c][kq]);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bv[j] = *reinterpret_cast<const s16x4 *>(&L.Bh[wn + 16 * j + c][kq]);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av[i], bv[j], acc[i][j], 0, 0, 0);
+  } else {
+#pragma unroll
+    for (int kk = 0; kk < GBK; kk += 4) {
+      const int kr = kk + (lane >> 4), c = lane & 15;
+      float av[TM], bv[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) av[i] = L.As[kr][wm + 16 * i + c];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bv[j] = L.Bs[kr][wn + 16 * j + c];
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {  // the two small terms first
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al[i], bh[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah[i], bl[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah[i], bh[j], acc[i][j], 0, 0, 0);
-        }
-    } else if constexpr (BF) {
-      const int kq = 4 * (lane >> 4), c = lane & 15;
-      s16x4 av[TM], bv[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) av[i] = *reinterpret_cast<const s16x4 *>(&L.Ah[wm + 16 * i + c][kq]);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) bv[j] = *reinterpret_cast<const s16x4 *>(&L.Bh[wn + 16 * j + c][kq]);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av[i], bv[j], acc[i][j], 0, 0, 0);
-    } else {
-#pragma unroll
-      for (int kk = 0; kk < GBK; kk += 4) {
-        const int kr = kk + (lane >> 4), c = lane & 15;
-        float av[TM], bv[TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) av[i] = L.As[kr][wm + 16 * i + c];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) bv[j] = L.Bs[kr][wn + 16 * j + c];
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
-      }
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
     }
   }
 }
@@ -297,8 +283,25 @@ __global__ __launch_bounds__(256) void k_gemm(GemmP p) {
   for (int i = 0; i < BM / 32; ++i)
 #pragma unroll
     for (int j = 0; j < BN / 32; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  gemm_walk<TA, TB, PR, BM, BN>(L, p.A + (long)b * p.sA, p.B + (long)b * p.sB, p.lda, p.ldb, p.M, p.N, m0, n0, kbeg, kend,
-                                p.vecA != 0, p.vecB != 0, acc);
+  const float *__restrict__ A = p.A + (long)b * p.sA;
+  const float *__restrict__ B = p.B + (long)b * p.sB;
+  const int tid = threadIdx.x;
+  const bool vecA = p.vecA != 0, vecB = p.vecB != 0;
+  // the next K step's tiles travel from memory while the matrix cores work on the current one
+  float ra[BM / 16], rb[BN / 16];
+  load_tile<!TA, BM>(A, p.lda, m0, p.M, kbeg, kend, vecA, tid, ra);
+  load_tile<TB, BN>(B, p.ldb, n0, p.N, kbeg, kend, vecB, tid, rb);
+  for (int k0 = kbeg; k0 < kend; k0 += GBK) {
+    __syncthreads();  // the previous step's tile reads are over
+    stage_tile<!TA, PR, BM>(L.As, L.Ah, L.Al, vecA, tid, ra);
+    stage_tile<TB, PR, BN>(L.Bs, L.Bh, L.Bl, vecB, tid, rb);
+    __syncthreads();
+    if (k0 + GBK < kend) {
+      load_tile<!TA, BM>(A, p.lda, m0, p.M, k0 + GBK, kend, vecA, tid, ra);
+      load_tile<TB, BN>(B, p.ldb, n0, p.N, k0 + GBK, kend, vecB, tid, rb);
+    }
+    gemm_step<PR, BM, BN>(L, acc);
+  }
   const bool direct = p.ksplit == 1;
   float *__restrict__ C = direct ? p.C + (long)b * p.sC : p.part + ((long)ks * p.batch + b) * (long)p.M * p.N;
   gemm_store<BM, BN>(acc, C, direct ? p.ldc : p.N, p.M, p.N, m0, n0, p.alpha, p.bias, p.accumulate != 0, direct);
@@ -333,11 +336,37 @@ __global__ __launch_bounds__(256) void k_gemm_sum(GemmSumP p) {
   for (int i = 0; i < BM / 32; ++i)
 #pragma unroll
     for (int j = 0; j < BN / 32; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  for (int ti = 0; ti < p.nterms; ++ti) {
-    const GemmTerm &t = p.t[ti];
-    const float *A = t.A + (long)b * t.sA, *B = t.B + (long)b * t.sB;
-    if (t.tb) gemm_walk<false, true, PR, BM, BN>(L, A, B, t.lda, t.ldb, p.M, p.N, m0, n0, 0, t.K, t.vecA != 0, t.vecB != 0, acc);
-    else gemm_walk<false, false, PR, BM, BN>(L, A, B, t.lda, t.ldb, p.M, p.N, m0, n0, 0, t.K, t.vecA != 0, t.vecB != 0, acc);
+  // one K walk over all terms (a term's last step is padded with zeros to 16), so that the loads of a term's
+  // first tile travel under the previous term's last matrix instructions.  `cur` describes the tile held in
+  // registers, `nxt` the one to request; a term is picked by comparisons, not by indexing (an indexed read of
+  // the by-value argument would move all four terms into vector registers).
+  const int tid = threadIdx.x;
+  auto term = [&](int ti) { return ti == 0 ? p.t[0] : ti == 1 ? p.t[1] : ti == 2 ? p.t[2] : p.t[3]; };
+  auto fetch = [&](const GemmTerm &t, int k0, float (&ra)[BM / 16], float (&rb)[BN / 16]) {
+    load_tile<true, BM>(t.A + (long)b * t.sA, t.lda, m0, p.M, k0, t.K, t.vecA != 0, tid, ra);
+    if (t.tb) load_tile<true, BN>(t.B + (long)b * t.sB, t.ldb, n0, p.N, k0, t.K, t.vecB != 0, tid, rb);
+    else load_tile<false, BN>(t.B + (long)b * t.sB, t.ldb, n0, p.N, k0, t.K, t.vecB != 0, tid, rb);
+  };
+  float ra[BM / 16], rb[BN / 16];
+  int ti = 0, k0 = 0;
+  GemmTerm cur = term(0);
+  fetch(cur, 0, ra, rb);
+  while (true) {
+    __syncthreads();  // the previous step's tile reads are over
+    stage_tile<true, PR, BM>(L.As, L.Ah, L.Al, cur.vecA != 0, tid, ra);
+    if (cur.tb) stage_tile<true, PR, BN>(L.Bs, L.Bh, L.Bl, cur.vecB != 0, tid, rb);
+    else stage_tile<false, PR, BN>(L.Bs, L.Bh, L.Bl, cur.vecB != 0, tid, rb);
+    __syncthreads();
+    k0 += GBK;
+    if (k0 >= cur.K) {
+      k0 = 0;
+      ++ti;
+      if (ti < p.nterms) cur = term(ti);
+    }
+    const bool more = ti < p.nterms;
+    if (more) fetch(cur, k0, ra, rb);
+    gemm_step<PR, BM, BN>(L, acc);
+    if (!more) break;
   }
   gemm_store<BM, BN>(acc, p.C + (long)b * p.sC, p.ldc, p.M, p.N, m0, n0, p.alpha, p.bias, p.accumulate != 0, true);
 }
@@ -379,7 +408,7 @@ static int gemm_launch(int form, int transA, int transB, int M, int N, int K, fl
   int BM = 64, BN = 64;
   if (N > 64) {
     BN = 128;
-    if (K >= 256 && M >= 128 && (long)((M + 127) / 128) * ((N + 127) / 128) * batch >= 512) BM = 128;
+    if (K >= 128 && M >= 128 && (long)((M + 127) / 128) * ((N + 127) / 128) * batch >= 512) BM = 128;
   }
   const long tiles = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN) * batch;
   // a contraction that is long for the few output tiles it feeds: slice K so that several hundred
@@ -480,7 +509,7 @@ extern "C" int vt_gemm_sum(int form, int nterms, const vt_gemm_term *terms, int 
   int BM = 64, BN = 64;
   if (N > 64) {
     BN = 128;
-    if (ktot >= 256 && M >= 128 && (long)((M + 127) / 128) * ((N + 127) / 128) * batch >= 512) BM = 128;
+    if (ktot >= 128 && M >= 128 && (long)((M + 127) / 128) * ((N + 127) / 128) * batch >= 512) BM = 128;
   }
   if (batch > 65535 || (N + BN - 1) / BN > 65535) return VT_EUNSUPPORTED;
   const dim3 grid((M + BM - 1) / BM, (N + BN - 1) / BN, (unsigned)batch);
