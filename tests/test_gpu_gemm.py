@@ -55,6 +55,9 @@ def test_gemm_transposes_and_edges(ta, tb):
     _run(ta, tb, 130, 75, 37, pad=3, seed=1)
     _run(ta, tb, 100, 16, 200, batch=5, alpha=0.25, bias=True, seed=2)
     _run(ta, tb, 33, 129, 64, batch=3, acc=True, pad=1, seed=3)
+    _run(ta, tb, 6000, 64, 64, seed=4)  # tall and narrow (row-panel kernel when A is not transposed)
+    _run(ta, tb, 2500, 16, 128, batch=3, alpha=0.5, bias=True, acc=True, seed=5)
+    _run(ta, tb, 2100, 128, 20, pad=4, seed=6)
 
 
 def test_gemm_sliced_contraction():
@@ -80,22 +83,15 @@ def test_gemm_split_products_keep_fp32_accuracy(ta, tb):
     _run(ta, tb, 33, 129, 64, batch=3, acc=True, pad=1, seed=3, **kw)
     _run(ta, tb, 3136, 512, 512, seed=8, **kw)
     _run(ta, tb, 256, 196, 512, batch=4, seed=9, **kw)
+    _run(ta, tb, 6000, 64, 64, seed=10, **kw)  # tall and narrow (row-panel kernel when A is not transposed)
+    _run(ta, tb, 2500, 16, 128, batch=3, alpha=0.5, bias=True, acc=True, seed=11, **kw)
 
 
-@pytest.mark.parametrize("form,tol", [(0, 2e-6), (2, 2e-5)])
-def test_gemm_sum_of_products(form, tol):
-    """vt_gemm_sum: up to four A_t . op(B_t) terms accumulated in registers into one C (bias, accumulate, per-term
-    transpose of B, operands shared by the batch through stride 0, ragged sizes) against numpy in double precision."""
+def _sum_cases(form, tol, cases):
     import torch
     from vit_amd._lib import VtGemmTerm, check, lib
     rng = np.random.default_rng(11)
-    for (M, N, batch, ks, tbs, shared, bias, acc) in [
-        (200, 64, 3, (128, 64, 16, 16), (1, 1, 0, 1), (1, 1, 0, 1), False, False),  # the input-delta sum's shape
-        (300, 128, 2, (64, 16), (0, 0), (1, 0), True, False),                       # the projector output's
-        (77, 45, 2, (5, 33, 18), (0, 1, 0), (0, 0, 1), True, True),
-        (130, 200, 1, (300,), (1,), (0,), False, True),
-        (256, 256, 4, (256, 196), (0, 0), (1, 0), True, False),
-    ]:
+    for (M, N, batch, ks, tbs, shared, bias, acc) in cases:
         terms = (VtGemmTerm * len(ks))()
         keep = []
         want = np.zeros((batch, M, N))
@@ -121,8 +117,32 @@ def test_gemm_sum_of_products(form, tol):
                               C.c_void_p(torch.cuda.current_stream().cuda_stream)), "vt_gemm_sum")
         torch.cuda.synchronize()
         assert rel_err(dC.cpu().numpy(), want) < tol, (M, N, ks)
+
+
+@pytest.mark.parametrize("form,tol", [(0, 2e-6), (2, 2e-5)])
+def test_gemm_sum_of_products(form, tol):
+    """vt_gemm_sum: up to four A_t . op(B_t) terms accumulated in registers into one C (bias, accumulate, per-term
+    transpose of B, operands shared by the batch through stride 0, ragged sizes) against numpy in double precision."""
+    from vit_amd._lib import VtGemmTerm, lib
+    _sum_cases(form, tol, [
+        (200, 64, 3, (128, 64, 16, 16), (1, 1, 0, 1), (1, 1, 0, 1), False, False),  # the input-delta sum's shape
+        (300, 128, 2, (64, 16), (0, 0), (1, 0), True, False),                       # the projector output's
+        (77, 45, 2, (5, 33, 18), (0, 1, 0), (0, 0, 1), True, True),
+        (130, 200, 1, (300,), (1,), (0,), False, True),
+        (256, 256, 4, (256, 196), (0, 0), (1, 0), True, False),
+    ])
+    _sum_cases(form, tol, [
+        # tall and narrow: the row-panel kernel (B resident in LDS, A straight into operand layout)
+        (5000, 64, 2, (128, 64, 16, 16), (1, 1, 0, 1), (1, 1, 0, 1), False, False),
+        (4100, 128, 3, (64, 16), (0, 0), (1, 0), True, False),
+        (2049, 45, 2, (36, 20), (0, 1), (0, 1), True, True),
+        (70000, 16, 1, (64,), (0,), (1,), True, False),
+        (3000, 30, 2, (8,), (1,), (0,), False, True),
+    ])
     # argument checks
     bad = (VtGemmTerm * 1)()
+    import torch
+    dC = torch.zeros(16, device="cuda")
     assert lib.vt_gemm_sum(0, 5, bad, 4, 4, 1.0, 0, C.c_void_p(dC.data_ptr()), 4, 16, None, 1, None) != 0
     assert lib.vt_gemm_sum(0, 1, bad, 4, 4, 1.0, 0, C.c_void_p(dC.data_ptr()), 4, 16, None, 1, None) != 0  # NULL operands
 

@@ -371,6 +371,146 @@ __global__ __launch_bounds__(256) void k_gemm_sum(GemmSumP p) {
   gemm_store<BM, BN>(acc, p.C + (long)b * p.sC, p.ldc, p.M, p.N, m0, n0, p.alpha, p.bias, p.accumulate != 0, true);
 }
 
+// ---- tall and narrow results (M in the millions of pixel rows, N <= 128, total depth a few hundred): the
+// row-panel form of the same sum of products.  Such a product is a stream: every row of A is read once, every
+// row of C written once, and op(B) (all terms, a few tens of KB) is the only thing reused.  So B lives in LDS
+// for the whole workgroup (as bf16 hi/lo pairs [n][k] in the split form, fp32 [k][n] in the exact one), and a
+// wave takes 16-row tiles of A straight from memory into matrix-instruction operand layout: lane (row c, k
+// group g) loads the four consecutive k of its row as one 16-byte load per 16-deep step, several steps ahead of
+// the matrix instructions that consume them, with no LDS staging and no workgroup barrier in the loop.
+// (The 16x16x4 fp32 instruction wants lane group g to hold k = step, not four consecutive k; a sum over k does
+// not care about the order, so instruction j of a step takes k = 4g + j from both operands.)
+struct PanelStep {
+  const float *A;  // the term's A at this batch member
+  int lda, K, k0, kofs;  // kofs: the step's first k row / column inside the LDS copy of op(B)
+};
+constexpr int PANEL_STEPS = 16, PANEL_HEAD = 512;  // bytes reserved in front of B for the step table
+
+template <int PR, int NT>
+__global__ __launch_bounds__(256) void k_gemm_panel(GemmSumP p, int rows_per_wg, int Kp, int nsteps) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  PanelStep *steps = reinterpret_cast<PanelStep *>(smem);
+  constexpr int NP16 = NT * 16;
+  const int ldk = Kp + 4, ldn = NP16 + 4;
+  unsigned short *__restrict__ Bh = reinterpret_cast<unsigned short *>(smem + PANEL_HEAD);
+  unsigned short *__restrict__ Bl = Bh + NP16 * ldk;
+  float *__restrict__ Bs = reinterpret_cast<float *>(smem + PANEL_HEAD);
+  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4;
+  // step table and the LDS copy of op(B), term by term (constant term indices: the by-value argument stays in
+  // scalar registers)
+  int kofs = 0, sbase = 0;
+#pragma unroll
+  for (int ti = 0; ti < 4; ++ti) {
+    if (ti < p.nterms) {
+      const GemmTerm t = p.t[ti];
+      const int ns = (t.K + 15) >> 4, K16 = ns * 16;
+      if (tid >= sbase && tid < sbase + ns) {
+        const int sidx = tid - sbase;
+        steps[tid] = PanelStep{t.A + (long)b * t.sA, t.lda, t.K, sidx * 16, kofs + sidx * 16};
+      }
+      const float *__restrict__ B = t.B + (long)b * t.sB;
+      for (int e = tid; e < K16 * NP16; e += 256) {
+        int k, n;
+        if (t.tb) { k = e % K16; n = e / K16; } else { n = e % NP16; k = e / NP16; }
+        const float v = (k < t.K && n < p.N) ? B[t.tb ? (long)n * t.ldb + k : (long)k * t.ldb + n] : 0.f;
+        if constexpr (PR == 2) {
+          const unsigned short h = to_bf16(v);
+          Bh[n * ldk + kofs + k] = h;
+          Bl[n * ldk + kofs + k] = to_bf16(v - from_bf16(h));
+        } else {
+          Bs[(kofs + k) * ldn + n] = v;
+        }
+      }
+      kofs += K16;
+      sbase += ns;
+    }
+  }
+  __syncthreads();
+
+  const int G = (nsteps + 3) >> 2;  // groups of four steps: one group is in the matrix cores, the next in flight
+  const long wg_row0 = (long)blockIdx.x * rows_per_wg;
+  const int ntiles = rows_per_wg / 64;  // 16-row tiles per wave: tile i of this wave is tile wave + 4 i of the workgroup
+  auto tile_row0 = [&](int i) { return wg_row0 + (long)(wave + 4 * i) * 16; };
+  auto fetch = [&](long row0, int gi, float4 (&dst)[4]) {
+    const long row = row0 + c;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int si = gi * 4 + e;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (si < nsteps) {
+        const PanelStep st = steps[si];
+        const int k = st.k0 + 4 * g;
+        if (row < p.M && k < st.K) v = *reinterpret_cast<const float4 *>(st.A + row * st.lda + k);
+      }
+      dst[e] = v;
+    }
+  };
+  f32x4 acc[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float4 cur[4], nxt[4];
+  fetch(tile_row0(0), 0, cur);
+  float *__restrict__ C = p.C + (long)b * p.sC;
+  for (int i = 0; i < ntiles; ++i) {
+    const long row0 = tile_row0(i);
+    for (int gi = 0; gi < G; ++gi) {
+      const bool last = gi + 1 == G;
+      if (!last) fetch(row0, gi + 1, nxt);
+      else if (i + 1 < ntiles) fetch(tile_row0(i + 1), 0, nxt);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int si = gi * 4 + e;
+        if (si < nsteps) {
+          const int kb = steps[si].kofs + 4 * g;
+          const float av[4] = {cur[e].x, cur[e].y, cur[e].z, cur[e].w};
+          if constexpr (PR == 2) {
+            s16x4 ah, al;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const unsigned short h = to_bf16(av[q]);
+              ah[q] = (short)h;
+              al[q] = (short)to_bf16(av[q] - from_bf16(h));
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+              const s16x4 bh = *reinterpret_cast<const s16x4 *>(&Bh[(j * 16 + c) * ldk + kb]);
+              const s16x4 bl = *reinterpret_cast<const s16x4 *>(&Bl[(j * 16 + c) * ldk + kb]);
+              acc[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al, bh, acc[j], 0, 0, 0);
+              acc[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, bl, acc[j], 0, 0, 0);
+              acc[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, bh, acc[j], 0, 0, 0);
+            }
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+              for (int j = 0; j < NT; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], Bs[(kb + q) * ldn + j * 16 + c], acc[j], 0, 0, 0);
+          }
+        }
+      }
+      if (last) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const long gm = row0 + 4 * g + v;
+            const int gn = j * 16 + c;
+            if (gm < p.M && gn < p.N) {
+              float r = acc[j][v] * p.alpha;
+              if (p.bias) r += p.bias[gn];
+              if (p.accumulate) r += C[gm * p.ldc + gn];
+              C[gm * p.ldc + gn] = r;
+            }
+          }
+          acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) cur[e] = nxt[e];
+    }
+  }
+}
+
 // C[b][m][n] = sum over slices of part[s][b][m][n] (+ bias) (+ C), slices in ascending order.
 __global__ __launch_bounds__(256) void k_gemm_splitk_reduce(GemmP p, int batch) {
   const long per = (long)p.M * p.N, total = per * batch;
@@ -390,6 +530,45 @@ __global__ __launch_bounds__(256) void k_gemm_splitk_reduce(GemmP p, int batch) 
 }  // namespace vt
 
 using namespace vt;
+
+// Row-panel launch of a sum of products when it is tall and narrow and every A is 16-byte loadable; returns
+// 1 when it took the job, 0 when the tiled kernels should, < 0 on a launch error.
+static int panel_launch(int form, const GemmSumP &p, int batch, hipStream_t hs) {
+  static const bool off = [] {
+    const char *e = getenv("VT_GEMM_PANEL");
+    return e && *e == '0';
+  }();
+  if (off || (form != 0 && form != 2) || p.N > 128 || p.M < 2048 || batch > 65535) return 0;
+  int Kp = 0, nsteps = 0;
+  for (int i = 0; i < p.nterms; ++i) {
+    if (!p.t[i].vecA) return 0;
+    const int ns = (p.t[i].K + 15) / 16;
+    nsteps += ns;
+    Kp += ns * 16;
+  }
+  if (nsteps > PANEL_STEPS) return 0;
+  const int NT = p.N <= 16 ? 1 : p.N <= 32 ? 2 : p.N <= 64 ? 4 : 8;
+  const size_t lds = PANEL_HEAD + (form == 2 ? (size_t)2 * NT * 16 * (Kp + 4) * 2 : (size_t)Kp * (NT * 16 + 4) * 4);
+  if (lds > 64 * 1024) return 0;
+  // rows per workgroup: as many as leave a few thousand workgroups (the LDS copy of B is paid once per workgroup)
+  int rows = 512;
+  while (rows > 128 && (long)((p.M + rows - 1) / rows) * batch < 2048) rows >>= 1;
+  const dim3 grid((unsigned)((p.M + rows - 1) / rows), (unsigned)batch);
+#define VT_PANEL(PR_, NT_) hipLaunchKernelGGL((k_gemm_panel<PR_, NT_>), grid, dim3(256), lds, hs, p, rows, Kp, nsteps)
+#define VT_PANEL_NT(PR_)                 \
+  do {                                   \
+    if (NT == 1) VT_PANEL(PR_, 1);       \
+    else if (NT == 2) VT_PANEL(PR_, 2);  \
+    else if (NT == 4) VT_PANEL(PR_, 4);  \
+    else VT_PANEL(PR_, 8);               \
+  } while (0)
+  if (form == 2) VT_PANEL_NT(2);
+  else VT_PANEL_NT(0);
+#undef VT_PANEL_NT
+#undef VT_PANEL
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 1 : -(int)e;
+}
 
 static int gemm_launch(int form, int transA, int transB, int M, int N, int K, float alpha, const float *A, int lda,
                        long strideA, const float *B, int ldb, long strideB, int accumulate, float *C, int ldc, long strideC,
@@ -428,6 +607,13 @@ static int gemm_launch(int form, int transA, int transB, int M, int N, int K, fl
       p.ksplit = (K + p.kchunk - 1) / p.kchunk;
       p.part = workspace;
     }
+  }
+  if (!transA && p.ksplit == 1) {  // tall and narrow: the row-panel kernel
+    GemmSumP q{};
+    q.t[0] = GemmTerm{A, B, strideA, strideB, K, lda, ldb, transB ? 1 : 0, p.vecA, p.vecB};
+    q.nterms = 1; q.C = C; q.bias = bias; q.M = M; q.N = N; q.ldc = ldc; q.sC = strideC; q.alpha = alpha;
+    q.accumulate = p.accumulate;
+    if (const int took = panel_launch(form, q, batch, (hipStream_t)s)) return took > 0 ? 0 : -took;
   }
   const long gz = (long)batch * p.ksplit;
   if (gz > 65535) return VT_EUNSUPPORTED;
@@ -506,6 +692,7 @@ extern "C" int vt_gemm_sum(int form, int nterms, const vt_gemm_term *terms, int 
   }
   p.nterms = nterms; p.C = C; p.bias = bias; p.M = M; p.N = N; p.ldc = ldc; p.sC = strideC; p.alpha = alpha;
   p.accumulate = accumulate ? 1 : 0;
+  if (const int took = panel_launch(form, p, batch, (hipStream_t)s)) return took > 0 ? 0 : -took;
   int BM = 64, BN = 64;
   if (N > 64) {
     BN = 128;

@@ -419,13 +419,20 @@ __global__ __launch_bounds__(GT) void k_pool_fwd(const float *__restrict__ z, co
                                                  const float *__restrict__ g, const float *__restrict__ b,
                                                  float *__restrict__ pooled, int *__restrict__ pool_idx, long strips, int C2,
                                                  int H, int pk) {
-  extern __shared__ float lds[];  // [4 waves][W] best value, [4 waves][W] best row
+  extern __shared__ float lds[];  // [4 waves][W] best value, [4 waves][W] best row, [C2] mean, [C2] scale, [C2] beta
   const int W = H, P = H * W, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long sid_raw = (long)blockIdx.x * (GT / 64) + wave;
   const bool active = sid_raw < strips;
   const long sid = active ? sid_raw : strips - 1;  // idle waves redo the last strip's reads and write nothing
   float *__restrict__ bv = lds + wave * W;
   int *__restrict__ bk = reinterpret_cast<int *>(lds + (GT / 64) * W) + wave * W;
+  float *__restrict__ sm = lds + 2 * (GT / 64) * W, *__restrict__ sc = sm + C2, *__restrict__ sf = sc + C2;
+  for (int c = threadIdx.x; c < C2; c += GT) {  // y = (z - mean) * (inv * gamma) + beta
+    sm[c] = stat[c];
+    sc[c] = stat[C2 + c] * g[c];
+    sf[c] = b[c];
+  }
+  __syncthreads();
   const long nc = sid / 14;
   const int ii = (int)(sid - nc * 14);
   const float *__restrict__ plane = z + nc * P;
@@ -435,8 +442,24 @@ __global__ __launch_bounds__(GT) void k_pool_fwd(const float *__restrict__ z, co
     int c = (c_plane + (int)(((long)ii * pk * W + w) % C2)) % C2;
     float best = -INFINITY;
     int bki = 0;
-    for (int ki = 0; ki < pk; ++ki) {
-      const float y = fmaxf((plane[(ii * pk + ki) * W + w] - stat[c]) * stat[C2 + c] * g[c] + b[c], 0.f);
+    int ki = 0;
+    for (; ki + 4 <= pk; ki += 4) {  // four rows' loads in flight
+      float zv[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) zv[e] = plane[(ii * pk + ki + e) * W + w];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float y = fmaxf(fmaf(zv[e] - sm[c], sc[c], sf[c]), 0.f);
+        if (y > best) {
+          best = y;
+          bki = ki + e;
+        }
+        c += stepW;
+        if (c >= C2) c -= C2;
+      }
+    }
+    for (; ki < pk; ++ki) {
+      const float y = fmaxf(fmaf(plane[(ii * pk + ki) * W + w] - sm[c], sc[c], sf[c]), 0.f);
       if (y > best) {
         best = y;
         bki = ki;
@@ -964,7 +987,7 @@ int gen_forward(GenModel *g, const float *arena, const vt_layout *lo, float *are
   // reshape, max-pool, fc, softmax (vit_cnn.hpp:179-203)
   {
     const long strips = (long)n * C2 * 14;
-    hipLaunchKernelGGL(k_pool_fwd, dim3((unsigned)((strips + 3) / 4)), dim3(GT), (size_t)2 * (GT / 64) * g->H * sizeof(float), s,
+    hipLaunchKernelGGL(k_pool_fwd, dim3((unsigned)((strips + 3) / 4)), dim3(GT), ((size_t)2 * (GT / 64) * g->H + 3 * (size_t)C2) * sizeof(float), s,
                        g->z, g->stat_pn, W("proj.norm.gamma"), W("proj.norm.beta"), g->pooled, g->pool_idx, strips, C2, g->H,
                        g->pk);
     VT_CHECK_LAUNCH();
