@@ -385,9 +385,10 @@ struct PanelStep {
   int lda, K, k0, kofs;  // kofs: the step's first k row / column inside the LDS copy of op(B)
 };
 constexpr int PANEL_STEPS = 16, PANEL_HEAD = 512;  // bytes reserved in front of B for the step table
+constexpr int PANEL_T = 512, PANEL_W = PANEL_T / 64;  // eight waves share one LDS copy of B
 
 template <int PR, int NT>
-__global__ __launch_bounds__(256) void k_gemm_panel(GemmSumP p, int rows_per_wg, int Kp, int nsteps) {
+__global__ __launch_bounds__(PANEL_T) void k_gemm_panel(GemmSumP p, int rows_per_wg, int Kp, int nsteps) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   PanelStep *steps = reinterpret_cast<PanelStep *>(smem);
   constexpr int NP16 = NT * 16;
@@ -409,16 +410,72 @@ __global__ __launch_bounds__(256) void k_gemm_panel(GemmSumP p, int rows_per_wg,
         steps[tid] = PanelStep{t.A + (long)b * t.sA, t.lda, t.K, sidx * 16, kofs + sidx * 16};
       }
       const float *__restrict__ B = t.B + (long)b * t.sB;
-      for (int e = tid; e < K16 * NP16; e += 256) {
-        int k, n;
-        if (t.tb) { k = e % K16; n = e / K16; } else { n = e % NP16; k = e / NP16; }
-        const float v = (k < t.K && n < p.N) ? B[t.tb ? (long)n * t.ldb + k : (long)k * t.ldb + n] : 0.f;
+      auto put = [&](int k, int n, float v) {
         if constexpr (PR == 2) {
           const unsigned short h = to_bf16(v);
           Bh[n * ldk + kofs + k] = h;
           Bl[n * ldk + kofs + k] = to_bf16(v - from_bf16(h));
         } else {
           Bs[(kofs + k) * ldn + n] = v;
+        }
+      };
+      if (t.vecB) {  // 16-byte loads, eight per thread in flight before the first LDS store
+        const int qrow = t.tb ? K16 / 4 : NP16 / 4, Q = K16 * NP16 / 4;
+        for (int e0 = tid; e0 < Q; e0 += PANEL_T * 8) {
+          float4 v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int e = e0 + u * PANEL_T, major = e / qrow, minor = 4 * (e - major * qrow);
+            const int k = t.tb ? minor : major, n = t.tb ? major : minor;
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < Q && k < t.K && n < p.N)
+              v[u] = *reinterpret_cast<const float4 *>(B + (t.tb ? (long)n * t.ldb + k : (long)k * t.ldb + n));
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int e = e0 + u * PANEL_T, major = e / qrow, minor = 4 * (e - major * qrow);
+            if (e >= Q) continue;
+            const float x[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+            if (t.tb) {  // four consecutive k of row n
+              if constexpr (PR == 2) {
+                unsigned short h[4], l[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                  h[q] = to_bf16(x[q]);
+                  l[q] = to_bf16(x[q] - from_bf16(h[q]));
+                }
+                *reinterpret_cast<uint2 *>(&Bh[major * ldk + kofs + minor]) =
+                    make_uint2(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16));
+                *reinterpret_cast<uint2 *>(&Bl[major * ldk + kofs + minor]) =
+                    make_uint2(l[0] | ((unsigned)l[1] << 16), l[2] | ((unsigned)l[3] << 16));
+              } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) Bs[(kofs + minor + q) * ldn + major] = x[q];
+              }
+            } else {  // four consecutive n of row k
+              if constexpr (PR == 2) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) put(major, minor + q, x[q]);
+              } else {
+                *reinterpret_cast<float4 *>(&Bs[(kofs + major) * ldn + minor]) = v[u];
+              }
+            }
+          }
+        }
+      } else {
+        for (int e0 = tid; e0 < K16 * NP16; e0 += PANEL_T * 4) {
+          float v[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int e = e0 + u * PANEL_T;
+            const int k = t.tb ? e % K16 : e / NP16, n = t.tb ? e / K16 : e % NP16;
+            v[u] = (e < K16 * NP16 && k < t.K && n < p.N) ? B[t.tb ? (long)n * t.ldb + k : (long)k * t.ldb + n] : 0.f;
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int e = e0 + u * PANEL_T;
+            if (e < K16 * NP16) put(t.tb ? e % K16 : e / NP16, t.tb ? e / K16 : e % NP16, v[u]);
+          }
         }
       }
       kofs += K16;
@@ -429,8 +486,8 @@ __global__ __launch_bounds__(256) void k_gemm_panel(GemmSumP p, int rows_per_wg,
 
   const int G = (nsteps + 3) >> 2;  // groups of four steps: one group is in the matrix cores, the next in flight
   const long wg_row0 = (long)blockIdx.x * rows_per_wg;
-  const int ntiles = rows_per_wg / 64;  // 16-row tiles per wave: tile i of this wave is tile wave + 4 i of the workgroup
-  auto tile_row0 = [&](int i) { return wg_row0 + (long)(wave + 4 * i) * 16; };
+  const int ntiles = rows_per_wg / (16 * PANEL_W);  // 16-row tiles per wave: tile i of this wave is tile wave + PANEL_W i of the workgroup
+  auto tile_row0 = [&](int i) { return wg_row0 + (long)(wave + PANEL_W * i) * 16; };
   auto fetch = [&](long row0, int gi, float4 (&dst)[4]) {
     const long row = row0 + c;
 #pragma unroll
@@ -451,6 +508,7 @@ __global__ __launch_bounds__(256) void k_gemm_panel(GemmSumP p, int rows_per_wg,
   float4 cur[4], nxt[4];
   fetch(tile_row0(0), 0, cur);
   float *__restrict__ C = p.C + (long)b * p.sC;
+  const bool vecC = (reinterpret_cast<uintptr_t>(p.C) & 15) == 0 && p.ldc % 4 == 0 && p.sC % 4 == 0;
   for (int i = 0; i < ntiles; ++i) {
     const long row0 = tile_row0(i);
     for (int gi = 0; gi < G; ++gi) {
@@ -475,31 +533,44 @@ __global__ __launch_bounds__(256) void k_gemm_panel(GemmSumP p, int rows_per_wg,
             for (int j = 0; j < NT; ++j) {
               const s16x4 bh = *reinterpret_cast<const s16x4 *>(&Bh[(j * 16 + c) * ldk + kb]);
               const s16x4 bl = *reinterpret_cast<const s16x4 *>(&Bl[(j * 16 + c) * ldk + kb]);
-              acc[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al, bh, acc[j], 0, 0, 0);
-              acc[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, bl, acc[j], 0, 0, 0);
-              acc[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, bh, acc[j], 0, 0, 0);
+              // op(B)^T . A^T: the result tile comes out transposed, a lane holding four adjacent columns of
+              // one row of C (one 16-byte store)
+              acc[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bh, al, acc[j], 0, 0, 0);
+              acc[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bl, ah, acc[j], 0, 0, 0);
+              acc[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bh, ah, acc[j], 0, 0, 0);
             }
           } else {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
               for (int j = 0; j < NT; ++j)
-                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], Bs[(kb + q) * ldn + j * 16 + c], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(Bs[(kb + q) * ldn + j * 16 + c], av[q], acc[j], 0, 0, 0);
           }
         }
       }
       if (last) {
+        const long gm = row0 + c;  // lane (c, g) holds C[row c][16 j + 4 g .. + 3]
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
+          const int gn = j * 16 + 4 * g;
+          if (gm < p.M && gn < p.N) {
+            float *__restrict__ dst = C + gm * p.ldc + gn;
+            float r[4];
 #pragma unroll
-          for (int v = 0; v < 4; ++v) {
-            const long gm = row0 + 4 * g + v;
-            const int gn = j * 16 + c;
-            if (gm < p.M && gn < p.N) {
-              float r = acc[j][v] * p.alpha;
-              if (p.bias) r += p.bias[gn];
-              if (p.accumulate) r += C[gm * p.ldc + gn];
-              C[gm * p.ldc + gn] = r;
+            for (int v = 0; v < 4; ++v) {
+              r[v] = acc[j][v] * p.alpha;
+              if (p.bias && gn + v < p.N) r[v] += p.bias[gn + v];
+            }
+            if (vecC && gn + 3 < p.N) {
+              if (p.accumulate) {
+                const float4 o = *reinterpret_cast<const float4 *>(dst);
+                r[0] += o.x; r[1] += o.y; r[2] += o.z; r[3] += o.w;
+              }
+              *reinterpret_cast<float4 *>(dst) = make_float4(r[0], r[1], r[2], r[3]);
+            } else {
+#pragma unroll
+              for (int v = 0; v < 4; ++v)
+                if (gn + v < p.N) dst[v] = p.accumulate ? r[v] + dst[v] : r[v];
             }
           }
           acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -551,10 +622,10 @@ static int panel_launch(int form, const GemmSumP &p, int batch, hipStream_t hs) 
   const size_t lds = PANEL_HEAD + (form == 2 ? (size_t)2 * NT * 16 * (Kp + 4) * 2 : (size_t)Kp * (NT * 16 + 4) * 4);
   if (lds > 64 * 1024) return 0;
   // rows per workgroup: as many as leave a few thousand workgroups (the LDS copy of B is paid once per workgroup)
-  int rows = 512;
+  int rows = 1024;
   while (rows > 128 && (long)((p.M + rows - 1) / rows) * batch < 2048) rows >>= 1;
   const dim3 grid((unsigned)((p.M + rows - 1) / rows), (unsigned)batch);
-#define VT_PANEL(PR_, NT_) hipLaunchKernelGGL((k_gemm_panel<PR_, NT_>), grid, dim3(256), lds, hs, p, rows, Kp, nsteps)
+#define VT_PANEL(PR_, NT_) hipLaunchKernelGGL((k_gemm_panel<PR_, NT_>), grid, dim3(PANEL_T), lds, hs, p, rows, Kp, nsteps)
 #define VT_PANEL_NT(PR_)                 \
   do {                                   \
     if (NT == 1) VT_PANEL(PR_, 1);       \
