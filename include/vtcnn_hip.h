@@ -487,6 +487,15 @@ typedef struct vt_gemm_term {
 } vt_gemm_term;
 int vt_gemm_sum(int form, int nterms, const vt_gemm_term *terms, int M, int N, float alpha, int accumulate, float *C,
                 int ldc, long strideC, const float *bias, int batch, vt_stream s);
+/* A product whose rows go straight through Tensor::softmax over the last axis (epi 1; the projector's attention map,
+ * layers/projector_layer.hpp:80-84) or through Tensor::softmax_backward against a [batch, M, N] (epi 2: C <- a * (C -
+ * sum_row a * C); layers/projector_layer.hpp:163-171, layers/tokenizer.hpp:88-91):  C[b] = epi(alpha * A[b] . op(B[b])),
+ * C dense [batch, M, N] with strideC = M * N.  One launch when M is tall, N <= 16 and A is 16-byte loadable (the epilogue
+ * runs on the accumulators); otherwise the product followed by vt_softmax_rows / vt_softmax_bwd_rows.  form: 0 exact
+ * fp32, 2 hi/lo split. */
+int vt_gemm_softmax_rows(int form, int epi, const float *a, int transB, int M, int N, int K, float alpha, const float *A,
+                         int lda, long strideA, const float *B, int ldb, long strideB, float *C, long strideC, int batch,
+                         vt_stream s);
 /* Tensor::softmax over the last axis (tensor_cpu.hpp:894-944), in place on S [rows, width], and
  * Tensor::softmax_backward (tensor_cpu.hpp:946-950): da <- a * (da - sum_last(a * da)), in place on da. */
 int vt_softmax_rows(float *S, long rows, int width, vt_stream s);

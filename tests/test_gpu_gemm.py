@@ -147,6 +147,38 @@ def test_gemm_sum_of_products(form, tol):
     assert lib.vt_gemm_sum(0, 1, bad, 4, 4, 1.0, 0, C.c_void_p(dC.data_ptr()), 4, 16, None, 1, None) != 0  # NULL operands
 
 
+@pytest.mark.parametrize("form,tol", [(0, 3e-6), (2, 3e-5)])
+def test_gemm_with_softmax_epilogues(form, tol):
+    """vt_gemm_softmax_rows: product + softmax over each row, and product + softmax backward against a, where the
+    row-panel kernel applies the epilogue to its accumulators (tall M, N <= 16) and where it falls back to two
+    launches (short M, N > 16), against numpy in double precision."""
+    import torch
+    from vit_amd._lib import check, lib
+    rng = np.random.default_rng(3)
+    for (M, N, K, batch, tb) in [(5000, 16, 64, 2, 1), (3000, 10, 20, 3, 0), (2048, 16, 128, 1, 1), (70000, 7, 36, 1, 0),
+                                 (300, 16, 64, 2, 1), (2500, 33, 64, 2, 0)]:
+        A = rng.standard_normal((batch, M, K)).astype(np.float32)
+        B = (rng.standard_normal((batch, N, K) if tb else (batch, K, N)) * 0.3).astype(np.float32)
+        prod = 0.5 * (A.astype(np.float64) @ (np.swapaxes(B, 1, 2) if tb else B).astype(np.float64))
+        e = np.exp(prod - prod.max(axis=2, keepdims=True))
+        soft = e / e.sum(axis=2, keepdims=True)
+        a = rng.random((batch, M, N)).astype(np.float32)
+        bwd = a.astype(np.float64) * (prod - (a.astype(np.float64) * prod).sum(axis=2, keepdims=True))
+        dA, dB, da = torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda(), torch.from_numpy(a).cuda()
+        for epi, want in ((1, soft), (2, bwd)):
+            dC = torch.full((batch, M, N), 7.0, dtype=torch.float32, device="cuda")
+            check(lib.vt_gemm_softmax_rows(form, epi, C.c_void_p(da.data_ptr()) if epi == 2 else None, tb, M, N, K, 0.5,
+                                           C.c_void_p(dA.data_ptr()), K, M * K, C.c_void_p(dB.data_ptr()), K if tb else N,
+                                           N * K, C.c_void_p(dC.data_ptr()), M * N, batch,
+                                           C.c_void_p(torch.cuda.current_stream().cuda_stream)), "vt_gemm_softmax_rows")
+            torch.cuda.synchronize()
+            assert rel_err(dC.cpu().numpy(), want) < tol, (M, N, K, epi)
+    assert lib.vt_gemm_softmax_rows(1, 1, None, 0, 4, 4, 4, 1.0, C.c_void_p(dA.data_ptr()), 4, 0, C.c_void_p(dB.data_ptr()), 4, 0,
+                                    C.c_void_p(dC.data_ptr()), 16, 1, None) != 0  # no bf16 form
+    assert lib.vt_gemm_softmax_rows(0, 2, None, 0, 4, 4, 4, 1.0, C.c_void_p(dA.data_ptr()), 4, 0, C.c_void_p(dB.data_ptr()), 4, 0,
+                                    C.c_void_p(dC.data_ptr()), 16, 1, None) != 0  # backward needs a
+
+
 def _bf16_round(a):
     u = a.astype(np.float32).view(np.uint32).astype(np.uint64)
     u = (u + 0x7FFF + ((u >> 16) & 1)) >> 16 << 16

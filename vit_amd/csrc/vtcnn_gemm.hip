@@ -325,6 +325,10 @@ struct GemmSumP {
   long sC;
   float alpha;
   int accumulate;
+  // row-panel kernel, N <= 16 only: 1 = softmax over the row (Tensor::softmax over the last axis), 2 = its
+  // backward r <- a * (r - sum_row a * r) with a = epi_a (laid out like C); 0 = none
+  int epi;
+  const float *epi_a;
 };
 template <int PR, int BM, int BN>
 __global__ __launch_bounds__(256) void k_gemm_sum(GemmSumP p) {
@@ -553,14 +557,46 @@ __global__ __launch_bounds__(PANEL_T) void k_gemm_panel(GemmSumP p, int rows_per
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
           const int gn = j * 16 + 4 * g;
-          if (gm < p.M && gn < p.N) {
-            float *__restrict__ dst = C + gm * p.ldc + gn;
-            float r[4];
+          const bool row_on = gm < p.M;
+          float r[4];
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
-              r[v] = acc[j][v] * p.alpha;
-              if (p.bias && gn + v < p.N) r[v] += p.bias[gn + v];
+          for (int v = 0; v < 4; ++v) {
+            r[v] = acc[j][v] * p.alpha;
+            if (p.bias && gn + v < p.N) r[v] += p.bias[gn + v];
+          }
+          if (NT == 1 && p.epi != 0) {  // a row's (at most) 16 values sit in the four lanes c, c+16, c+32, c+48
+            if (p.epi == 1) {
+              float mx = -INFINITY;
+#pragma unroll
+              for (int v = 0; v < 4; ++v)
+                if (gn + v < p.N) mx = fmaxf(mx, r[v]);
+              mx = fmaxf(mx, __shfl_xor(mx, 16));
+              mx = fmaxf(mx, __shfl_xor(mx, 32));
+              float sum = 0.f;
+#pragma unroll
+              for (int v = 0; v < 4; ++v) {
+                r[v] = gn + v < p.N ? expf(r[v] - mx) : 0.f;
+                sum += r[v];
+              }
+              sum += __shfl_xor(sum, 16);
+              sum += __shfl_xor(sum, 32);
+#pragma unroll
+              for (int v = 0; v < 4; ++v) r[v] /= sum;
+            } else {
+              float a[4], dot = 0.f;
+#pragma unroll
+              for (int v = 0; v < 4; ++v) {
+                a[v] = (row_on && gn + v < p.N) ? p.epi_a[(long)b * p.sC + gm * p.ldc + gn + v] : 0.f;
+                dot += a[v] * r[v];
+              }
+              dot += __shfl_xor(dot, 16);
+              dot += __shfl_xor(dot, 32);
+#pragma unroll
+              for (int v = 0; v < 4; ++v) r[v] = a[v] * (r[v] - dot);
             }
+          }
+          if (row_on && gn < p.N) {
+            float *__restrict__ dst = C + gm * p.ldc + gn;
             if (vecC && gn + 3 < p.N) {
               if (p.accumulate) {
                 const float4 o = *reinterpret_cast<const float4 *>(dst);
@@ -610,6 +646,7 @@ static int panel_launch(int form, const GemmSumP &p, int batch, hipStream_t hs) 
     return e && *e == '0';
   }();
   if (off || (form != 0 && form != 2) || p.N > 128 || p.M < 2048 || batch > 65535) return 0;
+  if (p.epi != 0 && (p.N > 16 || p.accumulate)) return 0;
   int Kp = 0, nsteps = 0;
   for (int i = 0; i < p.nterms; ++i) {
     if (!p.t[i].vecA) return 0;
@@ -784,4 +821,26 @@ extern "C" int vt_gemm_sum(int form, int nterms, const vt_gemm_term *terms, int 
 #undef VT_SUM_LAUNCH
   VT_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int vt_gemm_softmax_rows(int form, int epi, const float *a, int transB, int M, int N, int K, float alpha,
+                                    const float *A, int lda, long strideA, const float *B, int ldb, long strideB, float *C,
+                                    long strideC, int batch, vt_stream s) {
+  if ((form != 0 && form != 2) || (epi != 1 && epi != 2) || M < 1 || N < 1 || K < 1 || batch < 1 || !A || !B || !C ||
+      (epi == 2 && !a))
+    return VT_EINVAL;
+  if (lda < K || ldb < (transB ? K : N)) return VT_EINVAL;
+  auto aligned = [](const float *q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  GemmSumP q{};
+  q.t[0] = GemmTerm{A, B, strideA, strideB, K, lda, ldb, transB ? 1 : 0,
+                    aligned(A) && lda % 4 == 0 && strideA % 4 == 0 && K % 4 == 0,
+                    aligned(B) && ldb % 4 == 0 && strideB % 4 == 0 && (transB ? K % 4 == 0 : N % 4 == 0)};
+  q.nterms = 1; q.C = C; q.M = M; q.N = N; q.ldc = N; q.sC = strideC; q.alpha = alpha; q.epi = epi; q.epi_a = a;
+  if (const int took = panel_launch(form, q, batch, (hipStream_t)s)) return took > 0 ? 0 : -took;
+  // shapes the row-panel kernel does not take with an epilogue: the product, then the softmax kernel over its rows
+  if (batch > 1 && strideC != (long)M * N) return VT_EUNSUPPORTED;
+  const int rc = gemm_launch(form, 0, transB, M, N, K, alpha, A, lda, strideA, B, ldb, strideB, 0, C, N, strideC, nullptr, batch,
+                             nullptr, 0, s);
+  if (rc != 0) return rc;
+  return epi == 1 ? vt_softmax_rows(C, (long)M * batch, N, s) : vt_softmax_bwd_rows(a, C, (long)M * batch, N, s);
 }

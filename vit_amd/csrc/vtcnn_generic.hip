@@ -859,6 +859,12 @@ int softmax_bwd_rows(const float *a, float *da, long rows, int Wd, hipStream_t s
   return 0;
 }
 
+// product + row softmax (epi 1) or softmax backward against a (epi 2): one launch where the row-panel kernel can
+int mm_softmax(vt::GenModel *, int form, int epi, const float *a, bool tb, int M, int N, int K, const float *A, int lda,
+               long sA, const float *B, int ldb, long sB, float *C, int batch, hipStream_t s) {
+  return vt_gemm_softmax_rows(form, epi, a, tb, M, N, K, 1.f, A, lda, sA, B, ldb, sB, C, (long)M * N, batch, (vt_stream)s);
+}
+
 }  // namespace
 
 namespace vt {
@@ -976,8 +982,8 @@ int gen_forward(GenModel *g, const float *arena, const vt_layout *lo, float *are
   VTG(mm_bf_exact(false, false, (int)NP, D, C1, g->x, C1, W("proj.linear1.W"), D, g->q, D));
   VTG(mm_bf_exact(false, false, (int)NL, D, D, g->o, D, W("proj.linear2.W"), D, g->k, D));
   VTG(mm_bf(false, false, (int)NL, C2, D, g->o, D, W("proj.linear3.W"), C2, g->v, C2, W("proj.linear3.b")));
-  VTG(mm_exact(false, true, P, L, D, g->q, D, g->k, D, g->pa, L, nullptr, false, 1.f, n, (long)P * D, (long)L * D, (long)P * L));
-  VTG(softmax_rows(g->pa, NP, L, s));
+  // scores and their softmax over the tokens (projector_layer.hpp:80-84): exact fp32, they feed the exponential
+  VTG(mm_softmax(g, 0, 1, nullptr, true, P, L, D, g->q, D, (long)P * D, g->k, D, (long)L * D, g->pa, n, s));
   {  // z = downsample(x) + attention . values (projector_layer.hpp:93-100), one pass, z written once
     const vt_gemm_term t[2] = {{g->x, W("proj.downsample.W"), (long)P * C1, 0, C1, C1, C2, 0},
                                {g->pa, g->v, (long)P * L, (long)L * C2, L, L, C2, 0}};
@@ -1022,11 +1028,10 @@ int gen_backward(GenModel *g, const float *arena, const vt_layout *lo, float *gr
     VTG(pool_bn_backward(g, W("proj.norm.gamma"), G("proj.norm.gamma"), G("proj.norm.beta"), G("proj.downsample.b"), n, s));
     VTG(mm(true, false, C1, C2, (int)NP, g->x, C1, g->dz, C2, G("proj.downsample.W"), C2));
     // delta of the attention map, softmax backward over tokens, deltas of q / k / v
-    VTG(mm(false, true, P, L, C2, g->dz, C2, g->v, C2, g->dsa, L, nullptr, false, 1.f, n, (long)P * C2, (long)L * C2,
-           (long)P * L));
+    VTG(mm_softmax(g, C2 >= 32 ? sum_form() : 0, 2, g->pa, true, P, L, C2, g->dz, C2,
+                   (long)P * C2, g->v, C2, (long)L * C2, g->dsa, n, s));
     VTG(mm(true, false, L, C2, P, g->pa, L, g->dz, C2, g->dv, C2, nullptr, false, 1.f, n, (long)P * L, (long)P * C2,
            (long)L * C2));
-    VTG(softmax_bwd_rows(g->pa, g->dsa, NP, L, s));
     VTG(mm(false, false, P, D, L, g->dsa, L, g->k, D, g->dq, D, nullptr, false, 1.f, n, (long)P * L, (long)L * D,
            (long)P * D));
     VTG(mm(true, false, L, D, P, g->dsa, L, g->q, D, g->dk, D, nullptr, false, 1.f, n, (long)P * L, (long)P * D,
@@ -1055,9 +1060,8 @@ int gen_backward(GenModel *g, const float *arena, const vt_layout *lo, float *gr
     // FilterTokenizer::backward2 (tokenizer.hpp:50-107): the softmax over pixels is differentiated over
     // the token axis (:91); the tokenizer's own weights stay frozen (their gradients are never applied)
     VTG(mm(false, true, (int)NL, C1, D, g->pdt, D, W("tok.linear2.W"), D, g->dT0, C1));
-    VTG(mm(false, true, P, L, C1, g->x, C1, g->dT0, C1, g->dsa, L, nullptr, false, 1.f, n, (long)P * C1, (long)L * C1,
-           (long)P * L));
-    VTG(softmax_bwd_rows(g->tokA, g->dsa, NP, L, s));
+    VTG(mm_softmax(g, C1 >= 32 ? sum_form() : 0, 2, g->tokA, true, P, L, C1, g->x, C1, (long)P * C1, g->dT0, C1, (long)L * C1,
+                   g->dsa, n, s));
     // the input deltas of the projector (through the downsample and through the queries) and of the tokenizer
     // (a^T path, score path) are one sum of four products, written once (projector_layer.hpp:196-213,
     // tokenizer.hpp:93-106)
