@@ -168,6 +168,48 @@ __device__ __forceinline__ void store_tile_bf16(unsigned short (*T)[GBK + HPAD],
   }
 }
 
+// Operand whose contiguous index is the row (A transposed, B as stored) on its way into the bf16 layouts [row][k]:
+// a thread takes four consecutive k of ONE row (four 4-byte loads, each coalesced over the 64 rows of its wave), so
+// that its LDS store is one 8-byte word per half instead of four scattered 2-byte stores.
+template <int R>
+__device__ __forceinline__ void load_tile_kq(const float *__restrict__ base, int ld, int r0, int rows, int k0, int kend,
+                                             int tid, float (&reg)[R / 16]) {
+#pragma unroll
+  for (int hb = 0; hb < R / 64; ++hb) {
+    const int gr = r0 + (tid & 63) + 64 * hb;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int gk = k0 + 4 * (tid >> 6) + j;
+      reg[4 * hb + j] = (gr < rows && gk < kend) ? base[(long)gk * ld + gr] : 0.f;
+    }
+  }
+}
+template <int PR, int R>
+__device__ __forceinline__ void store_tile_kq(unsigned short (*Th)[GBK + HPAD], unsigned short (*Tl)[GBK + HPAD], int tid,
+                                              const float (&reg)[R / 16]) {
+#pragma unroll
+  for (int hb = 0; hb < R / 64; ++hb) {
+    const int r = (tid & 63) + 64 * hb, k = 4 * (tid >> 6);
+    unsigned short h[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) h[j] = to_bf16(reg[4 * hb + j]);
+    *reinterpret_cast<uint2 *>(&Th[r][k]) = make_uint2(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16));
+    if constexpr (PR == 2) {
+      unsigned short l[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) l[j] = to_bf16(reg[4 * hb + j] - from_bf16(h[j]));
+      *reinterpret_cast<uint2 *>(&Tl[r][k]) = make_uint2(l[0] | ((unsigned)l[1] << 16), l[2] | ((unsigned)l[3] << 16));
+    }
+  }
+}
+// memory -> registers in the mapping the kernel's form stages from
+template <bool ALONG_K, int PR, int R>
+__device__ __forceinline__ void fetch_tile(const float *__restrict__ base, int ld, int r0, int rows, int k0, int kend, bool vec,
+                                           int tid, float (&reg)[R / 16]) {
+  if constexpr (!ALONG_K && PR != 0) load_tile_kq<R>(base, ld, r0, rows, k0, kend, tid, reg);
+  else load_tile<ALONG_K, R>(base, ld, r0, rows, k0, kend, vec, tid, reg);
+}
+
 // LDS tiles of one workgroup (only the arrays of the kernel's arithmetic form have a size)
 template <int PR, int BM, int BN>
 struct GemmLds {
@@ -183,7 +225,8 @@ struct GemmLds {
 template <bool ALONG_K, int PR, int R>
 __device__ __forceinline__ void stage_tile(float (*Tf)[R + GPAD], unsigned short (*Th)[GBK + HPAD],
                                            unsigned short (*Tl)[GBK + HPAD], bool vec, int tid, const float (&reg)[R / 16]) {
-  if constexpr (PR == 2) store_tile_split<ALONG_K, R>(Th, Tl, vec, tid, reg);
+  if constexpr (!ALONG_K && PR != 0) store_tile_kq<PR, R>(Th, Tl, tid, reg);
+  else if constexpr (PR == 2) store_tile_split<ALONG_K, R>(Th, Tl, vec, tid, reg);
   else if constexpr (PR == 1) store_tile_bf16<ALONG_K, R>(Th, vec, tid, reg);
   else store_tile<ALONG_K, R>(Tf, vec, tid, reg);
 }
@@ -269,14 +312,31 @@ __device__ __forceinline__ void gemm_store(const f32x4 (&acc)[BM / 32][BN / 32],
       }
 }
 
+// Which tile a workgroup takes.  Workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one, and with it
+// an L2), so the dispatch index is first regrouped by XCD (index b -> (b % 8) * total / 8 + b / 8), and the regrouped
+// index walks the N tiles fastest, then the M tiles, then batch members / K slices: the workgroups resident on one XCD
+// at a time then cover every N tile of a run of M tiles, and an operand tile that several of them need comes out of
+// that XCD's L2 instead of out of memory once per consumer.  A speed hint only: nothing depends on the placement.
+__device__ __forceinline__ void tile_of_block(unsigned &bx, unsigned &by, unsigned &bz) {
+  const unsigned gx = gridDim.x, gy = gridDim.y, total = gx * gy * gridDim.z;
+  const unsigned bid = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+  const unsigned lid = (total & 7u) == 0 ? (bid & 7u) * (total >> 3) + (bid >> 3) : bid;
+  by = lid % gy;
+  const unsigned t = lid / gy;
+  bx = t % gx;
+  bz = t / gx;
+}
+
 // BM x BN: the workgroup's tile of C (64x64 for narrow or small products, 64x128 when only N is
 // wide, 128x128 for the wide shapes: each wave then owns 64x64 = 4x4 MFMA tiles and an LDS operand
 // read feeds four matrix instructions instead of two).
 template <bool TA, bool TB, int PR, int BM, int BN>
 __global__ __launch_bounds__(256) void k_gemm(GemmP p) {
   __shared__ GemmLds<PR, BM, BN> L;
-  const int b = blockIdx.z / p.ksplit, ks = blockIdx.z - b * p.ksplit;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;  // rows on x: the batch's pixel rows run into the millions
+  unsigned bx, by, bz;
+  tile_of_block(bx, by, bz);
+  const int b = bz / p.ksplit, ks = bz - b * p.ksplit;
+  const int m0 = bx * BM, n0 = by * BN;  // rows on x: the batch's pixel rows run into the millions
   const int kbeg = ks * p.kchunk, kend = min(p.K, kbeg + p.kchunk);
   f32x4 acc[BM / 32][BN / 32];
 #pragma unroll
@@ -289,16 +349,16 @@ __global__ __launch_bounds__(256) void k_gemm(GemmP p) {
   const bool vecA = p.vecA != 0, vecB = p.vecB != 0;
   // the next K step's tiles travel from memory while the matrix cores work on the current one
   float ra[BM / 16], rb[BN / 16];
-  load_tile<!TA, BM>(A, p.lda, m0, p.M, kbeg, kend, vecA, tid, ra);
-  load_tile<TB, BN>(B, p.ldb, n0, p.N, kbeg, kend, vecB, tid, rb);
+  fetch_tile<!TA, PR, BM>(A, p.lda, m0, p.M, kbeg, kend, vecA, tid, ra);
+  fetch_tile<TB, PR, BN>(B, p.ldb, n0, p.N, kbeg, kend, vecB, tid, rb);
   for (int k0 = kbeg; k0 < kend; k0 += GBK) {
     __syncthreads();  // the previous step's tile reads are over
     stage_tile<!TA, PR, BM>(L.As, L.Ah, L.Al, vecA, tid, ra);
     stage_tile<TB, PR, BN>(L.Bs, L.Bh, L.Bl, vecB, tid, rb);
     __syncthreads();
     if (k0 + GBK < kend) {
-      load_tile<!TA, BM>(A, p.lda, m0, p.M, k0 + GBK, kend, vecA, tid, ra);
-      load_tile<TB, BN>(B, p.ldb, n0, p.N, k0 + GBK, kend, vecB, tid, rb);
+      fetch_tile<!TA, PR, BM>(A, p.lda, m0, p.M, k0 + GBK, kend, vecA, tid, ra);
+      fetch_tile<TB, PR, BN>(B, p.ldb, n0, p.N, k0 + GBK, kend, vecB, tid, rb);
     }
     gemm_step<PR, BM, BN>(L, acc);
   }
@@ -333,8 +393,10 @@ struct GemmSumP {
 template <int PR, int BM, int BN>
 __global__ __launch_bounds__(256) void k_gemm_sum(GemmSumP p) {
   __shared__ GemmLds<PR, BM, BN> L;
-  const int b = blockIdx.z;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  unsigned bx, by, bz;
+  tile_of_block(bx, by, bz);
+  const int b = bz;
+  const int m0 = bx * BM, n0 = by * BN;
   f32x4 acc[BM / 32][BN / 32];
 #pragma unroll
   for (int i = 0; i < BM / 32; ++i)
@@ -347,9 +409,9 @@ __global__ __launch_bounds__(256) void k_gemm_sum(GemmSumP p) {
   const int tid = threadIdx.x;
   auto term = [&](int ti) { return ti == 0 ? p.t[0] : ti == 1 ? p.t[1] : ti == 2 ? p.t[2] : p.t[3]; };
   auto fetch = [&](const GemmTerm &t, int k0, float (&ra)[BM / 16], float (&rb)[BN / 16]) {
-    load_tile<true, BM>(t.A + (long)b * t.sA, t.lda, m0, p.M, k0, t.K, t.vecA != 0, tid, ra);
-    if (t.tb) load_tile<true, BN>(t.B + (long)b * t.sB, t.ldb, n0, p.N, k0, t.K, t.vecB != 0, tid, rb);
-    else load_tile<false, BN>(t.B + (long)b * t.sB, t.ldb, n0, p.N, k0, t.K, t.vecB != 0, tid, rb);
+    fetch_tile<true, PR, BM>(t.A + (long)b * t.sA, t.lda, m0, p.M, k0, t.K, t.vecA != 0, tid, ra);
+    if (t.tb) fetch_tile<true, PR, BN>(t.B + (long)b * t.sB, t.ldb, n0, p.N, k0, t.K, t.vecB != 0, tid, rb);
+    else fetch_tile<false, PR, BN>(t.B + (long)b * t.sB, t.ldb, n0, p.N, k0, t.K, t.vecB != 0, tid, rb);
   };
   float ra[BM / 16], rb[BN / 16];
   int ti = 0, k0 = 0;
@@ -727,6 +789,7 @@ static int gemm_launch(int form, int transA, int transB, int M, int N, int K, fl
   if (gz > 65535) return VT_EUNSUPPORTED;
   if ((N + BN - 1) / BN > 65535) return VT_EUNSUPPORTED;
   const dim3 grid((M + BM - 1) / BM, (N + BN - 1) / BN, (unsigned)gz);
+  if ((long)grid.x * grid.y * grid.z >= (1L << 32)) return VT_EUNSUPPORTED;  // tile_of_block counts workgroups in 32 bits
   hipStream_t hs = (hipStream_t)s;
 #define VT_GEMM_LAUNCH(TA_, TB_, BF_)                                                                                  \
   do {                                                                                                                 \
@@ -808,6 +871,7 @@ extern "C" int vt_gemm_sum(int form, int nterms, const vt_gemm_term *terms, int 
   }
   if (batch > 65535 || (N + BN - 1) / BN > 65535) return VT_EUNSUPPORTED;
   const dim3 grid((M + BM - 1) / BM, (N + BN - 1) / BN, (unsigned)batch);
+  if ((long)grid.x * grid.y * grid.z >= (1L << 32)) return VT_EUNSUPPORTED;
   hipStream_t hs = (hipStream_t)s;
 #define VT_SUM_LAUNCH(PR_)                                                                               \
   do {                                                                                                   \
