@@ -15,12 +15,12 @@ struct GenModel {
   int Ci, H, P, C1, C2, L, D, heads, hd, K, Q, pk, maxN;
   int bf16;  // 1: products other than the gradient contractions run through bf16 operands
   // forward
-  float *col, *conv, *x, *tokA, *T0, *tok, *a, *hdn, *rl, *s2, *o, *q, *k, *v, *pa, *z, *pooled, *logits, *probs;
+  float *col, *conv, *x, *tokA, *T0, *tok, *a, *hdn, *rl, *s2, *o, *Mq, *k, *v, *pa, *z, *pooled, *logits, *probs;
   int *pool_idx;
   float *stat_bn, *stat_n1, *stat_n2, *stat_pn, *coef, *part, *ws, *spx;
   long part_floats, ws_floats;
   // backward
-  float *dlogits, *dpool, *du, *dz, *pdx, *dsa, *dq, *dv, *dk, *pdt, *d0, *ds2, *dh, *da, *dr, *dc;
+  float *dlogits, *dpool, *du, *dz, *pdx, *dsa, *dsa_tok, *U, *dv, *dk, *pdt, *d0, *ds2, *dh, *da, *dr, *dc;
   float *Qm, *Km, *Vm, *dQ, *dK, *dV, *attn, *dat, *dT0, *tdx;
 };
 

@@ -891,7 +891,7 @@ int gen_create(GenModel *g, const vt_dims *d, int maxN, int (*alloc)(void *, flo
   A(&g->rl, NL * D, nullptr);
   A(&g->s2, NL * D, "fwd.tr_s2");
   A(&g->o, NL * D, "fwd.tr_out");
-  A(&g->q, NP * D, nullptr);
+  A(&g->Mq, N * C1 * L, nullptr);  // per image: proj.linear1.W . keys^T, the folded query projection
   A(&g->k, NL * D, nullptr);
   A(&g->v, NL * C2, nullptr);
   A(&g->pa, NP * L, "fwd.proj_a");
@@ -919,7 +919,8 @@ int gen_create(GenModel *g, const vt_dims *d, int maxN, int (*alloc)(void *, flo
   A(&g->dz, NP * C2, "bwd.proj_dz");
   A(&g->pdx, NP * C1, "bwd.proj_dx");
   A(&g->dsa, NP * L, nullptr);
-  A(&g->dq, NP * D, nullptr);
+  A(&g->dsa_tok, NP * L, nullptr);
+  A(&g->U, NL * C1, nullptr);
   A(&g->dv, NL * C2, "bwd.proj_dv");
   A(&g->dk, NL * D, "bwd.proj_dk");
   A(&g->pdt, NL * D, "bwd.proj_dt");
@@ -979,11 +980,15 @@ int gen_forward(GenModel *g, const float *arena, const vt_layout *lo, float *are
   VTG(bn_stats(g, g->s2, NL, D, RW("norm2.running_mean"), RW("norm2.running_var"), g->stat_n2, false, s));
   VTG(col_affine(0, g->s2, g->stat_n2, W("norm2.gamma"), W("norm2.beta"), g->o, NL, D, s));
   // ProjectorLayer::forward (projector_layer.hpp:43-116)
-  VTG(mm_bf_exact(false, false, (int)NP, D, C1, g->x, C1, W("proj.linear1.W"), D, g->q, D));
   VTG(mm_bf_exact(false, false, (int)NL, D, D, g->o, D, W("proj.linear2.W"), D, g->k, D));
   VTG(mm_bf(false, false, (int)NL, C2, D, g->o, D, W("proj.linear3.W"), C2, g->v, C2, W("proj.linear3.b")));
-  // scores and their softmax over the tokens (projector_layer.hpp:80-84): exact fp32, they feed the exponential
-  VTG(mm_softmax(g, 0, 1, nullptr, true, P, L, D, g->q, D, (long)P * D, g->k, D, (long)L * D, g->pa, n, s));
+  // scores and their softmax over the tokens (projector_layer.hpp:80-84): exact fp32, they feed the exponential.
+  // The queries (x . linear1.W, projector_layer.hpp:62) only ever meet the keys of their own image, so the
+  // product is associated the other way: Mq[n] = linear1.W . keys[n]^T ([C1, L], a few KB per image), and the
+  // scores are x[n] . Mq[n]: the [N*P, D] query matrix is never written or read
+  VTG(mm_exact(false, true, C1, L, D, W("proj.linear1.W"), D, g->k, D, g->Mq, L, nullptr, false, 1.f, n, 0, (long)L * D,
+               (long)C1 * L));
+  VTG(mm_softmax(g, 0, 1, nullptr, false, P, L, C1, g->x, C1, (long)P * C1, g->Mq, L, (long)C1 * L, g->pa, n, s));
   {  // z = downsample(x) + attention . values (projector_layer.hpp:93-100), one pass, z written once
     const vt_gemm_term t[2] = {{g->x, W("proj.downsample.W"), (long)P * C1, 0, C1, C1, C2, 0},
                                {g->pa, g->v, (long)P * L, (long)L * C2, L, L, C2, 0}};
@@ -1032,16 +1037,18 @@ int gen_backward(GenModel *g, const float *arena, const vt_layout *lo, float *gr
                    (long)P * C2, g->v, C2, (long)L * C2, g->dsa, n, s));
     VTG(mm(true, false, L, C2, P, g->pa, L, g->dz, C2, g->dv, C2, nullptr, false, 1.f, n, (long)P * L, (long)P * C2,
            (long)L * C2));
-    VTG(mm(false, false, P, D, L, g->dsa, L, g->k, D, g->dq, D, nullptr, false, 1.f, n, (long)P * L, (long)L * D,
-           (long)P * D));
-    VTG(mm(true, false, L, D, P, g->dsa, L, g->q, D, g->dk, D, nullptr, false, 1.f, n, (long)P * L, (long)P * D,
-           (long)L * D));
+    // the query delta dq = dsa . keys and everything it feeds, without the [N*P, D] matrices: with
+    // U[n] = dsa[n]^T . x[n] ([L, C1] per image) the key delta dsa^T . (x . W1) is U . W1, the gradient of linear1.W
+    // x^T . (dsa . keys) is sum_n U[n]^T . keys[n], and the input delta dq . W1^T is dsa . Mq^T (a term of the sum below)
+    VTG(mm(true, false, L, C1, P, g->dsa, L, g->x, C1, g->U, C1, nullptr, false, 1.f, n, (long)P * L, (long)P * C1,
+           (long)L * C1));
+    VTG(mm(false, false, (int)NL, D, C1, g->U, C1, W("proj.linear1.W"), D, g->dk, D));
     VTG(mm(true, false, D, C2, (int)NL, g->o, D, g->dv, C2, G("proj.linear3.W"), C2));
     VTG(col_sums(g, g->dv, NL, C2, G("proj.linear3.b"), s));
     VTG(mm(false, true, (int)NL, D, C2, g->dv, C2, W("proj.linear3.W"), C2, g->pdt, D));
     VTG(mm(true, false, D, D, (int)NL, g->o, D, g->dk, D, G("proj.linear2.W"), D));
     VTG(mm(false, true, (int)NL, D, D, g->dk, D, W("proj.linear2.W"), D, g->pdt, D, nullptr, true));
-    VTG(mm(true, false, C1, D, (int)NP, g->x, C1, g->dq, D, G("proj.linear1.W"), D));
+    VTG(mm(true, false, C1, D, (int)NL, g->U, C1, g->k, D, G("proj.linear1.W"), D));
     // TransformerLayer::backward with targets = projector token delta: seed = out - delta
     // (visual_transformer.hpp:153-157, transformer_layer.hpp:133-207); no ReLU derivative (:174-181)
     VTG(ewise(g->o, g->pdt, g->d0, NL * D, 1, s));
@@ -1061,15 +1068,15 @@ int gen_backward(GenModel *g, const float *arena, const vt_layout *lo, float *gr
     // the token axis (:91); the tokenizer's own weights stay frozen (their gradients are never applied)
     VTG(mm(false, true, (int)NL, C1, D, g->pdt, D, W("tok.linear2.W"), D, g->dT0, C1));
     VTG(mm_softmax(g, C1 >= 32 ? sum_form() : 0, 2, g->tokA, true, P, L, C1, g->x, C1, (long)P * C1, g->dT0, C1, (long)L * C1,
-                   g->dsa, n, s));
+                   g->dsa_tok, n, s));
     // the input deltas of the projector (through the downsample and through the queries) and of the tokenizer
     // (a^T path, score path) are one sum of four products, written once (projector_layer.hpp:196-213,
     // tokenizer.hpp:93-106)
     {
       const vt_gemm_term t[4] = {{g->dz, W("proj.downsample.W"), (long)P * C2, 0, C2, C2, C2, 1},
-                                 {g->dq, W("proj.linear1.W"), (long)P * D, 0, D, D, D, 1},
+                                 {g->dsa, g->Mq, (long)P * L, (long)C1 * L, L, L, L, 1},
                                  {g->tokA, g->dT0, (long)P * L, (long)L * C1, L, L, C1, 0},
-                                 {g->dsa, W("tok.linear1.W"), (long)P * L, 0, L, L, L, 1}};
+                                 {g->dsa_tok, W("tok.linear1.W"), (long)P * L, 0, L, L, L, 1}};
       VTG(vt_gemm_sum(sum_form(), 4, t, P, C1, 1.f, 0, g->pdx, C1, (long)P * C1, nullptr, n, (vt_stream)s));
     }
     // BatchNorm2DLayer::backward + Conv2DLayer::backward gradients (batch_normalization_layer.hpp:300-327,
