@@ -76,6 +76,35 @@ __global__ __launch_bounds__(GT) void k_im2col(const float *__restrict__ X, floa
   }
 }
 
+// The same matrix, a workgroup taking 256 consecutive pixels of one image: gathered pixel by pixel into LDS (for a
+// fixed k neighbouring threads read neighbouring pixels), then written out as the contiguous block it is.
+__global__ __launch_bounds__(GT) void k_im2col_rows(const float *__restrict__ X, float *__restrict__ col, int Ci, int H) {
+  extern __shared__ float sh[];  // [256][Ci * 9]
+  const int CK = Ci * 9, P = H * H, n = blockIdx.y, p0 = blockIdx.x * GT, p = p0 + threadIdx.x;
+  if (p < P) {
+    const int h = p / H, w = p - h * H;
+    const float *__restrict__ img = X + (size_t)n * Ci * P;
+    for (int ci = 0; ci < Ci; ++ci)
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int hi = h + kh - 1, wi = w + kw - 1;
+          sh[threadIdx.x * CK + ci * 9 + kh * 3 + kw] =
+              (hi >= 0 && hi < H && wi >= 0 && wi < H) ? img[((size_t)ci * H + hi) * H + wi] : 0.f;
+        }
+  }
+  __syncthreads();
+  const int cnt = (P - p0 < GT ? P - p0 : GT) * CK;
+  float *__restrict__ dst = col + ((size_t)n * P + p0) * CK;
+  if ((cnt & 3) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+    for (int i = threadIdx.x * 4; i < cnt; i += GT * 4)
+      *reinterpret_cast<float4 *>(dst + i) = *reinterpret_cast<const float4 *>(sh + i);
+  } else {
+    for (int i = threadIdx.x; i < cnt; i += GT) dst[i] = sh[i];
+  }
+}
+
 // ---- per-column partial statistics of a row matrix: part[b][0][c] = sum, part[b][1][c] = sum of
 // squared distances from the block's own mean (merged by vt_bn_stats_finalize).  One pass over the rows: a
 // thread accumulates sum and sum of squares of (x - pivot), pivot = the first value it meets (so the squares
@@ -528,13 +557,13 @@ __global__ __launch_bounds__(GT) void k_pool_bwd(const float *__restrict__ z, co
   }
 }
 
-// The same delta without the dense array: the projector's BatchNorm backward reads it twice (its two column
-// sums, then din = delta * scale + shift), and only one element per pooling window is not zero, so both passes
-// form the delta on the fly from the window records (delta, arg-max offset, pooled maximum; the ReLU let the
-// arg-max through exactly when the pooled maximum is positive).  Threads are laid out as in the other column
-// kernels over the row matrix [R, C2]: VEC adjacent columns per thread, walking down the rows; element (r, c)
-// is flat position F = r * C2 + c of the [N, C2, H, W] reinterpretation, i.e. plane F / P at offset F % P,
-// which the walk carries along instead of dividing.
+// The same delta without the dense array: the projector's BatchNorm backward needs it twice (its two column
+// sums, then din = delta * scale + shift), and only one element per pooling window is not zero.  The sums are
+// taken over the window records (k_pool_delta_windows); the din pass forms the delta on the fly from them
+// (delta, arg-max offset, pooled maximum; the ReLU let the arg-max through exactly when the pooled maximum is
+// positive).  Its threads are laid out as in the other column kernels over the row matrix [R, C2]: VEC adjacent
+// columns per thread, walking down the rows; element (r, c) is flat position F = r * C2 + c of the [N, C2, H, W]
+// reinterpretation, i.e. plane F / P at offset F % P, which the walk carries along instead of dividing.
 struct PoolGeo {
   int P, W, pk, quad;  // quad: W and pk multiples of 4, so four adjacent flat positions share a window
 };
@@ -566,76 +595,113 @@ __device__ __forceinline__ void window_delta(long nc, int pos, const PoolGeo pg,
   }
 }
 
-// MODE 0: part[b][0][c] = sum delta, part[b][1][c] = sum delta * xhat (the record k_bnbwd_partial writes);
-// MODE 1: dz = delta * coef[c] + coef[C2 + c]
-template <int VEC, int MODE>
-__global__ __launch_bounds__(GT) void k_pool_delta(const float *__restrict__ z, const float *__restrict__ stat_or_coef,
-                                                   const float *__restrict__ dpool, const float *__restrict__ pooled,
-                                                   const int *__restrict__ pool_idx, long R, int C2, int rpb, ColGeo geo,
-                                                   PoolGeo pg, float *__restrict__ out) {
-  __shared__ float sh[MODE == 0 ? 2 : 1][MODE == 0 ? GT * VEC : 1];
+// dz = delta * coef[c] + coef[C2 + c], the delta formed on the fly from the window records
+template <int VEC>
+__global__ __launch_bounds__(GT) void k_pool_delta(const float *__restrict__ coef, const float *__restrict__ dpool,
+                                                   const float *__restrict__ pooled, const int *__restrict__ pool_idx, long R,
+                                                   int C2, int rpb, ColGeo geo, PoolGeo pg, float *__restrict__ out) {
   const int tx = threadIdx.x % geo.tx_n, ty = threadIdx.x / geo.tx_n;
+  if (ty >= geo.ty_n) return;
   const long r0 = (long)blockIdx.x * rpb, r1 = r0 + rpb < R ? r0 + rpb : R;
-  const bool lane_on = ty < geo.ty_n;
   const int step = geo.ty_n * C2;
-  for (int g0 = 0; g0 < geo.groups; g0 += geo.tx_n) {
-    const int grp = g0 + tx;
-    const bool on = lane_on && grp < geo.groups;
-    float s1[VEC], s2[VEC], pa[VEC], pb[VEC];
+  for (int grp = tx; grp < geo.groups; grp += geo.tx_n) {
+    float pa[VEC], pb[VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
-      s1[e] = s2[e] = 0.f;
-      pa[e] = on ? stat_or_coef[grp * VEC + e] : 0.f;       // mean | scale
-      pb[e] = on ? stat_or_coef[C2 + grp * VEC + e] : 0.f;  // 1/sigma | shift
+      pa[e] = coef[grp * VEC + e];       // scale
+      pb[e] = coef[C2 + grp * VEC + e];  // shift
     }
-    if (on) {
-      const long F0 = (r0 + ty) * C2 + (long)grp * VEC;
-      long nc = F0 / pg.P;
-      int pos = (int)(F0 - nc * pg.P);
-      for (long r = r0 + ty; r < r1; r += geo.ty_n) {
-        float d[VEC];
-        window_delta<VEC>(nc, pos, pg, dpool, pooled, pool_idx, d);
-        if (MODE == 0) {
+    const long F0 = (r0 + ty) * C2 + (long)grp * VEC;
+    long nc = F0 / pg.P;
+    int pos = (int)(F0 - nc * pg.P);
+    for (long r = r0 + ty; r < r1; r += geo.ty_n) {
+      float d[VEC];
+      window_delta<VEC>(nc, pos, pg, dpool, pooled, pool_idx, d);
+      Vecf<VEC> o;
 #pragma unroll
-          for (int e = 0; e < VEC; ++e)
-            if (d[e] != 0.f) {
-              s1[e] += d[e];
-              s2[e] += d[e] * ((z[r * C2 + grp * VEC + e] - pa[e]) * pb[e]);
-            }
-        } else {
-          Vecf<VEC> o;
+      for (int e = 0; e < VEC; ++e) o.v[e] = d[e] * pa[e] + pb[e];
+      stv<VEC>(out + r * C2 + (size_t)grp * VEC, o);
+      pos += step;
+      while (pos >= pg.P) {
+        pos -= pg.P;
+        ++nc;
+      }
+    }
+  }
+}
+
+// MODE 0's sums taken over the window records instead of over the positions: one record in pk * pk positions is
+// not zero, so a walk over the windows does 1/pk^2 of the index arithmetic.  A workgroup takes `wpb` consecutive
+// windows, 256 at a time: each thread turns one window into (channel, delta, delta * xhat) in LDS, then the threads
+// that own a channel add up the records of that channel in window order (every thread reads the same record at the
+// same time: one broadcast read), so the sums do not depend on scheduling.  Channel c is owned by 256 / C2 threads,
+// each with a slice of the 256 records (NK = 1); one thread owns up to four channels when C2 > 256 (NK = 4).
+template <int NK>
+__global__ __launch_bounds__(GT) void k_pool_delta_windows(const float *__restrict__ z, const float *__restrict__ stat,
+                                                           const float *__restrict__ dpool, const float *__restrict__ pooled,
+                                                           const int *__restrict__ pool_idx, long windows, int wpb, int C2,
+                                                           int P, float *__restrict__ out) {
+  __shared__ float4 rec[GT];
+  __shared__ float fin[2][GT];
+  const int tid = threadIdx.x;
+  const int parts = C2 <= GT ? GT / C2 : 1;              // threads per channel
+  const int ch0 = C2 <= GT ? tid % C2 : tid, part = C2 <= GT ? tid / C2 : 0;
+  const bool scanner = part < parts;
+  const int i0 = part * GT / parts, i1 = (part + 1) * GT / parts;  // this thread's slice of the records
+  float s1[NK], s2[NK];
 #pragma unroll
-          for (int e = 0; e < VEC; ++e) o.v[e] = d[e] * pa[e] + pb[e];
-          stv<VEC>(out + r * C2 + (size_t)grp * VEC, o);
-        }
-        pos += step;
-        while (pos >= pg.P) {
-          pos -= pg.P;
-          ++nc;
+  for (int k = 0; k < NK; ++k) s1[k] = s2[k] = 0.f;
+  const long w0 = (long)blockIdx.x * wpb, w1 = w0 + wpb < windows ? w0 + wpb : windows;
+  const int PmodC = P % C2;
+  for (long base = w0; base < w1; base += GT) {
+    const long wi = base + tid;
+    float4 r = make_float4(__int_as_float(-1), 0.f, 0.f, 0.f);
+    if (wi < w1) {
+      const float d = pooled[wi] > 0.f ? dpool[wi] : 0.f;  // the ReLU let the arg-max through iff the maximum is positive
+      if (d != 0.f) {
+        const long nc = wi / 196;
+        const int idx = pool_idx[wi];
+        const int c = (int)(((nc % C2) * PmodC + idx) % C2);  // (nc * P + idx) % C2 without 64-bit products
+        const float xh = (z[nc * P + idx] - stat[c]) * stat[C2 + c];
+        r = make_float4(__int_as_float(c), d, d * xh, 0.f);
+      }
+    }
+    rec[tid] = r;
+    __syncthreads();
+    if (scanner) {
+      for (int i = i0; i < i1; ++i) {
+        const float4 q = rec[i];
+        const int c = __float_as_int(q.x);
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+          const bool hit = c == ch0 + k * GT;
+          s1[k] += hit ? q.y : 0.f;
+          s2[k] += hit ? q.z : 0.f;
         }
       }
     }
-    if (MODE == 0) {
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) {
-        sh[0][threadIdx.x * VEC + e] = s1[e];
-        sh[1][threadIdx.x * VEC + e] = s2[e];
+    __syncthreads();
+  }
+  if (NK == 1) {
+    fin[0][tid] = s1[0];
+    fin[1][tid] = s2[0];
+    __syncthreads();
+    if (tid < C2) {
+      float t1 = 0.f, t2 = 0.f;
+      for (int k = 0; k < parts; ++k) {
+        t1 += fin[0][k * C2 + tid];
+        t2 += fin[1][k * C2 + tid];
       }
-      __syncthreads();
-      if (on && ty == 0) {
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-          float t1 = 0.f, t2 = 0.f;
-          for (int k = 0; k < geo.ty_n; ++k) {
-            t1 += sh[0][(k * geo.tx_n + tx) * VEC + e];
-            t2 += sh[1][(k * geo.tx_n + tx) * VEC + e];
-          }
-          out[(size_t)blockIdx.x * 2 * C2 + grp * VEC + e] = t1;
-          out[(size_t)blockIdx.x * 2 * C2 + C2 + grp * VEC + e] = t2;
-        }
-      }
-      __syncthreads();
+      out[(size_t)blockIdx.x * 2 * C2 + tid] = t1;
+      out[(size_t)blockIdx.x * 2 * C2 + C2 + tid] = t2;
     }
+  } else {
+#pragma unroll
+    for (int k = 0; k < NK; ++k)
+      if (ch0 + k * GT < C2) {
+        out[(size_t)blockIdx.x * 2 * C2 + ch0 + k * GT] = s1[k];
+        out[(size_t)blockIdx.x * 2 * C2 + C2 + ch0 + k * GT] = s2[k];
+      }
   }
 }
 
@@ -705,6 +771,19 @@ int sum_form() {
     return (e && *e && *e != '0') ? 0 : 2;
   }();
   return form;
+}
+
+// the im2col matrix of X [n, Ci, H, H] into g->col
+int im2col(vt::GenModel *g, const float *X, int n, hipStream_t s) {
+  const int CK = g->Ci * 9;
+  const long NP = (long)n * g->P;
+  const size_t lds = (size_t)GT * CK * sizeof(float);
+  if (lds <= 64 * 1024 && n <= 65535)
+    hipLaunchKernelGGL(k_im2col_rows, dim3((g->P + GT - 1) / GT, n), dim3(GT), lds, s, X, g->col, g->Ci, g->H);
+  else
+    hipLaunchKernelGGL(k_im2col, dim3(nblk(NP * CK)), dim3(GT), 0, s, X, g->col, NP * CK, g->Ci, g->H, g->H);
+  VT_CHECK_LAUNCH();
+  return 0;
 }
 
 int rows_per_block(long R) {
@@ -797,25 +876,30 @@ int pool_bn_backward(vt::GenModel *g, const float *gamma, float *ggamma, float *
   const long R = (long)n * g->P;
   const ColGeo geo = col_geo(C2);
   const PoolGeo pg{g->P, g->H, g->pk, (g->H % 4 == 0 && g->pk % 4 == 0) ? 1 : 0};
-  const int rpb = rows_per_block(R), nb = (int)((R + rpb - 1) / rpb);
-  if ((long)nb * 2 * C2 > g->part_floats) return VT_EUNSUPPORTED;
-  if (geo.vec == 4)
-    hipLaunchKernelGGL((k_pool_delta<4, 0>), dim3(nb), dim3(GT), 0, s, g->z, g->stat_pn, g->dpool, g->pooled, g->pool_idx, R, C2,
-                       rpb, geo, pg, g->part);
+  // the two column sums from a walk over the window records (one non-zero per pk x pk positions)
+  const long windows = (long)n * g->Q;
+  const long most = g->part_floats / (2L * C2);  // partial records the buffer holds
+  long wpb = 4096;
+  while ((windows + wpb - 1) / wpb > most) wpb *= 2;
+  const int nb = (int)((windows + wpb - 1) / wpb);
+  if (C2 > 4 * GT || wpb > (1L << 30)) return VT_EUNSUPPORTED;
+  if (C2 <= GT)
+    hipLaunchKernelGGL(k_pool_delta_windows<1>, dim3(nb), dim3(GT), 0, s, g->z, g->stat_pn, g->dpool, g->pooled, g->pool_idx,
+                       windows, (int)wpb, C2, g->P, g->part);
   else
-    hipLaunchKernelGGL((k_pool_delta<1, 0>), dim3(nb), dim3(GT), 0, s, g->z, g->stat_pn, g->dpool, g->pooled, g->pool_idx, R, C2,
-                       rpb, geo, pg, g->part);
+    hipLaunchKernelGGL(k_pool_delta_windows<4>, dim3(nb), dim3(GT), 0, s, g->z, g->stat_pn, g->dpool, g->pooled, g->pool_idx,
+                       windows, (int)wpb, C2, g->P, g->part);
   VT_CHECK_LAUNCH();
   VTG(vt_bn_bwd_finalize(g->part, nb, C2, R, gamma, g->stat_pn, g->z, ggamma, gbeta, g->coef, (vt_stream)s));
   VTG(bn_din_colsum(gamma, g->stat_pn, g->z, ggamma, C2, din_colsum, s));
   const int arpb = stream_rpb(C2, geo);
   const dim3 grid((unsigned)((R + arpb - 1) / arpb));
   if (geo.vec == 4)
-    hipLaunchKernelGGL((k_pool_delta<4, 1>), grid, dim3(GT), 0, s, g->z, g->coef, g->dpool, g->pooled, g->pool_idx, R, C2, arpb,
-                       geo, pg, g->dz);
+    hipLaunchKernelGGL(k_pool_delta<4>, grid, dim3(GT), 0, s, g->coef, g->dpool, g->pooled, g->pool_idx, R, C2, arpb, geo, pg,
+                       g->dz);
   else
-    hipLaunchKernelGGL((k_pool_delta<1, 1>), grid, dim3(GT), 0, s, g->z, g->coef, g->dpool, g->pooled, g->pool_idx, R, C2, arpb,
-                       geo, pg, g->dz);
+    hipLaunchKernelGGL(k_pool_delta<1>, grid, dim3(GT), 0, s, g->coef, g->dpool, g->pooled, g->pool_idx, R, C2, arpb, geo, pg,
+                       g->dz);
   VT_CHECK_LAUNCH();
   return 0;
 }
@@ -907,7 +991,7 @@ int gen_create(GenModel *g, const vt_dims *d, int maxN, int (*alloc)(void *, flo
   A(&g->stat_n2, 2 * D, "stat.norm2");
   A(&g->stat_pn, 2 * C2, "stat.proj.norm");
   A(&g->coef, 2 * (size_t)std::max(std::max(C1, C2), D), nullptr);
-  g->part_floats = 4096L * 2 * std::max(std::max(C1, C2), std::max(D, 64)) + 1024;
+  g->part_floats = 8192L * 2 * std::max(std::max(C1, C2), std::max(D, 64)) + 1024;
   A(&g->part, (size_t)g->part_floats, nullptr);
   A(&g->spx, N * ((g->P + SPX_CHUNK - 1) / SPX_CHUNK + 1) * 2 * L, nullptr);
   g->ws_floats = 16L << 20;
@@ -957,8 +1041,7 @@ int gen_forward(GenModel *g, const float *arena, const vt_layout *lo, float *are
   // scores feed an exponential)
   const Gemm mm{g, s, false}, mm_exact{g, s, false, true}, mm_bf{g, s, true}, mm_bf_exact{g, s, true, true};
   // Conv2DLayer::forward as im2col x W^T (conv2d_layer.hpp:35-87); output pixel-major [N*P, C1]
-  hipLaunchKernelGGL(k_im2col, dim3(nblk(NP * CK)), dim3(GT), 0, s, X, g->col, NP * CK, g->Ci, g->H, g->H);
-  VT_CHECK_LAUNCH();
+  VTG(im2col(g, X, n, s));
   VTG(mm(false, true, (int)NP, C1, CK, g->col, CK, W("conv.W"), CK, g->conv, C1, W("conv.b")));
   // BatchNorm2DLayer::forward (batch_normalization_layer.hpp:262-298): the only norm that honours eval
   VTG(bn_stats(g, g->conv, NP, C1, RW("bn.running_mean"), RW("bn.running_var"), g->stat_bn, !training, s));
