@@ -105,6 +105,52 @@ __global__ __launch_bounds__(GT) void k_im2col_rows(const float *__restrict__ X,
   }
 }
 
+// Column sums of that matrix without reading it: sum over images and output pixels of X[ci][h + kh - 1][w + kw - 1]
+// = the plane's total minus the one border row and / or column the tap never reaches.  part[blockIdx.y][ci * 9 + tap]
+// over the block's share of the images; grid (Ci, blocks).
+__global__ __launch_bounds__(GT) void k_im2col_colsum(const float *__restrict__ X, int n, int Ci, int H, int per_block,
+                                                      float *__restrict__ part) {
+  __shared__ float red[(GT / 64) * 9];
+  const int ci = blockIdx.x, i0 = blockIdx.y * per_block, i1 = min(n, i0 + per_block), P = H * H;
+  float acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = 0.f;
+  for (int img = i0; img < i1; ++img) {
+    const float *__restrict__ pl = X + ((size_t)img * Ci + ci) * P;
+    for (int h = 0; h < H; ++h) {
+      const bool top = h == 0, bot = h == H - 1;
+      for (int w = threadIdx.x; w < H; w += GT) {
+        const float x = pl[h * H + w];
+        const bool left = w == 0, right = w == H - 1;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            const bool skip = (kh == 0 && bot) || (kh == 2 && top) || (kw == 0 && right) || (kw == 2 && left);
+            acc[kh * 3 + kw] += skip ? 0.f : x;
+          }
+      }
+    }
+  }
+  block_sum<9>(acc, red);
+  if (threadIdx.x < 9) {
+    float v = 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) v = threadIdx.x == t ? acc[t] : v;
+    part[(size_t)blockIdx.y * Ci * 9 + ci * 9 + threadIdx.x] = v;
+  }
+}
+
+// G[c][k] = G[c][k] * coef[c] + coef[C + c] * csum[k]: the gradient of the convolution weights from the product with
+// the delta BEFORE the BatchNorm backward's affine map din = delta * coef[c] + coef[C + c]
+__global__ __launch_bounds__(GT) void k_affine_rank1(float *__restrict__ G, const float *__restrict__ coef,
+                                                     const float *__restrict__ csum, int C, int K) {
+  const int i = blockIdx.x * GT + threadIdx.x;
+  if (i >= C * K) return;
+  const int c = i / K, k = i - c * K;
+  G[i] = G[i] * coef[c] + coef[C + c] * csum[k];
+}
+
 // ---- per-column partial statistics of a row matrix: part[b][0][c] = sum, part[b][1][c] = sum of
 // squared distances from the block's own mean (merged by vt_bn_stats_finalize).  One pass over the rows: a
 // thread accumulates sum and sum of squares of (x - pivot), pivot = the first value it meets (so the squares
@@ -1024,6 +1070,8 @@ int gen_create(GenModel *g, const vt_dims *d, int maxN, int (*alloc)(void *, flo
   A(&g->dat, (size_t)L * N * N, nullptr);
   A(&g->dT0, NL * C1, nullptr);
   A(&g->tdx, NP * C1, "bwd.tok_dx");
+  A(&g->csum, (size_t)g->Ci * 9 + 4, nullptr);
+  g->tdx_valid = 0;
   return rc ? VT_ENOMEM : 0;
 }
 
@@ -1164,9 +1212,25 @@ int gen_backward(GenModel *g, const float *arena, const vt_layout *lo, float *gr
     }
     // BatchNorm2DLayer::backward + Conv2DLayer::backward gradients (batch_normalization_layer.hpp:300-327,
     // conv2d_layer.hpp:115-147); the conv input delta is never consumed
-    VTG(bn_backward(g, g->pdx, g->conv, g->stat_bn, W("bn.gamma"), NP, C1, G("bn.gamma"), G("bn.beta"), g->coef, g->tdx, s,
-                    G("conv.b")));
-    VTG(mm(true, false, C1, CK, (int)NP, g->tdx, C1, g->col, CK, G("conv.W"), CK));
+    // The BatchNorm's input delta din = pdx * coef[c] + coef[C1 + c] has one reader, the weight gradient din^T . col,
+    // so it is not written: din^T . col = coef[c] * (pdx^T . col) + coef[C1 + c] * (column sums of col), the second
+    // factor taken from the images directly (gen_expand_tdx forms din for callers that ask for it)
+    {
+      int nb = 0;
+      VTG(bnbwd_partial(g, g->pdx, g->conv, g->stat_bn, NP, C1, &nb, s));
+      VTG(vt_bn_bwd_finalize(g->part, nb, C1, NP, W("bn.gamma"), g->stat_bn, g->conv, G("bn.gamma"), G("bn.beta"), g->coef,
+                             (vt_stream)s));
+      VTG(bn_din_colsum(W("bn.gamma"), g->stat_bn, g->conv, G("bn.gamma"), C1, G("conv.b"), s));
+      g->tdx_valid = 0;
+      VTG(mm(true, false, C1, CK, (int)NP, g->pdx, C1, g->col, CK, G("conv.W"), CK));
+      const int per = 4, blocks = (n + per - 1) / per;
+      if ((long)blocks * CK > g->part_floats) return VT_EUNSUPPORTED;
+      hipLaunchKernelGGL(k_im2col_colsum, dim3(g->Ci, blocks), dim3(GT), 0, s, X, n, g->Ci, g->H, per, g->part);
+      VT_CHECK_LAUNCH();
+      VTG(vt_reduce_rows(g->part, blocks, CK, CK, g->csum, (vt_stream)s));
+      hipLaunchKernelGGL(k_affine_rank1, dim3((C1 * CK + GT - 1) / GT), dim3(GT), 0, s, G("conv.W"), g->coef, g->csum, C1, CK);
+      VT_CHECK_LAUNCH();
+    }
   }
   if (phase & 2) {
     // MultiHeadAttention::backward (multi_head_attention.hpp:109-193): L groups of n consecutive token
@@ -1195,6 +1259,16 @@ int gen_backward(GenModel *g, const float *arena, const vt_layout *lo, float *gr
     }
   }
   (void)X;
+  return 0;
+}
+
+// BatchNorm2DLayer::backward's input delta (batch_normalization_layer.hpp:316-326) as the dense array the reference
+// hands to the convolution; the step itself folds it into the convolution's weight gradient.  Valid until the next
+// BatchNorm backward of any layer reuses the coefficient buffer, i.e. right after a backward call.
+int gen_expand_tdx(GenModel *g, int n, hipStream_t s) {
+  if (g->tdx_valid) return 0;
+  VTG(col_affine(1, g->pdx, g->coef, nullptr, nullptr, g->tdx, (long)n * g->P, g->C1, s));
+  g->tdx_valid = 1;
   return 0;
 }
 
