@@ -102,6 +102,16 @@ TRAFFIC_FILES = ("r02_hbm_traffic_b1024_k8.json", "r01_hbm_traffic_b1024_k8.json
 STEP_LAUNCHES = {"k_bn_stats_finalize": 4, "k_bn_bwd_finalize": 4}  # launches per step where it is not one
 
 
+def measured_step_traffic(shape, batch, classes):
+    """HBM bytes of one whole general-shape training step from the committed PMC passes; None off the measured
+    configurations."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "r02_k_step_hbm_traffic_shapes.json")))
+        return int(t["steps"]["%s_b%d_k%d" % (shape, batch, classes)]["traffic_bytes"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def measured_traffic_table(batch, classes):
     """kernel -> HBM bytes per launch from the committed PMC passes; None off the measured configuration."""
     if batch != 1024 or classes != 8:
@@ -402,8 +412,9 @@ def main():
         roof = {"bound": "hbm", "kernel": "whole step (every launch of forward + backward + update)",
                 "achieved": round(step_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(step_gbs / HBM_PEAK_GBS, 4),
-                "traffic": None if not traffic_tbl else int(sum(v * STEP_LAUNCHES.get(k, 1) for k, v in traffic_tbl.items()
-                                                                if k != "k_probe_copy")),
+                "traffic": (measured_step_traffic(a.shape, B, a.classes) if (generic and a.mode == "train") else None)
+                           if not traffic_tbl else int(sum(v * STEP_LAUNCHES.get(k, 1) for k, v in traffic_tbl.items()
+                                                           if k != "k_probe_copy")),
                 "algorithmic_bytes_per_launch": total_bytes * B, "avg_launch_us": round(step_s * 1e6, 2),
                 "launches_timed": a.steps,
                 "definition": "algorithmic layer-boundary bytes per image x images per step / measured step time; "

@@ -103,6 +103,8 @@ def _check_against_exact_math(m, dims, n, x, y, arena0, p, gr, tol=TOL, gap_tol=
     (dict(num_classes=5, image_channels=2, input_dim=42, tokens=10, token_channels=24, vt_channels=48, heads=3), 9),
     (dict(num_classes=3, image_channels=1, input_dim=14, tokens=7, token_channels=20, vt_channels=10, heads=5), 3),
     (dict(num_classes=11, image_channels=4, input_dim=56, tokens=33, token_channels=36, vt_channels=6, heads=1), 70),
+    # more than 256 projector channels: a thread of the pooling-delta sums owns several channels
+    (dict(num_classes=4, image_channels=1, input_dim=28, tokens=6, token_channels=16, vt_channels=264, heads=2), 3),
 ])
 def test_irregular_shape_against_oracle(dims, n):
     """Dimensions that are multiples of nothing convenient (odd channel counts, token counts, head
