@@ -107,30 +107,28 @@ __global__ __launch_bounds__(GT) void k_im2col_rows(const float *__restrict__ X,
 
 // Column sums of that matrix without reading it: sum over images and output pixels of X[ci][h + kh - 1][w + kw - 1]
 // = the plane's total minus the one border row and / or column the tap never reaches.  part[blockIdx.y][ci * 9 + tap]
-// over the block's share of the images; grid (Ci, blocks).
-__global__ __launch_bounds__(GT) void k_im2col_colsum(const float *__restrict__ X, int n, int Ci, int H, int per_block,
+// over one band of rows of one image; grid (Ci, images * bands).
+__global__ __launch_bounds__(GT) void k_im2col_colsum(const float *__restrict__ X, int n, int Ci, int H, int bands,
                                                       float *__restrict__ part) {
   __shared__ float red[(GT / 64) * 9];
-  const int ci = blockIdx.x, i0 = blockIdx.y * per_block, i1 = min(n, i0 + per_block), P = H * H;
+  // block y = (image, band of image rows); a thread walks the band's pixels in steps of the workgroup size
+  const int ci = blockIdx.x, img = blockIdx.y / bands, band = blockIdx.y - img * bands, P = H * H;
+  const int rows_band = (H + bands - 1) / bands, h0 = band * rows_band, h1 = min(H, h0 + rows_band);
   float acc[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) acc[t] = 0.f;
-  for (int img = i0; img < i1; ++img) {
-    const float *__restrict__ pl = X + ((size_t)img * Ci + ci) * P;
-    for (int h = 0; h < H; ++h) {
-      const bool top = h == 0, bot = h == H - 1;
-      for (int w = threadIdx.x; w < H; w += GT) {
-        const float x = pl[h * H + w];
-        const bool left = w == 0, right = w == H - 1;
+  const float *__restrict__ pl = X + ((size_t)img * Ci + ci) * P;
+  for (int i = h0 * H + (int)threadIdx.x; i < h1 * H; i += GT) {
+    const int h = i / H, w = i - h * H;
+    const float x = pl[i];
+    const bool top = h == 0, bot = h == H - 1, left = w == 0, right = w == H - 1;
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh)
+    for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-          for (int kw = 0; kw < 3; ++kw) {
-            const bool skip = (kh == 0 && bot) || (kh == 2 && top) || (kw == 0 && right) || (kw == 2 && left);
-            acc[kh * 3 + kw] += skip ? 0.f : x;
-          }
+      for (int kw = 0; kw < 3; ++kw) {
+        const bool skip = (kh == 0 && bot) || (kh == 2 && top) || (kw == 0 && right) || (kw == 2 && left);
+        acc[kh * 3 + kw] += skip ? 0.f : x;
       }
-    }
   }
   block_sum<9>(acc, red);
   if (threadIdx.x < 9) {
@@ -441,6 +439,58 @@ __global__ __launch_bounds__(GT) void k_softmax_rows(float *__restrict__ S, long
   }
   s = wave_sum(s);
   for (int j = lane; j < Wd; j += 64) r[j] /= s;
+}
+
+// rows of at most 64 * NV values: the row stays in registers between the three steps (one read, one write; the
+// same operations in the same order as k_softmax_rows)
+template <int NV>
+__global__ __launch_bounds__(GT) void k_softmax_rows_reg(float *__restrict__ S, long rows, int Wd) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * (GT / 64) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float *__restrict__ r = S + row * Wd;
+  float x[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) x[k] = lane + 64 * k < Wd ? r[lane + 64 * k] : -INFINITY;
+  float mx = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) mx = fmaxf(mx, x[k]);
+  mx = wave_max(mx);
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < NV; ++k)
+    if (lane + 64 * k < Wd) {
+      x[k] = expf(x[k] - mx);
+      s += x[k];
+    }
+  s = wave_sum(s);
+#pragma unroll
+  for (int k = 0; k < NV; ++k)
+    if (lane + 64 * k < Wd) r[lane + 64 * k] = x[k] / s;
+}
+template <int NV>
+__global__ __launch_bounds__(GT) void k_softmax_bwd_rows_reg(const float *__restrict__ a, float *__restrict__ da, long rows,
+                                                             int Wd) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * (GT / 64) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float *__restrict__ ar = a + row * Wd;
+  float *__restrict__ dr = da + row * Wd;
+  float av[NV], dv[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const bool on = lane + 64 * k < Wd;
+    av[k] = on ? ar[lane + 64 * k] : 0.f;
+    dv[k] = on ? dr[lane + 64 * k] : 0.f;
+  }
+  float dot = 0.f;
+#pragma unroll
+  for (int k = 0; k < NV; ++k)
+    if (lane + 64 * k < Wd) dot += av[k] * dv[k];
+  dot = wave_sum(dot);
+#pragma unroll
+  for (int k = 0; k < NV; ++k)
+    if (lane + 64 * k < Wd) dr[lane + 64 * k] = av[k] * (dv[k] - dot);
 }
 
 // narrow rows (Wd = 16: the scaled shape's 16 tokens): four rows per wave, 16 lanes each
@@ -977,6 +1027,9 @@ int softmax_pixels(vt::GenModel *g, float *S, int n, int P, int Lt, hipStream_t 
 
 int softmax_rows(float *S, long rows, int Wd, hipStream_t s) {
   if (Wd == 16) hipLaunchKernelGGL(k_softmax_rows16, dim3((unsigned)((rows * 16 + GT - 1) / GT)), dim3(GT), 0, s, S, rows);
+  else if (Wd <= 64) hipLaunchKernelGGL(k_softmax_rows_reg<1>, dim3((unsigned)((rows + 3) / 4)), dim3(GT), 0, s, S, rows, Wd);
+  else if (Wd <= 128) hipLaunchKernelGGL(k_softmax_rows_reg<2>, dim3((unsigned)((rows + 3) / 4)), dim3(GT), 0, s, S, rows, Wd);
+  else if (Wd <= 256) hipLaunchKernelGGL(k_softmax_rows_reg<4>, dim3((unsigned)((rows + 3) / 4)), dim3(GT), 0, s, S, rows, Wd);
   else hipLaunchKernelGGL(k_softmax_rows, dim3((unsigned)((rows + 3) / 4)), dim3(GT), 0, s, S, rows, Wd);
   VT_CHECK_LAUNCH();
   return 0;
@@ -984,6 +1037,9 @@ int softmax_rows(float *S, long rows, int Wd, hipStream_t s) {
 
 int softmax_bwd_rows(const float *a, float *da, long rows, int Wd, hipStream_t s) {
   if (Wd == 16) hipLaunchKernelGGL(k_softmax_bwd_rows16, dim3((unsigned)((rows * 16 + GT - 1) / GT)), dim3(GT), 0, s, a, da, rows);
+  else if (Wd <= 64) hipLaunchKernelGGL(k_softmax_bwd_rows_reg<1>, dim3((unsigned)((rows + 3) / 4)), dim3(GT), 0, s, a, da, rows, Wd);
+  else if (Wd <= 128) hipLaunchKernelGGL(k_softmax_bwd_rows_reg<2>, dim3((unsigned)((rows + 3) / 4)), dim3(GT), 0, s, a, da, rows, Wd);
+  else if (Wd <= 256) hipLaunchKernelGGL(k_softmax_bwd_rows_reg<4>, dim3((unsigned)((rows + 3) / 4)), dim3(GT), 0, s, a, da, rows, Wd);
   else hipLaunchKernelGGL(k_softmax_bwd_rows, dim3((unsigned)((rows + 3) / 4)), dim3(GT), 0, s, a, da, rows, Wd);
   VT_CHECK_LAUNCH();
   return 0;
@@ -1223,9 +1279,11 @@ int gen_backward(GenModel *g, const float *arena, const vt_layout *lo, float *gr
       VTG(bn_din_colsum(W("bn.gamma"), g->stat_bn, g->conv, G("bn.gamma"), C1, G("conv.b"), s));
       g->tdx_valid = 0;
       VTG(mm(true, false, C1, CK, (int)NP, g->pdx, C1, g->col, CK, G("conv.W"), CK));
-      const int per = 4, blocks = (n + per - 1) / per;
-      if ((long)blocks * CK > g->part_floats) return VT_EUNSUPPORTED;
-      hipLaunchKernelGGL(k_im2col_colsum, dim3(g->Ci, blocks), dim3(GT), 0, s, X, n, g->Ci, g->H, per, g->part);
+      int bands = 8;
+      while (bands > 1 && ((long)n * bands * CK > g->part_floats || (long)n * bands > 65535)) bands >>= 1;
+      const int blocks = n * bands;
+      if ((long)blocks * CK > g->part_floats || blocks > 65535) return VT_EUNSUPPORTED;
+      hipLaunchKernelGGL(k_im2col_colsum, dim3(g->Ci, blocks), dim3(GT), 0, s, X, n, g->Ci, g->H, bands, g->part);
       VT_CHECK_LAUNCH();
       VTG(vt_reduce_rows(g->part, blocks, CK, CK, g->csum, (vt_stream)s));
       hipLaunchKernelGGL(k_affine_rank1, dim3((C1 * CK + GT - 1) / GT), dim3(GT), 0, s, G("conv.W"), g->coef, g->csum, C1, CK);
