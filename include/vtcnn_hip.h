@@ -487,6 +487,24 @@ typedef struct vt_gemm_term {
 } vt_gemm_term;
 int vt_gemm_sum(int form, int nterms, const vt_gemm_term *terms, int M, int N, float alpha, int accumulate, float *C,
                 int ldc, long strideC, const float *bias, int batch, vt_stream s);
+/* Products that read the delta behind the projector's BatchNorm (MaxPool2DLayer::backward + ReLU mask + BatchNorm
+ * backward, layers/pooling_layer.hpp:68-97, relu_layer.hpp:20-33, batch_normalization_layer.hpp:172-200) as RECORDS
+ * instead of a dense [rows, N] matrix.  With pooling windows a multiple of 16 wide, 16 adjacent elements of a row hold
+ * at most one non-zero pooling delta, so the matrix is  coef[N + n] + coef[n] * delta[row][n]  with delta given per
+ * row and group of 16 columns as one pair (value, column inside the group): rec [rows][N / 16][2] floats (the column
+ * as an int's bits), an eighth of the dense bytes.  N a multiple of 16; rec 8-byte aligned.
+ * vt_gemm_tn_records:  C[b] = A[b]^T . expand(rec[b]),  A [K, M] row-major (the weight gradient x^T . dz, the value
+ *   delta attention^T . dz; layers/projector_layer.hpp:150-195).  64 < N <= any; hi/lo split arithmetic; workspace
+ *   as in vt_gemm_f32.
+ * vt_gemm_sum_records:  vt_gemm_sum (epi 0) or vt_gemm_softmax_rows' softmax backward (epi 2, epi_a laid out like C)
+ *   with terms[0].A = rec (terms[0].K = N of the delta, a multiple of 16; terms[0].lda = K / 8 floats per row of
+ *   records; terms[0].strideA in floats).  Row-panel kernel only, results up to 16 or exactly 33..64 columns wide:
+ *   VT_EUNSUPPORTED otherwise, and nothing is launched. */
+int vt_gemm_tn_records(int M, int N, int K, const float *A, int lda, long strideA, const float *rec, long strideRec,
+                       const float *coef, float *C, int ldc, long strideC, int batch, float *workspace, long workspace_floats,
+                       vt_stream s);
+int vt_gemm_sum_records(int nterms, const vt_gemm_term *terms, const float *coef, int epi, const float *epi_a, int M, int N,
+                        float *C, int ldc, long strideC, const float *bias, int batch, vt_stream s);
 /* A product whose rows go straight through Tensor::softmax over the last axis (epi 1; the projector's attention map,
  * layers/projector_layer.hpp:80-84) or through Tensor::softmax_backward against a [batch, M, N] (epi 2: C <- a * (C -
  * sum_row a * C); layers/projector_layer.hpp:163-171, layers/tokenizer.hpp:88-91):  C[b] = epi(alpha * A[b] . op(B[b])),

@@ -35,6 +35,7 @@ struct GemmP {
   float alpha;
   int accumulate, ksplit, kchunk, batch, vecA, vecB;
   float *part;  // [ksplit][batch][M*N] when ksplit > 1
+  const float *bz_coef;  // kernels built with BZ: B holds delta records (load_tile_rec), ldb floats per row of records
 };
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -202,6 +203,34 @@ __device__ __forceinline__ void store_tile_kq(unsigned short (*Th)[GBK + HPAD], 
     }
   }
 }
+// B given as delta records instead of a dense matrix (GemmP::bz_coef): per row k and group of 16 adjacent columns
+// one pair (value, column inside the group), every other element of the group zero, and
+// B[k][n] = coef[N + n] + coef[n] * delta[k][n].  A K step's records (16 rows x R / 16 groups: a few hundred bytes)
+// are fetched by the first threads, one pair each, and passed through LDS; every thread then expands the elements
+// the mapping of load_tile_kq gives it, so that the tile is staged by the same code as a dense one.
+template <int R>
+__device__ __forceinline__ float2 load_rec(const float *__restrict__ rec, int ld, int r0, int rows, int k0, int kend, int tid) {
+  constexpr int NG = R / 16;
+  const int k = tid / NG, grp = tid - k * NG, gk = k0 + k, n = r0 + 16 * grp;
+  if (tid < GBK * NG && gk < kend && n < rows) return *reinterpret_cast<const float2 *>(rec + (long)gk * ld + 2 * (n >> 4));
+  return make_float2(0.f, __int_as_float(-1));
+}
+template <int R>
+__device__ __forceinline__ void expand_rec(const float2 *__restrict__ buf, const float (&ca)[R / 64], const float (&cb)[R / 64],
+                                           int k0, int kend, int tid, float (&reg)[R / 16]) {
+  constexpr int NG = R / 16;
+#pragma unroll
+  for (int hb = 0; hb < R / 64; ++hb) {
+    const int col = (tid & 63) + 64 * hb;  // column inside the tile
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int kq = 4 * (tid >> 6) + j;
+      const float2 rc = buf[kq * NG + (col >> 4)];
+      const float d = __float_as_int(rc.y) == (col & 15) ? rc.x : 0.f;
+      reg[4 * hb + j] = k0 + kq < kend ? fmaf(d, ca[hb], cb[hb]) : 0.f;
+    }
+  }
+}
 // memory -> registers in the mapping the kernel's form stages from
 template <bool ALONG_K, int PR, int R>
 __device__ __forceinline__ void fetch_tile(const float *__restrict__ base, int ld, int r0, int rows, int k0, int kend, bool vec,
@@ -330,7 +359,7 @@ __device__ __forceinline__ void tile_of_block(unsigned &bx, unsigned &by, unsign
 // BM x BN: the workgroup's tile of C (64x64 for narrow or small products, 64x128 when only N is
 // wide, 128x128 for the wide shapes: each wave then owns 64x64 = 4x4 MFMA tiles and an LDS operand
 // read feeds four matrix instructions instead of two).
-template <bool TA, bool TB, int PR, int BM, int BN>
+template <bool TA, bool TB, int PR, int BM, int BN, bool BZ = false>
 __global__ __launch_bounds__(256) void k_gemm(GemmP p) {
   __shared__ GemmLds<PR, BM, BN> L;
   unsigned bx, by, bz;
@@ -350,17 +379,47 @@ __global__ __launch_bounds__(256) void k_gemm(GemmP p) {
   // the next K step's tiles travel from memory while the matrix cores work on the current one
   float ra[BM / 16], rb[BN / 16];
   fetch_tile<!TA, PR, BM>(A, p.lda, m0, p.M, kbeg, kend, vecA, tid, ra);
-  fetch_tile<TB, PR, BN>(B, p.ldb, n0, p.N, kbeg, kend, vecB, tid, rb);
-  for (int k0 = kbeg; k0 < kend; k0 += GBK) {
-    __syncthreads();  // the previous step's tile reads are over
-    stage_tile<!TA, PR, BM>(L.As, L.Ah, L.Al, vecA, tid, ra);
-    stage_tile<TB, PR, BN>(L.Bs, L.Bh, L.Bl, vecB, tid, rb);
-    __syncthreads();
-    if (k0 + GBK < kend) {
-      fetch_tile<!TA, PR, BM>(A, p.lda, m0, p.M, k0 + GBK, kend, vecA, tid, ra);
-      fetch_tile<TB, PR, BN>(B, p.ldb, n0, p.N, k0 + GBK, kend, vecB, tid, rb);
+  if constexpr (BZ) {
+    // records: step s's pairs sit in recs[s % 2] (written while step s - 1 was staged), step s + 1's are in flight
+    __shared__ float2 recs[2][GBK * (BN / 16)];
+    float ca[BN / 64], cb[BN / 64];
+#pragma unroll
+    for (int hb = 0; hb < BN / 64; ++hb) {
+      const int gn = n0 + (tid & 63) + 64 * hb;
+      ca[hb] = gn < p.N ? p.bz_coef[gn] : 0.f;
+      cb[hb] = gn < p.N ? p.bz_coef[p.N + gn] : 0.f;
     }
-    gemm_step<PR, BM, BN>(L, acc);
+    float2 rnext = load_rec<BN>(B, p.ldb, n0, p.N, kbeg, kend, tid);
+    if (tid < GBK * (BN / 16)) recs[0][tid] = rnext;
+    rnext = load_rec<BN>(B, p.ldb, n0, p.N, kbeg + GBK, kend, tid);
+    __syncthreads();
+    int par = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += GBK, par ^= 1) {
+      expand_rec<BN>(recs[par], ca, cb, k0, kend, tid, rb);
+      __syncthreads();  // the previous step's tile reads are over
+      stage_tile<!TA, PR, BM>(L.As, L.Ah, L.Al, vecA, tid, ra);
+      stage_tile<TB, PR, BN>(L.Bs, L.Bh, L.Bl, vecB, tid, rb);
+      if (tid < GBK * (BN / 16)) recs[par ^ 1][tid] = rnext;
+      __syncthreads();
+      if (k0 + GBK < kend) {
+        fetch_tile<!TA, PR, BM>(A, p.lda, m0, p.M, k0 + GBK, kend, vecA, tid, ra);
+        rnext = load_rec<BN>(B, p.ldb, n0, p.N, k0 + 2 * GBK, kend, tid);
+      }
+      gemm_step<PR, BM, BN>(L, acc);
+    }
+  } else {
+    fetch_tile<TB, PR, BN>(B, p.ldb, n0, p.N, kbeg, kend, vecB, tid, rb);
+    for (int k0 = kbeg; k0 < kend; k0 += GBK) {
+      __syncthreads();  // the previous step's tile reads are over
+      stage_tile<!TA, PR, BM>(L.As, L.Ah, L.Al, vecA, tid, ra);
+      stage_tile<TB, PR, BN>(L.Bs, L.Bh, L.Bl, vecB, tid, rb);
+      __syncthreads();
+      if (k0 + GBK < kend) {
+        fetch_tile<!TA, PR, BM>(A, p.lda, m0, p.M, k0 + GBK, kend, vecA, tid, ra);
+        fetch_tile<TB, PR, BN>(B, p.ldb, n0, p.N, k0 + GBK, kend, vecB, tid, rb);
+      }
+      gemm_step<PR, BM, BN>(L, acc);
+    }
   }
   const bool direct = p.ksplit == 1;
   float *__restrict__ C = direct ? p.C + (long)b * p.sC : p.part + ((long)ks * p.batch + b) * (long)p.M * p.N;
@@ -389,6 +448,9 @@ struct GemmSumP {
   // backward r <- a * (r - sum_row a * r) with a = epi_a (laid out like C); 0 = none
   int epi;
   const float *epi_a;
+  // row-panel kernels built with DZ: term 0's A holds delta records (one pair per row and group of 16 adjacent k:
+  // value, k inside the group; every other element of the group zero) and A[m][k] = dz_coef[K + k] + dz_coef[k] * delta
+  const float *dz_coef;
 };
 template <int PR, int BM, int BN>
 __global__ __launch_bounds__(256) void k_gemm_sum(GemmSumP p) {
@@ -449,11 +511,12 @@ __global__ __launch_bounds__(256) void k_gemm_sum(GemmSumP p) {
 struct PanelStep {
   const float *A;  // the term's A at this batch member
   int lda, K, k0, kofs;  // kofs: the step's first k row / column inside the LDS copy of op(B)
+  int comp;              // 1: A holds delta records (kernels built with DZ), lda floats per row of records
 };
 constexpr int PANEL_STEPS = 16, PANEL_HEAD = 512;  // bytes reserved in front of B for the step table
 constexpr int PANEL_T = 512, PANEL_W = PANEL_T / 64;  // eight waves share one LDS copy of B
 
-template <int PR, int NT>
+template <int PR, int NT, bool DZ = false>
 __global__ __launch_bounds__(PANEL_T) void k_gemm_panel(GemmSumP p, int rows_per_wg, int Kp, int nsteps) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   PanelStep *steps = reinterpret_cast<PanelStep *>(smem);
@@ -473,7 +536,7 @@ __global__ __launch_bounds__(PANEL_T) void k_gemm_panel(GemmSumP p, int rows_per
       const int ns = (t.K + 15) >> 4, K16 = ns * 16;
       if (tid >= sbase && tid < sbase + ns) {
         const int sidx = tid - sbase;
-        steps[tid] = PanelStep{t.A + (long)b * t.sA, t.lda, t.K, sidx * 16, kofs + sidx * 16};
+        steps[tid] = PanelStep{t.A + (long)b * t.sA, t.lda, t.K, sidx * 16, kofs + sidx * 16, (DZ && ti == 0) ? 1 : 0};
       }
       const float *__restrict__ B = t.B + (long)b * t.sB;
       auto put = [&](int k, int n, float v) {
@@ -548,6 +611,13 @@ __global__ __launch_bounds__(PANEL_T) void k_gemm_panel(GemmSumP p, int rows_per
       sbase += ns;
     }
   }
+  // DZ: the expansion coefficients of term 0 (scale [K], shift [K]) behind the copy of op(B)
+  float *__restrict__ zc = reinterpret_cast<float *>(smem + PANEL_HEAD) +
+                           (PR == 2 ? NP16 * ldk : Kp * ldn);  // floats: the hi / lo halves together are NP16 * ldk floats
+  if constexpr (DZ) {
+    const int K0 = p.t[0].K;
+    for (int i = tid; i < 2 * K0; i += PANEL_T) zc[i] = p.dz_coef[i];
+  }
   __syncthreads();
 
   const int G = (nsteps + 3) >> 2;  // groups of four steps: one group is in the matrix cores, the next in flight
@@ -563,7 +633,14 @@ __global__ __launch_bounds__(PANEL_T) void k_gemm_panel(GemmSumP p, int rows_per
       if (si < nsteps) {
         const PanelStep st = steps[si];
         const int k = st.k0 + 4 * g;
-        if (row < p.M && k < st.K) v = *reinterpret_cast<const float4 *>(st.A + row * st.lda + k);
+        if (DZ && st.comp) {  // the record of (row, group st.k0 / 16): the four lanes of a row read the same pair
+          v.y = __int_as_float(-1);
+          if (row < p.M) {
+            const float2 rc = *reinterpret_cast<const float2 *>(st.A + row * st.lda + 2 * (st.k0 >> 4));
+            v.x = rc.x;
+            v.y = rc.y;
+          }
+        } else if (row < p.M && k < st.K) v = *reinterpret_cast<const float4 *>(st.A + row * st.lda + k);
       }
       dst[e] = v;
     }
@@ -586,7 +663,19 @@ __global__ __launch_bounds__(PANEL_T) void k_gemm_panel(GemmSumP p, int rows_per
         const int si = gi * 4 + e;
         if (si < nsteps) {
           const int kb = steps[si].kofs + 4 * g;
-          const float av[4] = {cur[e].x, cur[e].y, cur[e].z, cur[e].w};
+          float av[4] = {cur[e].x, cur[e].y, cur[e].z, cur[e].w};
+          if constexpr (DZ) {
+            if (steps[si].comp) {
+              const int k = steps[si].k0 + 4 * g, pos = __float_as_int(cur[e].y) - 4 * g;
+              const float4 ca = *reinterpret_cast<const float4 *>(&zc[k]);
+              const float4 cb = *reinterpret_cast<const float4 *>(&zc[steps[si].K + k]);
+              const float val = cur[e].x;
+              av[0] = fmaf(pos == 0 ? val : 0.f, ca.x, cb.x);
+              av[1] = fmaf(pos == 1 ? val : 0.f, ca.y, cb.y);
+              av[2] = fmaf(pos == 2 ? val : 0.f, ca.z, cb.z);
+              av[3] = fmaf(pos == 3 ? val : 0.f, ca.w, cb.w);
+            }
+          }
           if constexpr (PR == 2) {
             s16x4 ah, al;
 #pragma unroll
@@ -595,16 +684,22 @@ __global__ __launch_bounds__(PANEL_T) void k_gemm_panel(GemmSumP p, int rows_per
               ah[q] = (short)h;
               al[q] = (short)to_bf16(av[q] - from_bf16(h));
             }
+            // op(B)^T . A^T: the result tile comes out transposed, a lane holding four adjacent columns of
+            // one row of C (one 16-byte store).  All of op(B)'s fragments first, then the three partial products
+            // tile by tile: consecutive matrix instructions write different accumulators, none waits for the one
+            // before it
+            s16x4 bh[NT], bl[NT];
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-              const s16x4 bh = *reinterpret_cast<const s16x4 *>(&Bh[(j * 16 + c) * ldk + kb]);
-              const s16x4 bl = *reinterpret_cast<const s16x4 *>(&Bl[(j * 16 + c) * ldk + kb]);
-              // op(B)^T . A^T: the result tile comes out transposed, a lane holding four adjacent columns of
-              // one row of C (one 16-byte store)
-              acc[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bh, al, acc[j], 0, 0, 0);
-              acc[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bl, ah, acc[j], 0, 0, 0);
-              acc[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bh, ah, acc[j], 0, 0, 0);
+              bh[j] = *reinterpret_cast<const s16x4 *>(&Bh[(j * 16 + c) * ldk + kb]);
+              bl[j] = *reinterpret_cast<const s16x4 *>(&Bl[(j * 16 + c) * ldk + kb]);
             }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bh[j], al, acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bl[j], ah, acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bh[j], ah, acc[j], 0, 0, 0);
           } else {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
@@ -702,7 +797,7 @@ using namespace vt;
 
 // Row-panel launch of a sum of products when it is tall and narrow and every A is 16-byte loadable; returns
 // 1 when it took the job, 0 when the tiled kernels should, < 0 on a launch error.
-static int panel_launch(int form, const GemmSumP &p, int batch, hipStream_t hs) {
+static int panel_launch(int form, const GemmSumP &p, int batch, hipStream_t hs, bool dz = false) {
   static const bool off = [] {
     const char *e = getenv("VT_GEMM_PANEL");
     return e && *e == '0';
@@ -718,7 +813,11 @@ static int panel_launch(int form, const GemmSumP &p, int batch, hipStream_t hs) 
   }
   if (nsteps > PANEL_STEPS) return 0;
   const int NT = p.N <= 16 ? 1 : p.N <= 32 ? 2 : p.N <= 64 ? 4 : 8;
-  const size_t lds = PANEL_HEAD + (form == 2 ? (size_t)2 * NT * 16 * (Kp + 4) * 2 : (size_t)Kp * (NT * 16 + 4) * 4);
+  size_t lds = PANEL_HEAD + (form == 2 ? (size_t)2 * NT * 16 * (Kp + 4) * 2 : (size_t)Kp * (NT * 16 + 4) * 4);
+  if (dz) {
+    if (form != 2 || p.t[0].K % 16 != 0 || !p.dz_coef || (NT != 1 && NT != 4)) return 0;
+    lds += (size_t)2 * p.t[0].K * sizeof(float);
+  }
   if (lds > 64 * 1024) return 0;
   // rows per workgroup: as many as leave a few thousand workgroups (the LDS copy of B is paid once per workgroup)
   int rows = 1024;
@@ -732,7 +831,9 @@ static int panel_launch(int form, const GemmSumP &p, int batch, hipStream_t hs) 
     else if (NT == 4) VT_PANEL(PR_, 4);  \
     else VT_PANEL(PR_, 8);               \
   } while (0)
-  if (form == 2) VT_PANEL_NT(2);
+  if (dz && NT == 1) hipLaunchKernelGGL((k_gemm_panel<2, 1, true>), grid, dim3(PANEL_T), lds, hs, p, rows, Kp, nsteps);
+  else if (dz) hipLaunchKernelGGL((k_gemm_panel<2, 4, true>), grid, dim3(PANEL_T), lds, hs, p, rows, Kp, nsteps);
+  else if (form == 2) VT_PANEL_NT(2);
   else VT_PANEL_NT(0);
 #undef VT_PANEL_NT
 #undef VT_PANEL
@@ -745,7 +846,7 @@ static int gemm_launch(int form, int transA, int transB, int M, int N, int K, fl
                        const float *bias, int batch, float *workspace, long workspace_floats, vt_stream s) {
   if (M < 1 || N < 1 || K < 1 || batch < 1 || !A || !B || !C) return VT_EINVAL;
   if (lda < (transA ? M : K) || ldb < (transB ? K : N) || ldc < N) return VT_EINVAL;
-  GemmP p{A, B, C, bias, M, N, K, lda, ldb, ldc, strideA, strideB, strideC, alpha, accumulate ? 1 : 0, 1, K, batch, 0, 0, nullptr};
+  GemmP p{A, B, C, bias, M, N, K, lda, ldb, ldc, strideA, strideB, strideC, alpha, accumulate ? 1 : 0, 1, K, batch, 0, 0, nullptr, nullptr};
   // 16-byte loads need the contiguous extent and the leading dimension in multiples of 4 floats, the
   // batch strides too, and a 16-byte aligned base; K slices are multiples of 16, so with K % 4 == 0 no
   // vector straddles a slice end
@@ -885,6 +986,80 @@ extern "C" int vt_gemm_sum(int form, int nterms, const vt_gemm_term *terms, int 
 #undef VT_SUM_LAUNCH
   VT_CHECK_LAUNCH();
   return 0;
+}
+
+// ---- products with the projector's output delta given as records (vt_pool_delta_records) ----------------------
+extern "C" int vt_gemm_tn_records(int M, int N, int K, const float *A, int lda, long strideA, const float *rec, long strideRec,
+                                  const float *coef, float *C, int ldc, long strideC, int batch, float *workspace,
+                                  long workspace_floats, vt_stream s) {
+  if (M < 1 || N < 16 || N % 16 != 0 || K < 1 || batch < 1 || !A || !rec || !coef || !C || lda < M || ldc < N) return VT_EINVAL;
+  if (N <= 64) return VT_EUNSUPPORTED;  // built for the 64 x 128 tile only
+  const int ldr = N / 8;                // floats per row of records
+  GemmP p{A, rec, C, nullptr, M, N, K, lda, ldr, ldc, strideA, strideRec, strideC, 1.f, 0, 1, K, batch, 0, 0, nullptr, coef};
+  auto aligned = [](const float *q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  p.vecA = aligned(A) && lda % 4 == 0 && strideA % 4 == 0 && M % 4 == 0;
+  if ((reinterpret_cast<uintptr_t>(rec) & 7) != 0 || strideRec % 2 != 0) return VT_EINVAL;
+  const int BM = 64, BN = 128;
+  const long tiles = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN) * batch;
+  const long target = K >= 4096 ? 2048 : 1024;  // K slices as in gemm_launch
+  if (workspace && K >= 256 && tiles * 4 <= target) {
+    long want = (target + tiles - 1) / tiles;
+    const long most = K >= 4096 ? (K + 511) / 512 : K / 64;
+    want = want < most ? want : most;
+    const long fit = workspace_floats / ((long)M * N * batch);
+    if (want > fit) want = fit;
+    if (want > 1) {
+      p.ksplit = (int)want;
+      p.kchunk = (int)(((K + want - 1) / want + GBK - 1) / GBK * GBK);
+      p.ksplit = (K + p.kchunk - 1) / p.kchunk;
+      p.part = workspace;
+    }
+  }
+  const long gz = (long)batch * p.ksplit;
+  if (gz > 65535) return VT_EUNSUPPORTED;
+  const dim3 grid((M + BM - 1) / BM, (N + BN - 1) / BN, (unsigned)gz);
+  hipLaunchKernelGGL((k_gemm<true, false, 2, 64, 128, true>), grid, dim3(256), 0, (hipStream_t)s, p);
+  VT_CHECK_LAUNCH();
+  if (p.ksplit > 1 && ldc == N && (batch == 1 || strideC == (long)M * N) && (long)M * N * batch < (1L << 30))
+    return vt_reduce_rows(workspace, p.ksplit, (int)((long)M * N * batch), (int)((long)M * N * batch), C, s);
+  if (p.ksplit > 1) {
+    const long total = (long)M * N * batch;
+    const int nb = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(k_gemm_splitk_reduce, dim3(nb), dim3(256), 0, (hipStream_t)s, p, batch);
+    VT_CHECK_LAUNCH();
+  }
+  return 0;
+}
+
+extern "C" int vt_gemm_sum_records(int nterms, const vt_gemm_term *terms, const float *coef, int epi, const float *epi_a, int M,
+                                   int N, float *C, int ldc, long strideC, const float *bias, int batch, vt_stream s) {
+  if (nterms < 1 || nterms > 4 || !terms || !coef || M < 1 || N < 1 || batch < 1 || !C || ldc < N) return VT_EINVAL;
+  if ((epi != 0 && epi != 2) || (epi == 2 && (!epi_a || ldc != N))) return VT_EINVAL;
+  if (epi == 2 && N > 16) return VT_EUNSUPPORTED;
+  const int K0 = terms[0].K;
+  if (K0 % 16 != 0 || terms[0].lda != K0 / 8 || terms[0].strideA % 2 != 0 ||
+      (reinterpret_cast<uintptr_t>(terms[0].A) & 7) != 0)
+    return VT_EINVAL;
+  GemmSumP p{};
+  vt_gemm_term t0 = terms[0];
+  t0.lda = K0;  // passes the dense-operand checks; the kernel reads records with the stride set below
+  vt_gemm_term tt[4];
+  for (int i = 0; i < nterms; ++i) tt[i] = i == 0 ? t0 : terms[i];
+  auto aligned = [](const float *q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  for (int i = 0; i < nterms; ++i) {
+    const vt_gemm_term &t = tt[i];
+    if (!t.A || !t.B || t.K < 1 || t.lda < t.K || t.ldb < (t.transB ? t.K : N)) return VT_EINVAL;
+    GemmTerm &d = p.t[i];
+    d.A = t.A; d.B = t.B; d.sA = t.strideA; d.sB = t.strideB; d.K = t.K; d.lda = t.lda; d.ldb = t.ldb; d.tb = t.transB ? 1 : 0;
+    d.vecA = i == 0 ? 1 : (aligned(t.A) && t.lda % 4 == 0 && t.strideA % 4 == 0 && t.K % 4 == 0);
+    d.vecB = aligned(t.B) && t.ldb % 4 == 0 && t.strideB % 4 == 0 && (t.transB ? t.K % 4 == 0 : N % 4 == 0);
+  }
+  p.t[0].lda = K0 / 8;
+  p.nterms = nterms; p.C = C; p.bias = bias; p.M = M; p.N = N; p.ldc = ldc; p.sC = strideC; p.alpha = 1.f;
+  p.epi = epi; p.epi_a = epi_a; p.dz_coef = coef;
+  const int took = panel_launch(2, p, batch, (hipStream_t)s, true);
+  if (took < 0) return -took;
+  return took > 0 ? 0 : VT_EUNSUPPORTED;
 }
 
 extern "C" int vt_gemm_softmax_rows(int form, int epi, const float *a, int transB, int M, int N, int K, float alpha,

@@ -21,7 +21,8 @@ struct GenModel {
   long part_floats, ws_floats;
   // backward
   float *dlogits, *dpool, *du, *dz, *pdx, *dsa, *dsa_tok, *U, *dv, *dk, *pdt, *d0, *ds2, *dh, *da, *dr, *dc;
-  float *Qm, *Km, *Vm, *dQ, *dK, *dV, *attn, *dat, *dT0, *tdx, *csum;
+  float *Qm, *Km, *Vm, *dQ, *dK, *dV, *attn, *dat, *dT0, *tdx, *csum, *dzr, *coef_pn;
+  int dz_valid;   // 1: `dz` holds the dense delta behind the projector's BatchNorm (0: only the records `dzr` were written)
   int tdx_valid;  // 1: `tdx` holds the BatchNorm2D input delta of the last backward (0: it was folded into the conv gradient)
 };
 
@@ -35,6 +36,8 @@ int gen_backward(GenModel *g, const float *arena, const vt_layout *lo, float *gr
                  int phase, hipStream_t s);
 // fills g->du (the dense delta behind the pooling layer) from the last backward's window records
 int gen_expand_du(GenModel *g, const float *arena, const vt_layout *lo, int n, hipStream_t s);
+// fills g->dz (the dense delta behind the projector's BatchNorm) from the last backward's window records
+int gen_expand_dz(GenModel *g, int n, hipStream_t s);
 // fills g->tdx (the BatchNorm2D input delta) from the last backward's coefficients
 int gen_expand_tdx(GenModel *g, int n, hipStream_t s);
 

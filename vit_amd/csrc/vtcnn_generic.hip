@@ -726,6 +726,27 @@ __global__ __launch_bounds__(GT) void k_pool_delta(const float *__restrict__ coe
   }
 }
 
+// The same delta as records: when pooling windows are a multiple of 16 wide (and so is C2), 16 adjacent flat
+// positions lie in one row of one window, so at most one of them is not zero: rec[r][q] = (delta, its index inside
+// the group) for row r and channel group q of the row matrix [R, C2], 1/8 of the dense array's bytes.  The
+// products that read the delta expand it on load (vt_gemm_tn_records, vt_gemm_sum_records).  grid (blocks, images).
+__global__ __launch_bounds__(GT) void k_pool_delta_records(const float *__restrict__ dpool, const float *__restrict__ pooled,
+                                                           const int *__restrict__ pool_idx, int C2, int P, int W, int pk,
+                                                           float2 *__restrict__ out) {
+  const unsigned ng = C2 / 16, per_image = (unsigned)P * ng;  // records per image; an image is C2 planes of P positions
+  const unsigned img = blockIdx.y;
+  for (unsigned i = blockIdx.x * GT + threadIdx.x; i < per_image; i += gridDim.x * GT) {
+    const unsigned r = i / ng, q = i - r * ng;
+    const unsigned F = r * C2 + 16 * q;  // flat position inside the image
+    const unsigned plane = F / P, pos = F - plane * P;
+    const unsigned h = pos / W, w = pos - h * W;
+    const long win = ((long)img * C2 + plane) * 196 + (h / pk) * 14 + w / pk;
+    const unsigned off = (unsigned)(pool_idx[win] - (int)pos);
+    const bool hit = off < 16u && pooled[win] > 0.f;
+    out[(size_t)img * per_image + i] = make_float2(hit ? dpool[win] : 0.f, __int_as_float(hit ? (int)off : 0));
+  }
+}
+
 // MODE 0's sums taken over the window records instead of over the positions: one record in pk * pk positions is
 // not zero, so a walk over the windows does 1/pk^2 of the index arithmetic.  A workgroup takes `wpb` consecutive
 // windows, 256 at a time: each thread turns one window into (channel, delta, delta * xhat) in LDS, then the threads
@@ -966,12 +987,34 @@ int col_sums(vt::GenModel *g, const float *dY, long R, int C, float *out, hipStr
 // max-pool scatter + ReLU mask (pooling_layer.hpp:68-97, relu_layer.hpp:20-33) and the projector's BatchNorm
 // backward (batch_normalization_layer.hpp:172-200) without the dense delta in between: two passes over the
 // window records (column sums, then din), the second writing dz
-int pool_bn_backward(vt::GenModel *g, const float *gamma, float *ggamma, float *gbeta, float *din_colsum, int n,
-                     hipStream_t s) {
+// dense dz = delta * coef_pn[c] + coef_pn[C2 + c] from the window records
+int pool_delta_dense(vt::GenModel *g, int n, hipStream_t s) {
   const int C2 = g->C2;
   const long R = (long)n * g->P;
   const ColGeo geo = col_geo(C2);
   const PoolGeo pg{g->P, g->H, g->pk, (g->H % 4 == 0 && g->pk % 4 == 0) ? 1 : 0};
+  const int arpb = stream_rpb(C2, geo);
+  const dim3 grid((unsigned)((R + arpb - 1) / arpb));
+  if (geo.vec == 4)
+    hipLaunchKernelGGL(k_pool_delta<4>, grid, dim3(GT), 0, s, g->coef_pn, g->dpool, g->pooled, g->pool_idx, R, C2, arpb, geo, pg,
+                       g->dz);
+  else
+    hipLaunchKernelGGL(k_pool_delta<1>, grid, dim3(GT), 0, s, g->coef_pn, g->dpool, g->pooled, g->pool_idx, R, C2, arpb, geo, pg,
+                       g->dz);
+  VT_CHECK_LAUNCH();
+  g->dz_valid = 1;
+  return 0;
+}
+
+// whether the delta behind the projector's BatchNorm travels as records (k_pool_delta_records) in this model
+bool delta_records(const vt::GenModel *g) {
+  return g->pk % 16 == 0 && g->C2 % 16 == 0 && g->C2 > 64 && g->C2 <= 128 && sum_form() == 2 && (long)g->P * g->C2 < (1L << 31);
+}
+
+int pool_bn_backward(vt::GenModel *g, const float *gamma, float *ggamma, float *gbeta, float *din_colsum, int n,
+                     hipStream_t s) {
+  const int C2 = g->C2;
+  const long R = (long)n * g->P;
   // the two column sums from a walk over the window records (one non-zero per pk x pk positions)
   const long windows = (long)n * g->Q;
   const long most = g->part_floats / (2L * C2);  // partial records the buffer holds
@@ -986,18 +1029,17 @@ int pool_bn_backward(vt::GenModel *g, const float *gamma, float *ggamma, float *
     hipLaunchKernelGGL(k_pool_delta_windows<4>, dim3(nb), dim3(GT), 0, s, g->z, g->stat_pn, g->dpool, g->pooled, g->pool_idx,
                        windows, (int)wpb, C2, g->P, g->part);
   VT_CHECK_LAUNCH();
-  VTG(vt_bn_bwd_finalize(g->part, nb, C2, R, gamma, g->stat_pn, g->z, ggamma, gbeta, g->coef, (vt_stream)s));
+  VTG(vt_bn_bwd_finalize(g->part, nb, C2, R, gamma, g->stat_pn, g->z, ggamma, gbeta, g->coef_pn, (vt_stream)s));
   VTG(bn_din_colsum(gamma, g->stat_pn, g->z, ggamma, C2, din_colsum, s));
-  const int arpb = stream_rpb(C2, geo);
-  const dim3 grid((unsigned)((R + arpb - 1) / arpb));
-  if (geo.vec == 4)
-    hipLaunchKernelGGL(k_pool_delta<4>, grid, dim3(GT), 0, s, g->coef, g->dpool, g->pooled, g->pool_idx, R, C2, arpb, geo, pg,
-                       g->dz);
-  else
-    hipLaunchKernelGGL(k_pool_delta<1>, grid, dim3(GT), 0, s, g->coef, g->dpool, g->pooled, g->pool_idx, R, C2, arpb, geo, pg,
-                       g->dz);
-  VT_CHECK_LAUNCH();
-  return 0;
+  if (delta_records(g) && n <= 65535) {
+    const unsigned per_image = (unsigned)g->P * (C2 / 16);
+    hipLaunchKernelGGL(k_pool_delta_records, dim3((per_image + 4 * GT - 1) / (4 * GT), n), dim3(GT), 0, s, g->dpool, g->pooled,
+                       g->pool_idx, C2, g->P, g->H, g->pk, reinterpret_cast<float2 *>(g->dzr));
+    VT_CHECK_LAUNCH();
+    g->dz_valid = 0;
+    return 0;
+  }
+  return pool_delta_dense(g, n, s);
 }
 
 int ewise(const float *a, const float *b, float *out, long total, int op, hipStream_t s) {
@@ -1127,6 +1169,10 @@ int gen_create(GenModel *g, const vt_dims *d, int maxN, int (*alloc)(void *, flo
   A(&g->dT0, NL * C1, nullptr);
   A(&g->tdx, NP * C1, "bwd.tok_dx");
   A(&g->csum, (size_t)g->Ci * 9 + 4, nullptr);
+  A(&g->coef_pn, 2 * (size_t)C2, nullptr);
+  g->dzr = nullptr;
+  if (delta_records(g)) A(&g->dzr, NP * C2 / 8, nullptr);
+  g->dz_valid = 0;
   g->tdx_valid = 0;
   return rc ? VT_ENOMEM : 0;
 }
@@ -1218,12 +1264,44 @@ int gen_backward(GenModel *g, const float *arena, const vt_layout *lo, float *gr
     // ProjectorLayer::backward (projector_layer.hpp:118-214)
     // (the downsample bias gradient, the column sums of dz, comes out of the BatchNorm backward's own sums)
     VTG(pool_bn_backward(g, W("proj.norm.gamma"), G("proj.norm.gamma"), G("proj.norm.beta"), G("proj.downsample.b"), n, s));
-    VTG(mm(true, false, C1, C2, (int)NP, g->x, C1, g->dz, C2, G("proj.downsample.W"), C2));
+    // Where the delta travels as records (g->dz_valid == 0) its four readers expand it on load; a reader whose shape
+    // the record kernels do not take makes the dense array first.
+    const long sR = (long)P * C2 / 8;  // record floats per image
+    auto need_dense = [&]() { return g->dz_valid ? 0 : pool_delta_dense(g, n, s); };
+    int rc = VT_EUNSUPPORTED;
+    if (!g->dz_valid)
+      rc = vt_gemm_tn_records(C1, C2, (int)NP, g->x, C1, 0, g->dzr, 0, g->coef_pn, G("proj.downsample.W"), C2, 0, 1, g->ws,
+                              g->ws_floats, (vt_stream)s);
+    if (rc == VT_EUNSUPPORTED) {
+      VTG(need_dense());
+      VTG(mm(true, false, C1, C2, (int)NP, g->x, C1, g->dz, C2, G("proj.downsample.W"), C2));
+    } else if (rc != 0) {
+      return rc;
+    }
     // delta of the attention map, softmax backward over tokens, deltas of q / k / v
-    VTG(mm_softmax(g, C2 >= 32 ? sum_form() : 0, 2, g->pa, true, P, L, C2, g->dz, C2,
-                   (long)P * C2, g->v, C2, (long)L * C2, g->dsa, n, s));
-    VTG(mm(true, false, L, C2, P, g->pa, L, g->dz, C2, g->dv, C2, nullptr, false, 1.f, n, (long)P * L, (long)P * C2,
-           (long)L * C2));
+    rc = VT_EUNSUPPORTED;
+    if (!g->dz_valid) {
+      const vt_gemm_term t0 = {g->dzr, g->v, sR, (long)L * C2, C2, C2 / 8, C2, 1};
+      rc = vt_gemm_sum_records(1, &t0, g->coef_pn, 2, g->pa, P, L, g->dsa, L, (long)P * L, nullptr, n, (vt_stream)s);
+    }
+    if (rc == VT_EUNSUPPORTED) {
+      VTG(need_dense());
+      VTG(mm_softmax(g, C2 >= 32 ? sum_form() : 0, 2, g->pa, true, P, L, C2, g->dz, C2,
+                     (long)P * C2, g->v, C2, (long)L * C2, g->dsa, n, s));
+    } else if (rc != 0) {
+      return rc;
+    }
+    rc = VT_EUNSUPPORTED;
+    if (!g->dz_valid)
+      rc = vt_gemm_tn_records(L, C2, P, g->pa, L, (long)P * L, g->dzr, sR, g->coef_pn, g->dv, C2, (long)L * C2, n, g->ws,
+                              g->ws_floats, (vt_stream)s);
+    if (rc == VT_EUNSUPPORTED) {
+      VTG(need_dense());
+      VTG(mm(true, false, L, C2, P, g->pa, L, g->dz, C2, g->dv, C2, nullptr, false, 1.f, n, (long)P * L, (long)P * C2,
+             (long)L * C2));
+    } else if (rc != 0) {
+      return rc;
+    }
     // the query delta dq = dsa . keys and everything it feeds, without the [N*P, D] matrices: with
     // U[n] = dsa[n]^T . x[n] ([L, C1] per image) the key delta dsa^T . (x . W1) is U . W1, the gradient of linear1.W
     // x^T . (dsa . keys) is sum_n U[n]^T . keys[n], and the input delta dq . W1^T is dsa . Mq^T (a term of the sum below)
@@ -1264,7 +1342,18 @@ int gen_backward(GenModel *g, const float *arena, const vt_layout *lo, float *gr
                                  {g->dsa, g->Mq, (long)P * L, (long)C1 * L, L, L, L, 1},
                                  {g->tokA, g->dT0, (long)P * L, (long)L * C1, L, L, C1, 0},
                                  {g->dsa_tok, W("tok.linear1.W"), (long)P * L, 0, L, L, L, 1}};
-      VTG(vt_gemm_sum(sum_form(), 4, t, P, C1, 1.f, 0, g->pdx, C1, (long)P * C1, nullptr, n, (vt_stream)s));
+      int rc4 = VT_EUNSUPPORTED;
+      if (!g->dz_valid) {
+        vt_gemm_term tr[4] = {t[0], t[1], t[2], t[3]};
+        tr[0].A = g->dzr; tr[0].strideA = (long)P * C2 / 8; tr[0].lda = C2 / 8;
+        rc4 = vt_gemm_sum_records(4, tr, g->coef_pn, 0, nullptr, P, C1, g->pdx, C1, (long)P * C1, nullptr, n, (vt_stream)s);
+      }
+      if (rc4 == VT_EUNSUPPORTED) {
+        if (!g->dz_valid) VTG(pool_delta_dense(g, n, s));
+        VTG(vt_gemm_sum(sum_form(), 4, t, P, C1, 1.f, 0, g->pdx, C1, (long)P * C1, nullptr, n, (vt_stream)s));
+      } else if (rc4 != 0) {
+        return rc4;
+      }
     }
     // BatchNorm2DLayer::backward + Conv2DLayer::backward gradients (batch_normalization_layer.hpp:300-327,
     // conv2d_layer.hpp:115-147); the conv input delta is never consumed
@@ -1319,6 +1408,9 @@ int gen_backward(GenModel *g, const float *arena, const vt_layout *lo, float *gr
   (void)X;
   return 0;
 }
+
+// The delta behind the projector's BatchNorm as the dense array [n*P, C2] (the step may only have written records)
+int gen_expand_dz(GenModel *g, int n, hipStream_t s) { return g->dz_valid ? 0 : pool_delta_dense(g, n, s); }
 
 // BatchNorm2DLayer::backward's input delta (batch_normalization_layer.hpp:316-326) as the dense array the reference
 // hands to the convolution; the step itself folds it into the convolution's weight gradient.  Valid until the next
