@@ -104,15 +104,28 @@ __device__ __forceinline__ unsigned short to_bf16(float x) {
   return (unsigned short)(u >> 16);
 }
 __device__ __forceinline__ float from_bf16(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+// (a, b) -> the packed bf16 pair of their high parts and of their low parts (a in the low half), with the packed
+// hardware conversion (round to nearest even, as to_bf16) and a packed fp32 subtraction
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split2(float a, float b, unsigned &hi, unsigned &lo) {
+  const floatx2 f = {a, b};
+  hi = __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2));
+  const floatx2 r = f - floatx2{__uint_as_float(hi << 16), __uint_as_float(hi & 0xffff0000u)};
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
+}
 // the same tile as hi / lo halves (form 2)
 template <bool ALONG_K, int R>
 __device__ __forceinline__ void store_tile_split(unsigned short (*Th)[GBK + HPAD], unsigned short (*Tl)[GBK + HPAD], bool vec,
                                                  int tid, const float (&reg)[R / 16]) {
   unsigned short h[R / 16], l[R / 16];
 #pragma unroll
-  for (int e = 0; e < R / 16; ++e) {
-    h[e] = to_bf16(reg[e]);
-    l[e] = to_bf16(reg[e] - from_bf16(h[e]));
+  for (int e = 0; e < R / 16; e += 2) {
+    unsigned hp, lp;
+    split2(reg[e], reg[e + 1], hp, lp);
+    h[e] = (unsigned short)hp; h[e + 1] = (unsigned short)(hp >> 16);
+    l[e] = (unsigned short)lp; l[e + 1] = (unsigned short)(lp >> 16);
   }
   if (vec) {
 #pragma unroll
@@ -191,16 +204,11 @@ __device__ __forceinline__ void store_tile_kq(unsigned short (*Th)[GBK + HPAD], 
 #pragma unroll
   for (int hb = 0; hb < R / 64; ++hb) {
     const int r = (tid & 63) + 64 * hb, k = 4 * (tid >> 6);
-    unsigned short h[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) h[j] = to_bf16(reg[4 * hb + j]);
-    *reinterpret_cast<uint2 *>(&Th[r][k]) = make_uint2(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16));
-    if constexpr (PR == 2) {
-      unsigned short l[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) l[j] = to_bf16(reg[4 * hb + j] - from_bf16(h[j]));
-      *reinterpret_cast<uint2 *>(&Tl[r][k]) = make_uint2(l[0] | ((unsigned)l[1] << 16), l[2] | ((unsigned)l[3] << 16));
-    }
+    unsigned h01, l01, h23, l23;
+    split2(reg[4 * hb], reg[4 * hb + 1], h01, l01);
+    split2(reg[4 * hb + 2], reg[4 * hb + 3], h23, l23);
+    *reinterpret_cast<uint2 *>(&Th[r][k]) = make_uint2(h01, h23);
+    if constexpr (PR == 2) *reinterpret_cast<uint2 *>(&Tl[r][k]) = make_uint2(l01, l23);
   }
 }
 // B given as delta records instead of a dense matrix (GemmP::bz_coef): per row k and group of 16 adjacent columns
@@ -677,13 +685,10 @@ __global__ __launch_bounds__(PANEL_T) void k_gemm_panel(GemmSumP p, int rows_per
             }
           }
           if constexpr (PR == 2) {
-            s16x4 ah, al;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const unsigned short h = to_bf16(av[q]);
-              ah[q] = (short)h;
-              al[q] = (short)to_bf16(av[q] - from_bf16(h));
-            }
+            unsigned h01, l01, h23, l23;
+            split2(av[0], av[1], h01, l01);
+            split2(av[2], av[3], h23, l23);
+            const s16x4 ah = __builtin_bit_cast(s16x4, u32x2{h01, h23}), al = __builtin_bit_cast(s16x4, u32x2{l01, l23});
             // op(B)^T . A^T: the result tile comes out transposed, a lane holding four adjacent columns of
             // one row of C (one 16-byte store).  All of op(B)'s fragments first, then the three partial products
             // tile by tile: consecutive matrix instructions write different accumulators, none waits for the one
