@@ -1,6 +1,7 @@
 // Shared device helpers for the gfx950 VTCNN kernels.  wave = 64 lanes everywhere.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <cstdint>
 
 #include "../../include/vtcnn_hip.h"
@@ -175,6 +176,24 @@ int reduce_batch_flush_sgd(float *w, float *g, int n, float lr, float divisor, h
 int sgd_update_hole(float *w, float *g, int n, float lr, float divisor, int hole_first, int hole_count, hipStream_t s);
 
 }  // namespace vt
+
+// A launch that carries an event of its own completion: when the model has put an event into g_stop_event, the
+// next launch through this macro is made with hipExtLaunchKernelGGL and signals that event itself when it
+// finishes, so no separate event-record packet (which the stream's next kernel would wait behind) follows the
+// kernel on its stream.  The launch takes the event and clears the slot.
+namespace vt {
+extern thread_local hipEvent_t g_stop_event;
+}
+#define VT_LAUNCH_SIGNALLING(kernel, grid, block, lds, stream, ...)                                          \
+  do {                                                                                                       \
+    if (vt::g_stop_event) {                                                                                  \
+      hipEvent_t ev__ = vt::g_stop_event;                                                                    \
+      vt::g_stop_event = nullptr;                                                                            \
+      hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, nullptr, ev__, 0, __VA_ARGS__);                \
+    } else {                                                                                                 \
+      hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                     \
+    }                                                                                                        \
+  } while (0)
 
 #define VT_CHECK_LAUNCH()                      \
   do {                                         \

@@ -16,6 +16,9 @@
 #include "vtcnn_tail.h"
 #include "vtcnn_generic.h"
 
+namespace vt {
+thread_local hipEvent_t g_stop_event = nullptr;
+}
 using namespace vt;
 
 #define HIPCHK(x)                          \
@@ -41,6 +44,8 @@ struct vt_model {
   hipStream_t side = nullptr;
   hipEvent_t ev_rows = nullptr, ev_join = nullptr;
   bool concurrent = true, side_open = false;
+  bool join_signalled = false;  // the side chain's last kernel signals ev_join itself (no record needed)
+  bool signal_launches = [] { const char *e = getenv("VT_SIGNAL_LAUNCHES"); return !(e && *e == '0'); }();  // VT_SIGNAL_LAUNCHES=0: event-record packets
   // Deferred attention backward (vt_model_set_deferred_attention): the attention block's backward and the
   // update of its weights run on attn_stream beside the NEXT step's forward, which never reads those
   // weights.  tokbuf[2]: the token matrix is double-buffered so that the next forward can write its tokens
@@ -1031,11 +1036,21 @@ static int backward_main(vt_model *m, const int *d_labels, vt_stream s) {
   VTCHK(vt_reduce_rows(m->gslab + C1 * D, n, C1 * C2 + C2, 400, m->G_("proj.downsample.W"), s));
   // projector token side + transformer step a (targets = projector token delta, same bytes:
   // visual_transformer.hpp:153-157) in one launch
+  // the fork event is signalled by this launch itself where the stream is not being captured: an event-record
+  // packet behind it would hold up the stream's next kernel
+  bool capturing = false;
+  if (fork) {
+    hipStreamCaptureStatus cst = hipStreamCaptureStatusNone;
+    capturing = hipStreamIsCapturing(hs, &cst) != hipSuccess || cst != hipStreamCaptureStatusNone;
+    if (!capturing && m->signal_launches) vt::g_stop_event = m->ev_rows;
+  }
   STEP("projector_tokens_bwd", projector_tokens_bwd_transformer_a_tail(m->o, m->dv, m->dk, m->P_("proj.linear3.W"), m->P_("proj.linear2.W"),
                                 m->pdt, m->G_("proj.linear2.W"), m->sc_pt, m->s2, m->stat_n2, m->P_("tok.linear2.W"), m->part,
                                 m->dT0, NL, tails ? bwd_tail(5, "norm2.gamma", m->stat_n2, m->s2, m->coef_n2, NL) : BnBwdTail{}, hs));
   if (fork) {
-    HIPCHK(hipEventRecord(m->ev_rows, hs));
+    const bool signalled = !capturing && m->signal_launches && vt::g_stop_event == nullptr;
+    vt::g_stop_event = nullptr;
+    if (!signalled) HIPCHK(hipEventRecord(m->ev_rows, hs));
     HIPCHK(hipStreamWaitEvent(m->side, m->ev_rows, 0));
     m->side_open = true;
   }
@@ -1050,7 +1065,11 @@ static int backward_main(vt_model *m, const int *d_labels, vt_stream s) {
   STEP_ON("conv3x3_wgrad", t, vt_conv3x3_wgrad(m->last_images, m->dy, m->coef_bn, m->gslab_conv, n, Ci, H, H, t));
   VTCHK(vt_reduce_rows(m->gslab_conv, n, C1 * Ci * 9 + C1, C1 * Ci * 9 + C1, m->G_("conv.W"), s));  // queued
   // the fc weight gradient only needs the head's delta: it rides at the end of the shorter chain
+  m->join_signalled = false;
+  if (fork && !capturing && m->signal_launches) vt::g_stop_event = m->ev_join;  // the side chain's last kernel
   STEP_ON("fc_wgrad", t, vt_fc_wgrad(m->pooled, m->dlogits, m->G_("fc.W"), m->G_("fc.b"), m->sc_fc, n, Q, K, t));
+  if (fork && !capturing && m->signal_launches) m->join_signalled = vt::g_stop_event == nullptr;
+  vt::g_stop_event = nullptr;
   // feed-forward half of the transformer layer
   if (!tails)
     STEP("bn_bwd_finalize", vt_bn_bwd_finalize(m->part, nrb, D, NL, m->P_("norm2.gamma"), m->stat_n2, m->s2, m->G_("norm2.gamma"),
@@ -1088,7 +1107,8 @@ static int backward_attention(vt_model *m, float *g_out, vt_stream s) {
 static int join_side(vt_model *m, vt_stream s) {
   if (!m->side_open) return 0;
   m->side_open = false;
-  HIPCHK(hipEventRecord(m->ev_join, m->side));
+  if (!m->join_signalled) HIPCHK(hipEventRecord(m->ev_join, m->side));
+  m->join_signalled = false;
   HIPCHK(hipStreamWaitEvent((hipStream_t)s, m->ev_join, 0));
   return 0;
 }

@@ -997,8 +997,8 @@ extern "C" int vt_fc_wgrad(const float *pooled, const float *d_logits, float *gw
   if (!direct && !scratch) return VT_EINVAL;
   float *dst = direct ? gw : scratch;
   const int tiles = (Q + 15) / 16 + 1;
-  hipLaunchKernelGGL(k_fc_wgrad, dim3((tiles + NW - 1) / NW, ns), dim3(TPB), 0, (hipStream_t)s, pooled, d_logits, dst, N,
-                     Q, K, ld);
+  VT_LAUNCH_SIGNALLING(k_fc_wgrad, dim3((tiles + NW - 1) / NW, ns), dim3(TPB), 0, (hipStream_t)s, pooled, d_logits, dst, N, Q, K,
+                       ld);
   VT_CHECK_LAUNCH();
   if (!direct) {
     int rc = reduce_rows(scratch, ns, Q * K, ld, gw, (hipStream_t)s);

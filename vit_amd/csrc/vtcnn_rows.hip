@@ -718,11 +718,11 @@ int vt::projector_tokens_bwd_transformer_a_tail(const float *o, const float *dv,
   if (rows < 1) return VT_EINVAL;
   const int nb = (int)((rows + RB - 1) / RB);
   if (tail.ticket)
-    hipLaunchKernelGGL(k_projtok_bwd_tr_a<true>, dim3(nb), dim3(TPB), 0, s, o, dv, dk, wv, wk, pdt, scratch, s2, n2_stat, tok_w2,
-                       part, dT0, rows, tail);
+    VT_LAUNCH_SIGNALLING(k_projtok_bwd_tr_a<true>, dim3(nb), dim3(TPB), 0, s, o, dv, dk, wv, wk, pdt, scratch, s2, n2_stat, tok_w2,
+                         part, dT0, rows, tail);
   else
-    hipLaunchKernelGGL(k_projtok_bwd_tr_a<false>, dim3(nb), dim3(TPB), 0, s, o, dv, dk, wv, wk, pdt, scratch, s2, n2_stat, tok_w2,
-                       part, dT0, rows, tail);
+    VT_LAUNCH_SIGNALLING(k_projtok_bwd_tr_a<false>, dim3(nb), dim3(TPB), 0, s, o, dv, dk, wv, wk, pdt, scratch, s2, n2_stat,
+                         tok_w2, part, dT0, rows, tail);
   VT_CHECK_LAUNCH();
   return reduce_rows(scratch, nb, PT_STRIDE, PT_STRIDE, g_wk_wv_bv, s);
 }
