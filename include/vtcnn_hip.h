@@ -487,6 +487,14 @@ typedef struct vt_gemm_term {
 } vt_gemm_term;
 int vt_gemm_sum(int form, int nterms, const vt_gemm_term *terms, int M, int N, float alpha, int accumulate, float *C,
                 int ldc, long strideC, const float *bias, int batch, vt_stream s);
+/* BatchNorm2DLayer::forward's apply (layers/batch_normalization_layer.hpp:292-297) inside the first product that reads
+ * its result (the tokenizer's scores, layers/tokenizer.hpp:30-34):
+ *   A_out[m][k] = (A[m][k] - stat[k]) * stat[K + k] * gamma[k] + beta[k],   C = A_out . op(B) (+ bias[n])
+ * exact fp32, one pass over A (A_out laid out like A and written once; the normalised matrix is not read back for the
+ * product).  Row-panel kernel only: N <= 16, M >= 2048, A and A_out 16-byte loadable, else VT_EUNSUPPORTED and nothing
+ * is launched. */
+int vt_gemm_bn_apply(int M, int N, int K, const float *A, int lda, const float *stat, const float *gamma, const float *beta,
+                     float *A_out, const float *B, int ldb, int transB, const float *bias, float *C, int ldc, vt_stream s);
 /* Products that read the delta behind the projector's BatchNorm (MaxPool2DLayer::backward + ReLU mask + BatchNorm
  * backward, layers/pooling_layer.hpp:68-97, relu_layer.hpp:20-33, batch_normalization_layer.hpp:172-200) as RECORDS
  * instead of a dense [rows, N] matrix.  With pooling windows a multiple of 16 wide, 16 adjacent elements of a row hold

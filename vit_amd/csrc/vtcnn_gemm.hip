@@ -459,6 +459,12 @@ struct GemmSumP {
   // row-panel kernels built with DZ: term 0's A holds delta records (one pair per row and group of 16 adjacent k:
   // value, k inside the group; every other element of the group zero) and A[m][k] = dz_coef[K + k] + dz_coef[k] * delta
   const float *dz_coef;
+  // row-panel kernels built with AX == 2: term 0's A is a BatchNorm's input, normalised on load,
+  //   A'[m][k] = (A[m][k] - ax_stat[k]) * ax_stat[K + k] * ax_gamma[k] + ax_beta[k]
+  // (BatchNorm2DLayer::forward's apply, layers/batch_normalization_layer.hpp:292-297), and A' is also written to
+  // ax_out (laid out like A): the first reader of a BatchNorm output produces it instead of a pass of its own
+  const float *ax_stat, *ax_gamma, *ax_beta;
+  float *ax_out;
 };
 template <int PR, int BM, int BN>
 __global__ __launch_bounds__(256) void k_gemm_sum(GemmSumP p) {
@@ -524,7 +530,9 @@ struct PanelStep {
 constexpr int PANEL_STEPS = 16, PANEL_HEAD = 512;  // bytes reserved in front of B for the step table
 constexpr int PANEL_T = 512, PANEL_W = PANEL_T / 64;  // eight waves share one LDS copy of B
 
-template <int PR, int NT, bool DZ = false>
+// AX: what term 0's A is: 0 a plain matrix, 1 delta records (GemmSumP::dz_coef), 2 a BatchNorm input normalised on
+// load and written back (GemmSumP::ax_*)
+template <int PR, int NT, int AX = 0>
 __global__ __launch_bounds__(PANEL_T) void k_gemm_panel(GemmSumP p, int rows_per_wg, int Kp, int nsteps) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   PanelStep *steps = reinterpret_cast<PanelStep *>(smem);
@@ -544,7 +552,7 @@ __global__ __launch_bounds__(PANEL_T) void k_gemm_panel(GemmSumP p, int rows_per
       const int ns = (t.K + 15) >> 4, K16 = ns * 16;
       if (tid >= sbase && tid < sbase + ns) {
         const int sidx = tid - sbase;
-        steps[tid] = PanelStep{t.A + (long)b * t.sA, t.lda, t.K, sidx * 16, kofs + sidx * 16, (DZ && ti == 0) ? 1 : 0};
+        steps[tid] = PanelStep{t.A + (long)b * t.sA, t.lda, t.K, sidx * 16, kofs + sidx * 16, (AX != 0 && ti == 0) ? 1 : 0};
       }
       const float *__restrict__ B = t.B + (long)b * t.sB;
       auto put = [&](int k, int n, float v) {
@@ -622,9 +630,16 @@ __global__ __launch_bounds__(PANEL_T) void k_gemm_panel(GemmSumP p, int rows_per
   // DZ: the expansion coefficients of term 0 (scale [K], shift [K]) behind the copy of op(B)
   float *__restrict__ zc = reinterpret_cast<float *>(smem + PANEL_HEAD) +
                            (PR == 2 ? NP16 * ldk : Kp * ldn);  // floats: the hi / lo halves together are NP16 * ldk floats
-  if constexpr (DZ) {
+  if constexpr (AX == 1) {
     const int K0 = p.t[0].K;
     for (int i = tid; i < 2 * K0; i += PANEL_T) zc[i] = p.dz_coef[i];
+  }
+  if constexpr (AX == 2) {  // mean [K0p], 1/sigma [K0p], gamma [K0p], beta [K0p] (K0p = K padded to 16: zeros)
+    const int K0 = p.t[0].K, K0p = ((K0 + 15) >> 4) * 16;
+    for (int i = tid; i < 4 * K0p; i += PANEL_T) {
+      const int w = i / K0p, k = i - w * K0p;
+      zc[i] = k >= K0 ? 0.f : w == 0 ? p.ax_stat[k] : w == 1 ? p.ax_stat[K0 + k] : w == 2 ? p.ax_gamma[k] : p.ax_beta[k];
+    }
   }
   __syncthreads();
 
@@ -641,7 +656,7 @@ __global__ __launch_bounds__(PANEL_T) void k_gemm_panel(GemmSumP p, int rows_per
       if (si < nsteps) {
         const PanelStep st = steps[si];
         const int k = st.k0 + 4 * g;
-        if (DZ && st.comp) {  // the record of (row, group st.k0 / 16): the four lanes of a row read the same pair
+        if (AX == 1 && st.comp) {  // the record of (row, group st.k0 / 16): the four lanes of a row read the same pair
           v.y = __int_as_float(-1);
           if (row < p.M) {
             const float2 rc = *reinterpret_cast<const float2 *>(st.A + row * st.lda + 2 * (st.k0 >> 4));
@@ -672,7 +687,24 @@ __global__ __launch_bounds__(PANEL_T) void k_gemm_panel(GemmSumP p, int rows_per
         if (si < nsteps) {
           const int kb = steps[si].kofs + 4 * g;
           float av[4] = {cur[e].x, cur[e].y, cur[e].z, cur[e].w};
-          if constexpr (DZ) {
+          if constexpr (AX == 2) {
+            if (steps[si].comp) {
+              const PanelStep st = steps[si];
+              const int k = st.k0 + 4 * g, K0p = ((st.K + 15) >> 4) * 16;
+              const float4 mu = *reinterpret_cast<const float4 *>(&zc[k]);
+              const float4 iv = *reinterpret_cast<const float4 *>(&zc[K0p + k]);
+              const float4 ga = *reinterpret_cast<const float4 *>(&zc[2 * K0p + k]);
+              const float4 be = *reinterpret_cast<const float4 *>(&zc[3 * K0p + k]);
+              av[0] = (av[0] - mu.x) * iv.x * ga.x + be.x;
+              av[1] = (av[1] - mu.y) * iv.y * ga.y + be.y;
+              av[2] = (av[2] - mu.z) * iv.z * ga.z + be.z;
+              av[3] = (av[3] - mu.w) * iv.w * ga.w + be.w;
+              const long row = row0 + c;
+              if (row < p.M && k < st.K)  // K % 4 == 0 (the operand is 16-byte loadable)
+                *reinterpret_cast<float4 *>(p.ax_out + (st.A - p.t[0].A) + row * st.lda + k) = make_float4(av[0], av[1], av[2], av[3]);
+            }
+          }
+          if constexpr (AX == 1) {
             if (steps[si].comp) {
               const int k = steps[si].k0 + 4 * g, pos = __float_as_int(cur[e].y) - 4 * g;
               const float4 ca = *reinterpret_cast<const float4 *>(&zc[k]);
@@ -802,7 +834,7 @@ using namespace vt;
 
 // Row-panel launch of a sum of products when it is tall and narrow and every A is 16-byte loadable; returns
 // 1 when it took the job, 0 when the tiled kernels should, < 0 on a launch error.
-static int panel_launch(int form, const GemmSumP &p, int batch, hipStream_t hs, bool dz = false) {
+static int panel_launch(int form, const GemmSumP &p, int batch, hipStream_t hs, bool dz = false, bool ax = false) {
   static const bool off = [] {
     const char *e = getenv("VT_GEMM_PANEL");
     return e && *e == '0';
@@ -823,6 +855,10 @@ static int panel_launch(int form, const GemmSumP &p, int batch, hipStream_t hs, 
     if (form != 2 || p.t[0].K % 16 != 0 || !p.dz_coef || (NT != 1 && NT != 4)) return 0;
     lds += (size_t)2 * p.t[0].K * sizeof(float);
   }
+  if (ax) {  // built for the exact form with one result tile (the tokenizer's scores)
+    if (form != 0 || NT != 1 || !p.ax_stat || !p.ax_gamma || !p.ax_beta || !p.ax_out || p.t[0].K % 4 != 0) return 0;
+    lds += (size_t)4 * ((p.t[0].K + 15) / 16) * 16 * sizeof(float);
+  }
   if (lds > 64 * 1024) return 0;
   // rows per workgroup: as many as leave a few thousand workgroups (the LDS copy of B is paid once per workgroup)
   int rows = 1024;
@@ -836,8 +872,9 @@ static int panel_launch(int form, const GemmSumP &p, int batch, hipStream_t hs, 
     else if (NT == 4) VT_PANEL(PR_, 4);  \
     else VT_PANEL(PR_, 8);               \
   } while (0)
-  if (dz && NT == 1) hipLaunchKernelGGL((k_gemm_panel<2, 1, true>), grid, dim3(PANEL_T), lds, hs, p, rows, Kp, nsteps);
-  else if (dz) hipLaunchKernelGGL((k_gemm_panel<2, 4, true>), grid, dim3(PANEL_T), lds, hs, p, rows, Kp, nsteps);
+  if (ax) hipLaunchKernelGGL((k_gemm_panel<0, 1, 2>), grid, dim3(PANEL_T), lds, hs, p, rows, Kp, nsteps);
+  else if (dz && NT == 1) hipLaunchKernelGGL((k_gemm_panel<2, 1, 1>), grid, dim3(PANEL_T), lds, hs, p, rows, Kp, nsteps);
+  else if (dz) hipLaunchKernelGGL((k_gemm_panel<2, 4, 1>), grid, dim3(PANEL_T), lds, hs, p, rows, Kp, nsteps);
   else if (form == 2) VT_PANEL_NT(2);
   else VT_PANEL_NT(0);
 #undef VT_PANEL_NT
@@ -991,6 +1028,24 @@ extern "C" int vt_gemm_sum(int form, int nterms, const vt_gemm_term *terms, int 
 #undef VT_SUM_LAUNCH
   VT_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int vt_gemm_bn_apply(int M, int N, int K, const float *A, int lda, const float *stat, const float *gamma,
+                                const float *beta, float *A_out, const float *B, int ldb, int transB, const float *bias, float *C,
+                                int ldc, vt_stream s) {
+  if (M < 1 || N < 1 || K < 1 || !A || !stat || !gamma || !beta || !A_out || !B || !C || lda < K || ldc < N ||
+      ldb < (transB ? K : N))
+    return VT_EINVAL;
+  if (N > 16) return VT_EUNSUPPORTED;
+  auto aligned = [](const float *q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  GemmSumP p{};
+  p.t[0] = GemmTerm{A, B, 0, 0, K, lda, ldb, transB ? 1 : 0, aligned(A) && aligned(A_out) && lda % 4 == 0 && K % 4 == 0,
+                    aligned(B) && ldb % 4 == 0 && (transB ? K % 4 == 0 : N % 4 == 0)};
+  p.nterms = 1; p.C = C; p.bias = bias; p.M = M; p.N = N; p.ldc = ldc; p.sC = 0; p.alpha = 1.f;
+  p.ax_stat = stat; p.ax_gamma = gamma; p.ax_beta = beta; p.ax_out = A_out;
+  const int took = panel_launch(0, p, 1, (hipStream_t)s, false, true);
+  if (took < 0) return -took;
+  return took > 0 ? 0 : VT_EUNSUPPORTED;
 }
 
 // ---- products with the projector's output delta given as records (vt_pool_delta_records) ----------------------

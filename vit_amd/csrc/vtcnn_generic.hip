@@ -1195,9 +1195,21 @@ int gen_forward(GenModel *g, const float *arena, const vt_layout *lo, float *are
   VTG(mm(false, true, (int)NP, C1, CK, g->col, CK, W("conv.W"), CK, g->conv, C1, W("conv.b")));
   // BatchNorm2DLayer::forward (batch_normalization_layer.hpp:262-298): the only norm that honours eval
   VTG(bn_stats(g, g->conv, NP, C1, RW("bn.running_mean"), RW("bn.running_var"), g->stat_bn, !training, s));
-  VTG(col_affine(0, g->conv, g->stat_bn, W("bn.gamma"), W("bn.beta"), g->x, NP, C1, s));
-  // FilterTokenizer::forward (layers/tokenizer.hpp:22-48)
-  VTG(mm_exact(false, false, (int)NP, L, C1, g->x, C1, W("tok.linear1.W"), L, g->tokA, L, W("tok.linear1.b")));
+  // FilterTokenizer::forward (layers/tokenizer.hpp:22-48).  The BatchNorm apply rides in the launch of its first
+  // reader, the tokenizer's score product, where the row-panel kernel takes the shape: x is written by that launch and
+  // the convolution output is read once for both
+  {
+    int rc = VT_EUNSUPPORTED;
+    if (!g->bf16 && NP < (1L << 31))
+      rc = vt_gemm_bn_apply((int)NP, L, C1, g->conv, C1, g->stat_bn, W("bn.gamma"), W("bn.beta"), g->x, W("tok.linear1.W"), L, 0,
+                            W("tok.linear1.b"), g->tokA, L, (vt_stream)s);
+    if (rc == VT_EUNSUPPORTED) {
+      VTG(col_affine(0, g->conv, g->stat_bn, W("bn.gamma"), W("bn.beta"), g->x, NP, C1, s));
+      VTG(mm_exact(false, false, (int)NP, L, C1, g->x, C1, W("tok.linear1.W"), L, g->tokA, L, W("tok.linear1.b")));
+    } else if (rc != 0) {
+      return rc;
+    }
+  }
   VTG(softmax_pixels(g, g->tokA, n, P, L, s));
   VTG(mm(true, false, L, C1, P, g->tokA, L, g->x, C1, g->T0, C1, nullptr, false, 1.f, n, (long)P * L, (long)P * C1,
          (long)L * C1));
