@@ -29,7 +29,8 @@ def _records(rng, batch, rows, n):
     return rec, coef, dense
 
 
-@pytest.mark.parametrize("M,N,K,batch,ws", [(64, 128, 4096, 1, 1 << 22), (16, 128, 1568, 3, 0), (40, 256, 300, 2, 0)])
+@pytest.mark.parametrize("M,N,K,batch,ws", [(64, 128, 4096, 1, 1 << 22), (16, 128, 1568, 3, 0), (40, 256, 300, 2, 0),
+                                             (16, 128, 3001, 2, 1 << 20), (10, 128, 5000, 3, 1 << 20)])  # the 16-row streaming kernel
 def test_transposed_product_from_records(M, N, K, batch, ws):
     import torch
     from vit_amd._lib import check, lib

@@ -1048,6 +1048,82 @@ extern "C" int vt_gemm_bn_apply(int M, int N, int K, const float *A, int lda, co
   return took > 0 ? 0 : VT_EUNSUPPORTED;
 }
 
+// ---- transposed-A product with at most 16 result rows and B given as delta records: C[b] = A[b]^T . expand(rec[b]),
+// A [K, M <= 16].  With so few result rows a 64-row tile wastes three quarters of its matrix instructions and every K
+// step of 16 pays two barriers; here a wave takes 16 rows of K at a time straight from memory into operand layout
+// (A: lane (m, row group) loads its four rows' element m; B: the lane's four rows' records, expanded), keeps the whole
+// [16, N] result in registers over its share of K, and the waves' results are added in a fixed order: through LDS
+// inside the workgroup, through part[slice][batch][M * N] and k_gemm_splitk_reduce between the K slices.  No LDS or
+// barrier in the loop.  NT = N / 16 result tiles.
+template <int NT>
+__global__ __launch_bounds__(256) void k_tn16_records(GemmP p, int tiles_per_slice) {
+  __shared__ float red[3][16 * NT * 16];
+  const int b = blockIdx.y, slice = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+  const float *__restrict__ A = p.A + (long)b * p.sA;
+  const float *__restrict__ R = p.B + (long)b * p.sB;
+  float ca[NT], cb[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    ca[j] = p.bz_coef[16 * j + c];
+    cb[j] = p.bz_coef[p.N + 16 * j + c];
+  }
+  f32x4 acc[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int t0 = slice * tiles_per_slice, t1 = min(t0 + tiles_per_slice, (p.K + 15) >> 4);
+  for (int t = t0 + wave; t < t1; t += 4) {
+    const int r0 = t * 16 + 4 * g;  // this lane's four rows of K
+    float a[4];
+    float2 rc[NT][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a[q] = (r0 + q < p.K && c < p.M) ? A[(long)(r0 + q) * p.lda + c] : 0.f;
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        rc[j][q] = r0 + q < p.K ? *reinterpret_cast<const float2 *>(R + (long)(r0 + q) * p.ldb + 2 * j) : make_float2(0.f, 0.f);
+    unsigned h01, l01, h23, l23;
+    split2(a[0], a[1], h01, l01);
+    split2(a[2], a[3], h23, l23);
+    const s16x4 ah = __builtin_bit_cast(s16x4, u32x2{h01, h23}), al = __builtin_bit_cast(s16x4, u32x2{l01, l23});
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      float bv[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float d = __float_as_int(rc[j][q].y) == c ? rc[j][q].x : 0.f;
+        bv[q] = r0 + q < p.K ? fmaf(d, ca[j], cb[j]) : 0.f;  // rows past the end contribute nothing (not the shift)
+      }
+      unsigned bh01, bl01, bh23, bl23;
+      split2(bv[0], bv[1], bh01, bl01);
+      split2(bv[2], bv[3], bh23, bl23);
+      const s16x4 bh = __builtin_bit_cast(s16x4, u32x2{bh01, bh23}), bl = __builtin_bit_cast(s16x4, u32x2{bl01, bl23});
+      acc[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al, bh, acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, bl, acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, bh, acc[j], 0, 0, 0);
+    }
+  }
+  // lane (n = c, g) holds D[4 g + v][16 j + c]; waves 1..3 hand theirs to wave 0 through LDS
+  if (wave > 0) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) red[wave - 1][(4 * g + v) * (NT * 16) + 16 * j + c] = acc[j][v];
+  }
+  __syncthreads();
+  if (wave == 0) {
+    float *__restrict__ dst = p.part + ((long)slice * p.batch + b) * (long)p.M * p.N;
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int m = 4 * g + v, idx = m * (NT * 16) + 16 * j + c;
+        const float r = ((acc[j][v] + red[0][idx]) + red[1][idx]) + red[2][idx];
+        if (m < p.M) dst[(long)m * p.N + 16 * j + c] = r;
+      }
+  }
+}
+
 // ---- products with the projector's output delta given as records (vt_pool_delta_records) ----------------------
 extern "C" int vt_gemm_tn_records(int M, int N, int K, const float *A, int lda, long strideA, const float *rec, long strideRec,
                                   const float *coef, float *C, int ldc, long strideC, int batch, float *workspace,
@@ -1059,6 +1135,30 @@ extern "C" int vt_gemm_tn_records(int M, int N, int K, const float *A, int lda, 
   auto aligned = [](const float *q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
   p.vecA = aligned(A) && lda % 4 == 0 && strideA % 4 == 0 && M % 4 == 0;
   if ((reinterpret_cast<uintptr_t>(rec) & 7) != 0 || strideRec % 2 != 0) return VT_EINVAL;
+  static const bool skinny_off = [] {
+    const char *e = getenv("VT_GEMM_TN16");
+    return e && *e == '0';
+  }();
+  if (!skinny_off && M <= 16 && N == 128 && workspace && K >= 1024) {
+    // at most 16 result rows: the streaming kernel, K cut into slices that leave a few thousand workgroups and fit the
+    // workspace
+    const long tiles = (K + 15) / 16, per = (long)M * N * batch;
+    long slices = (2048 + batch - 1) / batch;
+    if (slices > tiles / 8) slices = tiles / 8 > 0 ? tiles / 8 : 1;
+    if (slices > workspace_floats / per) slices = workspace_floats / per;
+    if (slices >= 1 && slices <= 65535 && batch <= 65535) {
+      const int tps = (int)((tiles + slices - 1) / slices);
+      p.ksplit = (int)((tiles + tps - 1) / tps);
+      p.part = workspace;
+      hipLaunchKernelGGL(k_tn16_records<8>, dim3(p.ksplit, batch), dim3(256), 0, (hipStream_t)s, p, tps);
+      VT_CHECK_LAUNCH();
+      const long total = per;
+      const int nb = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+      hipLaunchKernelGGL(k_gemm_splitk_reduce, dim3(nb), dim3(256), 0, (hipStream_t)s, p, batch);
+      VT_CHECK_LAUNCH();
+      return 0;
+    }
+  }
   const int BM = 64, BN = 128;
   const long tiles = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN) * batch;
   const long target = K >= 4096 ? 2048 : 1024;  // K slices as in gemm_launch
