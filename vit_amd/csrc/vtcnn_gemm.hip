@@ -1077,11 +1077,16 @@ __global__ __launch_bounds__(256) void k_tn16_records(GemmP p, int tiles_per_sli
     float2 rc[NT][4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) a[q] = (r0 + q < p.K && c < p.M) ? A[(long)(r0 + q) * p.lda + c] : 0.f;
+    // a row's records are adjacent: two per 16-byte load (the launcher checked the alignment; NT is even)
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
+    for (int q = 0; q < 4; ++q)
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-        rc[j][q] = r0 + q < p.K ? *reinterpret_cast<const float2 *>(R + (long)(r0 + q) * p.ldb + 2 * j) : make_float2(0.f, 0.f);
+      for (int j = 0; j < NT; j += 2) {
+        const float4 v = r0 + q < p.K ? *reinterpret_cast<const float4 *>(R + (long)(r0 + q) * p.ldb + 2 * j)
+                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+        rc[j][q] = make_float2(v.x, v.y);
+        rc[j + 1][q] = make_float2(v.z, v.w);
+      }
     unsigned h01, l01, h23, l23;
     split2(a[0], a[1], h01, l01);
     split2(a[2], a[3], h23, l23);
@@ -1139,7 +1144,7 @@ extern "C" int vt_gemm_tn_records(int M, int N, int K, const float *A, int lda, 
     const char *e = getenv("VT_GEMM_TN16");
     return e && *e == '0';
   }();
-  if (!skinny_off && M <= 16 && N == 128 && workspace && K >= 1024) {
+  if (!skinny_off && M <= 16 && N == 128 && workspace && K >= 1024 && aligned(rec) && strideRec % 4 == 0) {
     // at most 16 result rows: the streaming kernel, K cut into slices that leave a few thousand workgroups and fit the
     // workspace
     const long tiles = (K + 15) / 16, per = (long)M * N * batch;
