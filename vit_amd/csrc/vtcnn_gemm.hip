@@ -537,7 +537,9 @@ __global__ __launch_bounds__(PANEL_T) void k_gemm_panel(GemmSumP p, int rows_per
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   PanelStep *steps = reinterpret_cast<PanelStep *>(smem);
   constexpr int NP16 = NT * 16;
-  const int ldk = Kp + 4, ldn = NP16 + 4;
+  // rows of Kp + 8 halves: Kp is a multiple of 16, so a row is an odd multiple of four banks and the 8-byte operand
+  // reads of the 32 lanes of a half wave (16 rows x 2 k groups) fall on 64 different banks
+  const int ldk = Kp + 8, ldn = NP16 + 4;
   unsigned short *__restrict__ Bh = reinterpret_cast<unsigned short *>(smem + PANEL_HEAD);
   unsigned short *__restrict__ Bl = Bh + NP16 * ldk;
   float *__restrict__ Bs = reinterpret_cast<float *>(smem + PANEL_HEAD);
@@ -850,7 +852,7 @@ static int panel_launch(int form, const GemmSumP &p, int batch, hipStream_t hs, 
   }
   if (nsteps > PANEL_STEPS) return 0;
   const int NT = p.N <= 16 ? 1 : p.N <= 32 ? 2 : p.N <= 64 ? 4 : 8;
-  size_t lds = PANEL_HEAD + (form == 2 ? (size_t)2 * NT * 16 * (Kp + 4) * 2 : (size_t)Kp * (NT * 16 + 4) * 4);
+  size_t lds = PANEL_HEAD + (form == 2 ? (size_t)2 * NT * 16 * (Kp + 8) * 2 : (size_t)Kp * (NT * 16 + 4) * 4);
   if (dz) {
     if (form != 2 || p.t[0].K % 16 != 0 || !p.dz_coef || (NT != 1 && NT != 4)) return 0;
     lds += (size_t)2 * p.t[0].K * sizeof(float);
