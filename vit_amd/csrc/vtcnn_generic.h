@@ -22,6 +22,8 @@ struct GenModel {
   // backward
   float *dlogits, *dpool, *du, *dz, *pdx, *dsa, *dsa_tok, *U, *dv, *dk, *pdt, *d0, *ds2, *dh, *da, *dr, *dc;
   float *Qm, *Km, *Vm, *dQ, *dK, *dV, *attn, *dat, *dT0, *tdx, *csum, *dzr, *coef_pn;
+  int heads_batched;  // 1: the attention backward's buffers hold every head at once (one launch per operation)
+  float *dch;         // the concat delta head-major [heads][n*L][hd]
   int dz_valid;   // 1: `dz` holds the dense delta behind the projector's BatchNorm (0: only the records `dzr` were written)
   int tdx_valid;  // 1: `tdx` holds the BatchNorm2D input delta of the last backward (0: it was folded into the conv gradient)
 };

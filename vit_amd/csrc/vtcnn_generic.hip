@@ -149,6 +149,17 @@ __global__ __launch_bounds__(GT) void k_affine_rank1(float *__restrict__ G, cons
   G[i] = G[i] * coef[c] + coef[C + c] * csum[k];
 }
 
+// out[h][r][j] = in[r][h * hd + j]: the columns of one head of a [rows, heads * hd] matrix as a matrix of their own
+__global__ __launch_bounds__(GT) void k_head_major(const float *__restrict__ in, float *__restrict__ out, long rows, int heads,
+                                                   int hd) {
+  const long total = rows * heads * hd;
+  for (long i = (long)blockIdx.x * GT + threadIdx.x; i < total; i += (long)gridDim.x * GT) {
+    const long r = i / (heads * hd);
+    const int c = (int)(i - r * heads * hd), h = c / hd, j = c - h * hd;
+    out[((long)h * rows + r) * hd + j] = in[i];
+  }
+}
+
 // ---- per-column partial statistics of a row matrix: part[b][0][c] = sum, part[b][1][c] = sum of
 // squared distances from the block's own mean (merged by vt_bn_stats_finalize).  One pass over the rows: a
 // thread accumulates sum and sum of squares of (x - pivot), pivot = the first value it meets (so the squares
@@ -1158,14 +1169,20 @@ int gen_create(GenModel *g, const vt_dims *d, int maxN, int (*alloc)(void *, flo
   A(&g->da, NL * D, nullptr);
   A(&g->dr, NL * D, "bwd.tr_dr");
   A(&g->dc, NL * D, nullptr);
-  A(&g->Qm, NL * hd, nullptr);
-  A(&g->Km, NL * hd, nullptr);
-  A(&g->Vm, NL * hd, nullptr);
-  A(&g->dQ, NL * hd, nullptr);
-  A(&g->dK, NL * hd, nullptr);
-  A(&g->dV, NL * hd, nullptr);
-  A(&g->attn, (size_t)L * N * N, nullptr);
-  A(&g->dat, (size_t)L * N * N, nullptr);
+  // attention backward: every head at once (one launch per operation) while the score matrices of all heads stay
+  // under 4 GiB each, head by head beyond that
+  g->heads_batched = g->heads > 1 && (size_t)L * N * N * g->heads <= ((size_t)1 << 30) && (size_t)L * g->heads <= 65535;
+  const size_t hb = g->heads_batched ? g->heads : 1;
+  A(&g->Qm, NL * hd * hb, nullptr);
+  A(&g->Km, NL * hd * hb, nullptr);
+  A(&g->Vm, NL * hd * hb, nullptr);
+  A(&g->dQ, NL * hd * hb, nullptr);
+  A(&g->dK, NL * hd * hb, nullptr);
+  A(&g->dV, NL * hd * hb, nullptr);
+  A(&g->attn, (size_t)L * N * N * hb, nullptr);
+  A(&g->dat, (size_t)L * N * N * hb, nullptr);
+  g->dch = nullptr;
+  if (g->heads_batched) A(&g->dch, NL * D, nullptr);
   A(&g->dT0, NL * C1, nullptr);
   A(&g->tdx, NP * C1, "bwd.tok_dx");
   A(&g->csum, (size_t)g->Ci * 9 + 4, nullptr);
@@ -1397,7 +1414,42 @@ int gen_backward(GenModel *g, const float *arena, const vt_layout *lo, float *gr
     VTG(mm(false, true, (int)NL, D, D, g->dr, D, W("mha.o.W"), D, g->dc, D));
     const float scale = 1.0f / sqrtf((float)hd);
     const long sG = (long)n * hd, sS = (long)n * n;
-    for (int h = 0; h < g->heads; ++h) {
+    // The heads' weights lie q0 k0 v0 q1 k1 v1 ... at one stride in the arena; with it the per-head operations are
+    // batch members of one launch each: heads x L groups of n rows (head h, token l = member h * L + l).
+    const int H = g->heads;
+    long wstride = 0;
+    bool batched = g->heads_batched != 0;
+    if (batched) {
+      const long q0 = lo->t[vt_find(lo, "mha.q0.W")].offset, q1 = lo->t[vt_find(lo, "mha.q1.W")].offset;
+      wstride = q1 - q0;
+      for (int h = 0; h < H && batched; ++h) {
+        const std::string hs = std::to_string(h);
+        batched = lo->t[vt_find(lo, ("mha.q" + hs + ".W").c_str())].offset == q0 + h * wstride &&
+                  lo->t[vt_find(lo, ("mha.k" + hs + ".W").c_str())].offset == lo->t[vt_find(lo, "mha.k0.W")].offset + h * wstride &&
+                  lo->t[vt_find(lo, ("mha.v" + hs + ".W").c_str())].offset == lo->t[vt_find(lo, "mha.v0.W")].offset + h * wstride;
+      }
+    }
+    if (batched) {
+      const long sH = NL * hd;  // one head's [n*L, hd] matrix
+      const int HL = H * L;
+      // queries, keys and their scores feed the softmax's exponential: exact fp32
+      VTG(mm_fwd_exact(false, false, (int)NL, hd, D, g->tok, D, W("mha.q0.W"), hd, g->Qm, hd, nullptr, false, 1.f, H, 0, wstride, sH));
+      VTG(mm_fwd_exact(false, false, (int)NL, hd, D, g->tok, D, W("mha.k0.W"), hd, g->Km, hd, nullptr, false, 1.f, H, 0, wstride, sH));
+      VTG(mm_fwd(false, false, (int)NL, hd, D, g->tok, D, W("mha.v0.W"), hd, g->Vm, hd, nullptr, false, 1.f, H, 0, wstride, sH));
+      VTG(mm_exact(false, true, n, n, hd, g->Km, hd, g->Qm, hd, g->attn, n, nullptr, false, scale, HL, sG, sG, sS));
+      VTG(softmax_rows(g->attn, NL * H, n, s));
+      hipLaunchKernelGGL(k_head_major, dim3(nblk(NL * D)), dim3(GT), 0, s, g->dc, g->dch, NL, H, hd);
+      VT_CHECK_LAUNCH();
+      VTG(mm(false, true, n, n, hd, g->dch, hd, g->Vm, hd, g->dat, n, nullptr, false, 1.f, HL, sG, sG, sS));
+      VTG(mm(true, false, n, hd, n, g->attn, n, g->dch, hd, g->dV, hd, nullptr, false, 1.f, HL, sS, sG, sG));
+      VTG(softmax_bwd_rows(g->attn, g->dat, NL * H, n, s));
+      VTG(mm(false, false, n, hd, n, g->dat, n, g->Qm, hd, g->dK, hd, nullptr, false, 1.f, HL, sS, sG, sG));
+      VTG(mm(true, false, n, hd, n, g->dat, n, g->Km, hd, g->dQ, hd, nullptr, false, 1.f, HL, sS, sG, sG));
+      VTG(mm(true, false, D, hd, (int)NL, g->tok, D, g->dK, hd, G("mha.k0.W"), hd, nullptr, false, 1.f, H, 0, sH, wstride));
+      VTG(mm(true, false, D, hd, (int)NL, g->tok, D, g->dQ, hd, G("mha.q0.W"), hd, nullptr, false, 1.f, H, 0, sH, wstride));
+      VTG(mm(true, false, D, hd, (int)NL, g->tok, D, g->dV, hd, G("mha.v0.W"), hd, nullptr, false, 1.f, H, 0, sH, wstride));
+    }
+    for (int h = 0; h < (batched ? 0 : g->heads); ++h) {
       const std::string hs = std::to_string(h);
       const std::string nq = "mha.q" + hs + ".W", nk = "mha.k" + hs + ".W", nv = "mha.v" + hs + ".W";
       // queries, keys and their scores feed the softmax's exponential: exact fp32
