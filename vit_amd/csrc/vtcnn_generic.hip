@@ -1469,7 +1469,6 @@ int gen_backward(GenModel *g, const float *arena, const vt_layout *lo, float *gr
       VTG(mm(true, false, D, hd, (int)NL, g->tok, D, g->dV, hd, G(nv.c_str()), hd));
     }
   }
-  (void)X;
   return 0;
 }
 
