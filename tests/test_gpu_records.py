@@ -95,3 +95,27 @@ def test_sum_and_softmax_backward_from_records():
     from vit_amd._lib import lib as L
     assert L.vt_gemm_sum_records(1, t, C.c_void_p(dcoef.data_ptr()), 0, None, 64, 16, C.c_void_p(out.data_ptr()), 16, 64 * 16, None,
                                  1, s) == -2  # fewer than 2048 rows
+
+
+def test_batchnorm_apply_inside_its_first_product():
+    """vt_gemm_bn_apply: the normalised matrix and the product that reads it from one pass over the BatchNorm input."""
+    import torch
+    from vit_amd._lib import check, lib
+    rng = np.random.default_rng(6)
+    M, N, K = 5000, 16, 64
+    A = (rng.standard_normal((M, K)) * 3 + 1).astype(np.float32)
+    stat = np.concatenate([A.mean(0), 1.0 / np.sqrt(A.var(0) + 1e-5)]).astype(np.float32)
+    gamma, beta = rng.uniform(0.5, 1.5, K).astype(np.float32), rng.standard_normal(K).astype(np.float32)
+    B, bias = rng.standard_normal((K, N)).astype(np.float32), rng.standard_normal(N).astype(np.float32)
+    d = [torch.from_numpy(x).cuda() for x in (A, stat, gamma, beta, B, bias)]
+    x = torch.zeros((M, K), dtype=torch.float32, device="cuda")
+    out = torch.zeros((M, N), dtype=torch.float32, device="cuda")
+    P = lambda t: C.c_void_p(t.data_ptr())
+    check(lib.vt_gemm_bn_apply(M, N, K, P(d[0]), K, P(d[1]), P(d[2]), P(d[3]), P(x), P(d[4]), N, 0, P(d[5]), P(out), N,
+                               C.c_void_p(torch.cuda.current_stream().cuda_stream)), "vt_gemm_bn_apply")
+    torch.cuda.synchronize()
+    want_x = (A.astype(np.float64) - stat[:K]) * stat[K:] * gamma + beta
+    assert rel_err(x.cpu().numpy(), want_x) < 2e-6
+    assert rel_err(out.cpu().numpy(), want_x @ B.astype(np.float64) + bias) < 2e-6
+    # more than 16 result columns: refused, nothing launched
+    assert lib.vt_gemm_bn_apply(M, 32, K, P(d[0]), K, P(d[1]), P(d[2]), P(d[3]), P(x), P(d[4]), 32, 0, None, P(out), 32, None) == -2
