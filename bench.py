@@ -12,6 +12,11 @@ semantic unit because of BatchNorm), gradients are summed over ranks with one RC
 the flat gradient arena and divided by world*batch.  Rank 0 prints ONE JSON line: the contract's fields, `roofline`
 (whole-step HBM form: algorithmic layer-boundary bytes per step over the measured step time, with the per-launcher
 table and the event-timed dominant launcher beside it) and `cpu_baseline` (the real reference on the host cores).
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment: this process never touches a GPU; it starts N ranks
+(`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ...` on a free port of 127.0.0.1), relays rank 0's
+JSON line and exits with the launcher's status.  `n_gpus` in the line is the number of ranks that joined the
+process group (an all-reduce of ones), not the flag.
 """
 import argparse
 import json
@@ -20,8 +25,53 @@ import subprocess
 import sys
 import time
 
-import numpy as np
-import torch
+ROOT_ = os.path.dirname(os.path.abspath(__file__))
+
+
+def launch_ranks(n, argv):
+    """Parent of a multi-rank run: starts one process per GPU before anything here has touched a device, passes
+    the children's stderr through, prints the one JSON line rank 0 wrote and returns the launcher's exit status."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT_, "bench.py")] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", "1")  # what torch.distributed.run would set itself, without its warning
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    lines = []
+    for line in proc.stdout:
+        if line.startswith('{"metric"'):
+            lines.append(line.rstrip("\n"))
+        else:
+            sys.stderr.write(line)
+    rc = proc.wait()
+    if lines:
+        print(lines[-1], flush=True)
+    elif rc == 0:
+        sys.stderr.write("bench.py: the ranks exited without a result line\n")
+        rc = 1
+    return rc
+
+
+def _launch_if_parent():
+    """`--gpus N > 1` outside a process group: become the parent (before numpy / torch are even imported)."""
+    if "WORLD_SIZE" in os.environ:
+        return
+    ap = argparse.ArgumentParser(add_help=False)
+    ap.add_argument("--gpus", type=int, default=1)
+    known, _ = ap.parse_known_args()
+    if known.gpus > 1:
+        sys.exit(launch_ranks(known.gpus, sys.argv[1:]))
+
+
+if __name__ == "__main__":
+    _launch_if_parent()
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -150,6 +200,12 @@ def cpu_baseline(batch, classes):
             r1 = json.loads(one.stdout.strip().splitlines()[-1])
             res["one_core"] = {"value": round(r1["images_per_sec"], 2), "unit": "images/sec", "cores": 1,
                                "sample": "3 training steps of one 32-image mini-batch"}
+            # and what `run.sh main <dataset> train` itself runs: the reference's loader batch of 32 (main.cpp:77) on all cores
+            b32 = subprocess.run([exe, "bench", "32", str(classes), "20", "2"], env=env, capture_output=True, text=True, timeout=300)
+            r32 = json.loads(b32.stdout.strip().splitlines()[-1])
+            res["batch32_all_cores"] = {"value": round(r32["images_per_sec"], 2), "unit": "images/sec", "cores": int(r32["threads"]),
+                                        "sample": "20 training steps (after 2 warm-up) of one 32-image mini-batch, the reference's own "
+                                                  "loader batch size"}
             return res
         except Exception as e:  # fall through to the port
             sys.stderr.write("reference harness failed (%s); timing the oracle port instead\n" % e)
@@ -169,6 +225,108 @@ def cpu_baseline(batch, classes):
     dt = time.time() - t0
     return {"value": round(n / dt, 2), "unit": "images/sec", "cores": cores, "host_cpu_count": host_cpus, "kind": "port",
             "sample": "1 training step of one %d-image mini-batch, CPU restatement (oracle/vtcnn_oracle.c)" % n}
+
+
+def algorithmic_flops_per_image(d, batch, forward_only=False):
+    """Matrix-product and convolution FLOPs of one image in the reference's own formulation: forward
+    2*[conv + tokenizer + transformer (q/k/v, scores and attention.values over the mini-batch axis, output projection,
+    feed-forward) + projector + fc], training = 3 x forward (the reference's recomputations and its unused
+    convolution input delta are not counted)."""
+    Ci, P, C2, L, D, K = d.image_channels, d.input_dim ** 2, d.vt_channels, d.tokens, d.token_channels, d.num_classes
+    C1, Q = C2 // 2, C2 * 196
+    fwd = 2 * (9 * Ci * C1 * P + 2 * P * C1 * L + L * C1 * D + 3 * L * D * D + 2 * L * batch * D + L * D * D + 2 * L * D * D
+               + P * C1 * D + L * D * D + P * D * L + L * D * C2 + P * L * C2 + P * C1 * C2 + Q * K)
+    return fwd if forward_only else 3 * fwd
+
+
+GENERIC_EMULATION = ("fp32 storage and accumulation; products of depth >= 32 that do not feed an exponential (activation x "
+                     "weight, delta x weight, gradient contractions) run as bf16x3 hi/lo split products with fp32 accumulate "
+                     "(about 2^-17 relative per product), the others on exact fp32 MFMA; VT_GEMM_EXACT=1 keeps every product exact")
+BF16_EMULATION = ("--bf16: the dense-layer products (feed-forward, projector linear layers, classifier, recomputed q/k/v) round "
+                  "their operands to bf16 (fp32 accumulate); everything else as in the fp32 mode of the general step")
+
+
+def emulation_note(generic, bf16):
+    if not generic:
+        return ("fp32 storage and accumulation; the 16- and 32-deep contractions "
+                "(projector value/downsample and delta products, tokenizer input delta, all attention-backward products) "
+                "run as bf16x3 hi/lo split products with fp32 accumulate (about 2^-17 relative per product), "
+                "the narrow ones on exact fp32 MFMA")
+    if os.environ.get("VT_GEMM_EXACT", "") not in ("", "0"):
+        return BF16_EMULATION if bf16 else None
+    return (BF16_EMULATION + "; " + GENERIC_EMULATION) if bf16 else GENERIC_EMULATION
+
+
+def time_extra_config(shape, batch, bf16, classes, steps=3, warmup=1):
+    """One of the other BASELINE configurations under the same clock, in this process (after the headline model is
+    gone): `steps` training steps of the general-shape step on one resident synthetic mini-batch.  The scaled shape
+    is HBM-bound (layer-boundary byte model), the wide shape matrix-bound (algorithmic FLOPs against the dense
+    matrix peak of the arithmetic it runs in: exact-fp32 MFMA 157.3 TF, bf16 2.5 PF)."""
+    from vit_amd import VTCNN, Dims
+    dims = Dims(num_classes=classes, **SHAPES[shape])
+    m = VTCNN(dims, max_batch=batch, seed=42)
+    if bf16:
+        m.set_matmul_precision(True)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(123)
+    x = torch.rand((batch, dims.image_channels, dims.input_dim, dims.input_dim), device="cuda", generator=g)
+    y = torch.randint(0, classes, (batch,), device="cuda", generator=g).to(torch.int32)
+    for _ in range(warmup):
+        m.train_step(x, y, float(batch))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        m.train_step(x, y, float(batch))
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    finite = bool(torch.isfinite(m.arena).all().item())
+    _, total_bytes = algorithmic_bytes_per_image(dims, False, True)
+    flops = algorithmic_flops_per_image(dims, batch)
+    gbs = total_bytes * batch / dt / 1e9
+    tfs = flops * batch / dt / 1e12
+    if shape == "wide":
+        peak = MFMA_BF16_PEAK_TFLOPS if bf16 else MFMA_F32_PEAK_TFLOPS
+        roof = {"bound": "mfma", "achieved": round(tfs, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tfs / peak, 4),
+                "algorithmic_flops_per_step": flops * batch, "hbm_gbs_on_the_byte_model": round(gbs, 1)}
+    else:
+        roof = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                "algorithmic_bytes_per_step": total_bytes * batch, "tflops_on_the_flop_model": round(tfs, 2)}
+    roof["traffic"] = measured_step_traffic(shape, batch, classes) if not bf16 else None
+    roof["traffic_source"] = "committed PMC passes of this configuration (profiles/), not this run" if roof["traffic"] else None
+    del m, x, y
+    torch.cuda.empty_cache()
+    return {"ms_per_step": round(dt * 1e3, 3), "images_per_sec": round(batch / dt, 1), "batch": batch, "steps": steps,
+            "warmup": warmup, "dtype": "bf16" if bf16 else "f32", "emulation": emulation_note(True, bf16),
+            "weights_finite_after_run": finite, "roofline": roof}
+
+
+def dry_run(a, world, rank):
+    """VT_BENCH_DRY=1: rehearsal of everything around the device work on a machine without a GPU (CPU tests): the
+    ranks rendezvous over gloo, count themselves, exchange a gradient-sized buffer, and rank 0 prints the line with
+    `value` null."""
+    import torch.distributed as dist
+    from vit_amd.engine import Dims, layout_sizes
+    dims = Dims(num_classes=a.classes, **SHAPES[a.shape])
+    n_total, n_train = layout_sizes(dims)
+    joined = 1
+    if world > 1:
+        dist.init_process_group("gloo")
+        ones = torch.ones(1)
+        dist.all_reduce(ones)
+        joined = int(ones.item())
+        g = torch.full((n_train,), float(rank + 1))
+        dist.all_reduce(g)
+        assert float(g[0]) == world * (world + 1) / 2 and float(g[-1]) == float(g[0])
+    if rank == 0:
+        print(json.dumps({"metric": "train images/sec (whole node) VTCNN BloodMNIST", "value": None, "unit": "images/sec",
+                          "n_gpus": joined, "steps": a.steps, "warmup": a.warmup, "ms_per_step": None, "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "dry_run": True,
+                          "config": {"workload": "rehearsal without a device: rendezvous and exchange only",
+                                     "per_gpu_batch": a.batch, "global_batch": a.batch * joined, "parallelism": "dp%d" % joined,
+                                     "grad_allreduce_floats": int(n_train) if world > 1 else 0}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():
@@ -201,12 +359,18 @@ def main():
                          "vt_model_set_deferred_attention); only without a gradient exchange (one GPU)")
     ap.add_argument("--fused-reductions", type=int, default=-1, help="BatchNorm reductions closed inside their producer kernels: 1 / 0, default: the library's choice")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-configs", action="store_true",
+                    help="skip the three short runs of the scaled and wide configurations behind the headline timing")
     ap.add_argument("--kernel", default=None, help="launcher to time with HIP events (default: the slowest)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world and rank == 0:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: the process group decides\n" % (a.gpus, world))
+    if os.environ.get("VT_BENCH_DRY", "") not in ("", "0"):
+        return dry_run(a, world, rank)
     if os.environ.get("VT_BENCH_FAULT_TIMEOUT"):  # debugging aid: dump every thread's stack and exit if the run stalls
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["VT_BENCH_FAULT_TIMEOUT"]), exit=True)
@@ -237,6 +401,18 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local))
+
+    joined, distinct = 1, 1
+    if dist is not None and world > 1:
+        ones = torch.ones(1, device="cuda")
+        dist.all_reduce(ones)  # every rank that joined the group adds one: this, not the flag, is n_gpus
+        joined = int(ones.item())
+        uu = torch.zeros(world, dtype=torch.int64, device="cuda")
+        import zlib
+        ident = str(getattr(torch.cuda.get_device_properties(local), "uuid", local))
+        uu[rank] = zlib.crc32(ident.encode()) + 1
+        dist.all_reduce(uu)
+        distinct = len(set(uu.tolist()))
 
     from vit_amd import VTCNN, Dims
     dims = Dims(num_classes=a.classes, **SHAPES[a.shape])
@@ -304,11 +480,11 @@ def main():
     breakdown = m.profile_read()
     per_launch_ms = {k: v[0] / v[1] for k, v in breakdown.items()}
     tbl, total_bytes = algorithmic_bytes_per_image(dims, a.mode == "predict", generic)
-    candidates = {k: v for k, v in breakdown.items() if k in tbl or k == "mha_bwd_rows"}
-    # fixed choice (not "the slowest this run": two launchers tie within a microsecond): the launcher that the
-    # byte model charges with the most bytes, which is also one of the two longest in the committed kernel traces
-    dominant = a.kernel or ("generic_backward" if generic else ("head_fwd" if a.mode == "predict" else "projector_bwd"))
-    del candidates
+    candidates = {k: per_launch_ms[k] for k in breakdown if k in tbl or k == "mha_bwd_rows"}
+    # the dominant launcher = the slowest one of this run's warm-up breakdown (among those a roofline is defined for:
+    # the byte model's launchers and the attention backward); `most_bytes_kernel` names the byte model's largest
+    most_bytes = max(tbl, key=lambda k: tbl[k])
+    dominant = a.kernel or (max(candidates, key=lambda k: candidates[k]) if candidates else most_bytes)
     # timed with HIP events on one step in eight: the two queue markers of an event pair stall the launch
     # stream for about 4.4 us each time, which would otherwise be part of every measured step
     m.profile(dominant + "/8")
@@ -361,7 +537,7 @@ def main():
         del src, dst
 
     if rank == 0:
-        value = a.steps * B * world / dt
+        value = a.steps * B * joined / dt
         step_s = dt / a.steps
         traffic_tbl = measured_traffic_table(B, a.classes) if (a.mode == "train" and not generic) else None
         # per-launcher table from the warm-up breakdown (HIP events around every launcher; an event pair adds
@@ -404,7 +580,8 @@ def main():
                    "algorithmic_bytes_per_launch": tbl.get(dominant, 0) * B}
         dom.update({"avg_launch_us": None if not k_cnt else round(avg_s * 1e6, 2), "launches_timed": k_cnt, "timed_every_nth_step": 8,
                     "event_pair_overhead_us": round(pair_us, 2),
-                    "chosen": "fixed: the launcher with the most algorithmic bytes" if not a.kernel else "--kernel"})
+                    "chosen": "the slowest launcher of this run's warm-up breakdown" if not a.kernel else "--kernel",
+                    "most_bytes_kernel": most_bytes})
         # headline roofline: HBM is the bounding roofline of this shape (every contraction is 8 to 32 deep), so
         # the figure is the whole step: algorithmic bytes of one step over the measured time of one step
         # (all launches of the step; `ms_per_step` of this same line)
@@ -415,6 +592,8 @@ def main():
                 "traffic": (measured_step_traffic(a.shape, B, a.classes) if (generic and a.mode == "train") else None)
                            if not traffic_tbl else int(sum(v * STEP_LAUNCHES.get(k, 1) for k, v in traffic_tbl.items()
                                                            if k != "k_probe_copy")),
+                "traffic_source": "summed from the committed PMC passes of this configuration (profiles/, separate "
+                                  "rocprofv3 --pmc runs of this command), not measured in this run",
                 "algorithmic_bytes_per_launch": total_bytes * B, "avg_launch_us": round(step_s * 1e6, 2),
                 "launches_timed": a.steps,
                 "definition": "algorithmic layer-boundary bytes per image x images per step / measured step time; "
@@ -422,28 +601,39 @@ def main():
                 "dominant_kernel": dom, "kernels": ktable}
         res = {
             "metric": ("train" if a.mode == "train" else "predict") + " images/sec (whole node) VTCNN " + {"blood": "BloodMNIST"}.get(a.shape, a.shape), "value": round(value, 1), "unit": "images/sec",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 4),
+            "n_gpus": joined, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if a.bf16 else "f32",
-            "emulation": None if (a.bf16 or generic) else "fp32 storage and accumulation; the 16- and 32-deep contractions "
-                         "(projector value/downsample and delta products, tokenizer input delta, all attention-backward products) "
-                         "run as bf16x3 hi/lo split products with fp32 accumulate (about 2^-17 relative per product), "
-                         "the narrow ones on exact fp32 MFMA",
+            "emulation": emulation_note(generic, a.bf16),
             "data": "synthetic",
             "config": {"workload": ("VTCNN train step (forward+backward+SGD)" if a.mode == "train" else
                                     "VTCNN predict step (eval-mode forward)") + ", %s shape %dx%dx%d, %d classes, "
                                    "mini-batch %d per GPU, fp32, seed-42 reference init" % (
                                        {"blood": "BloodMNIST"}.get(a.shape, a.shape), dims.image_channels, dims.input_dim,
                                        dims.input_dim, a.classes, B),
-                       "hip_graph": bool(use_graph), "two_stream_backward": bool(a.concurrent) and not generic, "deferred_attention_backward": deferred, "statistics_group": a.group if a.mode == "predict" else 0, "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world,
+                       "hip_graph": bool(use_graph), "two_stream_backward": bool(a.concurrent) and not generic, "deferred_attention_backward": deferred, "statistics_group": a.group if a.mode == "predict" else 0, "per_gpu_batch": B, "global_batch": B * joined, "parallelism": "dp%d" % joined,
+                       "distinct_devices": distinct,
                        "exchange_overlapped": bool(dp.overlap and a.mode == "train" and not use_graph),
                        "grad_allreduce_floats": int(m.layout.n_trainable) if world > 1 else 0},
             "weights_finite_after_run": weights_finite,
             "roofline": roof,
-            "whole_step_hbm_frac": round(value / world * total_bytes / (HBM_PEAK_GBS * 1e9), 4),  # algorithmic bytes, not measured
+            "whole_step_hbm_frac": round(value / joined * total_bytes / (HBM_PEAK_GBS * 1e9), 4),  # algorithmic bytes, not measured
             "measured_copy_gbs": None if copy_gbs is None else round(copy_gbs, 1),
             "algorithmic_bytes_per_image": total_bytes,
             "launcher_us": {k: round(1e3 * v, 2) for k, v in sorted(per_launch_ms.items(), key=lambda kv: -kv[1])},
         }
+        if world == 1 and not a.no_extra_configs and a.mode == "train" and not generic and not a.exchange_alone:
+            # the other BASELINE configurations under the same clock: three steps each, after the headline model is gone
+            del m, dp, xs, ys
+            torch.cuda.empty_cache()
+            extra = {}
+            for name, shp, bt, bf in (("scaled_b1024_f32", "scaled", 1024, False), ("wide_b16_f32", "wide", 16, False),
+                                      ("wide_b16_bf16", "wide", 16, True)):
+                try:
+                    extra[name] = time_extra_config(shp, bt, bf, a.classes)
+                except Exception as e:  # the headline line must survive a failure here
+                    extra[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+                    torch.cuda.empty_cache()
+            res["configs"] = extra
         if world == 1 and not a.no_cpu_baseline and a.mode == "train" and not generic:
             res["cpu_baseline"] = cpu_baseline(B, a.classes)
         print(json.dumps(res), flush=True)

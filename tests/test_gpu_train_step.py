@@ -471,6 +471,30 @@ def test_deferred_attention_backward_is_bit_identical(n):
     assert np.array_equal(a.get_arena(), b.get_arena())
 
 
+def test_graph_replay_waits_for_a_deferred_attention_backward():
+    """vt_model_graph_launch after an eager step whose attention backward was deferred: the replay overwrites the
+    buffers, gradients and attention weights that deferred work still reads and writes, so it must wait for it.
+    Eager deferred step, then two graph replays, against the same three steps in order on a plain model."""
+    import torch
+    from vit_amd import VTCNN, Dims
+    n = 256
+    rng = np.random.default_rng(99)
+    xs = [torch.from_numpy(rng.integers(0, 256, size=(n, 1, 28, 28)).astype(np.float32) / np.float32(255.0)).cuda() for _ in range(3)]
+    ys = [torch.from_numpy(rng.integers(0, 8, size=n).astype(np.int32)).cuda() for _ in range(3)]
+    a, b = (VTCNN(Dims(num_classes=8), max_batch=n, seed=42) for _ in range(2))
+    xbuf, ybuf = torch.empty_like(xs[0]), torch.empty_like(ys[0])
+    b.capture_step(xbuf, ybuf, float(n))
+    b.set_deferred_attention(True)
+    for rep in range(2):
+        a.forward(xs[0]); a.backward(ys[0]); a.update_weights(float(n))
+        b.forward(xs[0]); b.backward(ys[0]); b.update_weights(float(n))  # attention block trails on its own stream
+        for t in (1, 2):
+            a.forward(xs[t]); a.backward(ys[t]); a.update_weights(float(n))
+            xbuf.copy_(xs[t]); ybuf.copy_(ys[t])
+            b.step_graph()
+        assert np.array_equal(a.get_arena(), b.get_arena()), rep
+
+
 def test_batch_size_may_change_from_step_to_step():
     """One model (max_batch 96) stepping through batches of 96, 5, 33, 1, 64, 96 images (the short last
     batch of an epoch, then full ones again) computes, at every step, exactly what a model created for that

@@ -1266,6 +1266,9 @@ extern "C" int vt_model_graph_capture_forward(vt_model *m, const float *x_dev, i
 
 extern "C" int vt_model_graph_launch(vt_model *m, vt_stream s) {
   if (!m || !m->graph_exec) return VT_EINVAL;
+  // an eager step's deferred attention backward (and the update behind it) may still be reading and writing the
+  // buffers, gradients and weights the captured step is about to overwrite
+  VTCHK(attention_join(m, (hipStream_t)s));
   HIPCHK(hipGraphLaunch(m->graph_exec, (hipStream_t)s));
   return 0;
 }

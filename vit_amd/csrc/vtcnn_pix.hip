@@ -153,9 +153,10 @@ __global__ __launch_bounds__(TPB) void k_proj_fwd(const float *__restrict__ conv
                                                   const float *__restrict__ pk, const float *__restrict__ Wd,
                                                   const float *__restrict__ bd, const float *__restrict__ piv,
                                                   float *__restrict__ projA, float *__restrict__ z,
-                                                  float *__restrict__ part_pn, int P, const BnFwdTail tail) {
+                                                  float *__restrict__ part_pn, int P, int sgroup, const BnFwdTail tail) {
   __shared__ float red[NW][2 * C2];
   const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, gq = lane >> 4;
+  if (sgroup > 0) st += (size_t)(n / sgroup) * 2 * C1;  // BatchNorm2D statistics of this image's mini-batch
   const float *__restrict__ mq = pk + (size_t)n * PK_STRIDE;
   const float *__restrict__ vv = mq + C1 * L;
   float amq[2], awd[2], av[4], pv[4];
@@ -297,11 +298,15 @@ __global__ __launch_bounds__(TPB) void k_proj_bwd(const float *__restrict__ du, 
                                                   const float *__restrict__ pk, const float *__restrict__ Wq,
                                                   const float *__restrict__ Wd, float *__restrict__ pdx,
                                                   float *__restrict__ dv_out, float *__restrict__ dk_out,
-                                                  float *__restrict__ gslab, int P) {
+                                                  float *__restrict__ gslab, int P, int sgroup) {
   __shared__ __attribute__((aligned(16))) float patch[NW][16 * PB_RS];
   __shared__ float sred[NW][3][256];
   __shared__ float sG[C1 * L];
   const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, gq = lane >> 4;
+  if (sgroup > 0) {  // statistics and backward coefficients of this image's mini-batch
+    st += (size_t)(n / sgroup) * 2 * C1;
+    coef += (size_t)(n / sgroup) * 2 * C2;
+  }
   const float *__restrict__ mq = pk + (size_t)n * PK_STRIDE;
   const float *__restrict__ vv = mq + C1 * L;
   const float *__restrict__ kk = vv + L * C2;
@@ -475,7 +480,7 @@ __global__ __launch_bounds__(TPB, 4) void k_tokenizer_fwd(const float *__restric
                                                        const float *__restrict__ W2, const float *__restrict__ b2,
                                                        float *__restrict__ tokA, float *__restrict__ tok_stat,
                                                        float *__restrict__ tok, float *__restrict__ part_n1, int P,
-                                                       const BnFwdTail tail) {
+                                                       int sgroup, const BnFwdTail tail) {
   __shared__ float redm[NW][L], reds[NW][L];
   __shared__ float sT[NW][256];
   __shared__ float sT0[L * C1];
@@ -487,6 +492,7 @@ __global__ __launch_bounds__(TPB, 4) void k_tokenizer_fwd(const float *__restric
   __shared__ float sx[16 * NW * TK_MAXT * TKX];
   const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, gq = lane >> 4;
   const int ntiles = (P + 15) >> 4;
+  if (sgroup > 0) st += (size_t)(n / sgroup) * 2 * C1;  // BatchNorm2D statistics of this image's mini-batch
   float bw[2];
 #pragma unroll
   for (int s = 0; s < 2; ++s) bw[s] = W1[(2 * gq + s) * L + j];  // B[channel 2g+s][token j]
@@ -628,9 +634,10 @@ __global__ __launch_bounds__(TPB) void k_tokenizer_bwd(const float *__restrict__
                                                        const float *__restrict__ tok_stat, const float *__restrict__ dT0,
                                                        const float *__restrict__ W1, const float *__restrict__ b1,
                                                        const float *__restrict__ pdx, float *__restrict__ dy,
-                                                       float *__restrict__ part, int P, const BnBwdTail tail) {
+                                                       float *__restrict__ part, int P, int sgroup, const BnBwdTail tail) {
   __shared__ float red[NW][2 * C1];
   const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, gq = lane >> 4;
+  if (sgroup > 0) st += (size_t)(n / sgroup) * 2 * C1;  // BatchNorm2D statistics of this image's mini-batch
   const float *__restrict__ dt = dT0 + (size_t)n * L * C1;
   const float *__restrict__ ts = tok_stat + (size_t)n * 2 * L;
   float adt[2], aw1[2], a1[4], a2[4], cmv[4], csv[4], hm[4], hi[4];
@@ -734,9 +741,10 @@ constexpr int CW_MAXCI = 4;
 template <bool W4>
 __global__ __launch_bounds__(TPB) void k_conv_wgrad(const float *__restrict__ X, const float *__restrict__ dy,
                                                     const float *__restrict__ coef, float *__restrict__ gslab, int Ci,
-                                                    int H, int W, int ld) {
+                                                    int H, int W, int ld, int sgroup) {
   __shared__ float sred[NW][CW_MAXCI][256];
   const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, gq = lane >> 4;
+  if (sgroup > 0) coef += (size_t)(n / sgroup) * 2 * C1;  // BatchNorm2D backward coefficients of this image's mini-batch
   const int P = H * W, ntiles = (P + 15) >> 4;
   const int kh = j / 3 - 1, kw = j % 3 - 1;  // tap offsets of lanes j < 9
   const float c0 = j < C1 ? coef[j] : 0.f, c1 = j < C1 ? coef[C1 + j] : 0.f;

@@ -43,6 +43,20 @@ class Layout:
         return arena[off:off + size].reshape(shape)
 
 
+def layout_sizes(d):
+    """(n_total, n_trainable) of the parameter arena for hyper-parameters d; mirrors include/vtcnn_layout.h
+    (every tensor padded to a multiple of 4 floats)."""
+    c2, c1, L, D, h, K, ci = d.vt_channels, d.vt_channels // 2, d.tokens, d.token_channels, d.heads, d.num_classes, d.image_channels
+    pad = lambda n: (n + 3) & ~3  # noqa: E731
+    hd = D // h
+    train = [c1 * ci * 9, c1, c1, c1] + [D * hd] * (3 * h) + [D * D, D * D, D, D * D, D, D, D, D, D,
+                                                               c1 * D, D * D, D * c2, c2, c2, c2, c1 * c2, c2,
+                                                               c2 * 196 * K, K]
+    rest = [c1 * L, L, c1 * D, D, c1, c1, D, D, D, D, c2, c2]
+    n_train = sum(pad(x) for x in train)
+    return n_train + sum(pad(x) for x in rest), n_train
+
+
 class VTCNN:
     """VTCNN model on one MI355X (reference model/vit_cnn.hpp:14-557).
 
@@ -79,17 +93,7 @@ class VTCNN:
             check(lib.vt_model_init_seed(self._h, int(seed)), "vt_model_init_seed")
 
     def _layout_sizes(self):
-        # mirrors include/vtcnn_layout.h: every tensor padded to a multiple of 4 floats
-        d = self.dims
-        c2, c1, L, D, h, K, ci = d.vt_channels, d.vt_channels // 2, d.tokens, d.token_channels, d.heads, d.num_classes, d.image_channels
-        pad = lambda n: (n + 3) & ~3
-        hd = D // h
-        train = [c1 * ci * 9, c1, c1, c1] + [D * hd] * (3 * h) + [D * D, D * D, D, D * D, D, D, D, D, D,
-                                                                   c1 * D, D * D, D * c2, c2, c2, c2, c1 * c2, c2,
-                                                                   c2 * 196 * K, K]
-        rest = [c1 * L, L, c1 * D, D, c1, c1, D, D, D, D, c2, c2]
-        n_train = sum(pad(x) for x in train)
-        return n_train + sum(pad(x) for x in rest), n_train
+        return layout_sizes(self.dims)
 
     def __del__(self):
         h = getattr(self, "_h", None)
