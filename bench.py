@@ -341,8 +341,9 @@ def main():
     ap.add_argument("--mode", choices=("train", "predict"), default="train",
                     help="train: the headline metric; predict: forward-only images/sec (eval mode)")
     ap.add_argument("--group", type=int, default=0,
-                    help="predict mode: the batch is consecutive reference mini-batches of this many images, "
-                         "each with its own BatchNorm1D statistics (what run.sh predict evaluates)")
+                    help="the batch is consecutive reference mini-batches of this many images, each with its own BatchNorm "
+                         "statistics: predict mode = what run.sh predict evaluates; train mode = that many independent "
+                         "mini-batches trained side by side with one summed update (vt_model_train_step_grouped)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step as one HIP graph (single GPU, train mode; for small batches)")
     ap.add_argument("--overlap", type=int, default=0,
@@ -440,7 +441,7 @@ def main():
     if a.mode == "predict":
         m.set_training(False)
 
-    use_graph = a.graph and world == 1 and (a.mode == "train" or a.group == 0)
+    use_graph = a.graph and world == 1 and a.group == 0
     if use_graph:
         xbuf, ybuf = torch.empty_like(xs[0]), torch.empty_like(ys[0])
         if a.mode == "train":
@@ -458,6 +459,13 @@ def main():
             m.forward_grouped(xs[i % nb], a.group)
         elif a.mode == "predict":
             m.forward(xs[i % nb])
+        elif a.group > 0 and world == 1 and not a.exchange_alone:
+            m.train_step_grouped(xs[i % nb], ys[i % nb], a.group, float(a.group))  # divisor (B / group) * group = B
+        elif a.group > 0:  # grouped forward / backward, the ranks' sums exchanged, one update
+            m.forward_grouped(xs[i % nb], a.group)
+            m.backward(ys[i % nb])
+            dp.all_reduce_grads()
+            m.update_weights(float(B) * world)
         else:
             dp.train_step(xs[i % nb], ys[i % nb], B)
 
@@ -610,7 +618,7 @@ def main():
                                    "mini-batch %d per GPU, fp32, seed-42 reference init" % (
                                        {"blood": "BloodMNIST"}.get(a.shape, a.shape), dims.image_channels, dims.input_dim,
                                        dims.input_dim, a.classes, B),
-                       "hip_graph": bool(use_graph), "two_stream_backward": bool(a.concurrent) and not generic, "deferred_attention_backward": deferred, "statistics_group": a.group if a.mode == "predict" else 0, "per_gpu_batch": B, "global_batch": B * joined, "parallelism": "dp%d" % joined,
+                       "hip_graph": bool(use_graph), "two_stream_backward": bool(a.concurrent) and not generic, "deferred_attention_backward": deferred, "statistics_group": a.group, "per_gpu_batch": B, "global_batch": B * joined, "parallelism": "dp%d" % joined,
                        "distinct_devices": distinct,
                        "exchange_overlapped": bool(dp.overlap and a.mode == "train" and not use_graph),
                        "grad_allreduce_floats": int(m.layout.n_trainable) if world > 1 else 0},

@@ -147,12 +147,16 @@ int vt_model_backward(vt_model *m, const int *d_labels, vt_stream s);
 int vt_model_backward_main(vt_model *m, const int *d_labels, vt_stream s);
 int vt_model_backward_attention(vt_model *m, float *d_grads_out, vt_stream s);
 int vt_model_attention_range(const vt_model *m, int *first, int *count);
-/* Evaluation sweep in one launch set (eval mode only): the n images are consecutive mini-batches
- * of `group` images (a multiple of 4; the last batch may be short), each normalised with its own
- * BatchNorm1D statistics exactly as Trainer::evaluate / evaluate_test see them batch after batch
- * (utils/trainer.hpp:104-127, 172-197); the running statistics end as after that loop.  The
- * probabilities equal those of calling vt_model_forward on each batch up to the rounding of the
- * statistics (1e-6 relative).  No backward. */
+/* Several reference mini-batches in one launch set: the n images are consecutive mini-batches of `group` images (a
+ * multiple of 4), each normalised with its own batch statistics.
+ * Eval mode: the sweep of Trainer::evaluate / evaluate_test (utils/trainer.hpp:104-127, 172-197): BatchNorm2D on the
+ * running statistics, the three BatchNorm1D layers on each batch's own; the last batch may be short; the running
+ * statistics end as after that loop; no backward.  The probabilities equal those of calling vt_model_forward on each
+ * batch up to the rounding of the statistics (1e-6 relative).
+ * Training mode (headline shape, 28x28 inputs, n a multiple of group): the forward half of vt_model_train_step_grouped;
+ * BatchNorm2D, too, takes each mini-batch's own statistics, the running statistics receive the groups' updates one after
+ * another in order, and vt_model_backward (or the two-call form) afterwards leaves the SUM of the mini-batches'
+ * gradients in the gradient arena. */
 int vt_model_forward_grouped(vt_model *m, const float *d_images, int n, int group, float *d_probs, vt_stream s);
 /* VTCNN::update_weights + SGD::update + zero_grad (model/vit_cnn.hpp:244-260,
  * utils/optimizer.hpp:22-28):  g <- g * (1/divisor);  w <- w - g * lr  over the trainable region.
@@ -165,6 +169,18 @@ int vt_model_sgd_step(vt_model *m, float lr, float divisor, vt_stream s);
  * who must exchange gradients between backward and update, keeps the separate calls. */
 int vt_model_train_step(vt_model *m, const float *d_images, int n, const int *d_labels, float lr, float divisor,
                         float *d_probs, vt_stream s);
+/* Data-parallel training on one GPU ("virtual ranks"; no counterpart in the reference, which trains one mini-batch at a
+ * time, utils/trainer.hpp:39-54).  The n images are n / group independent reference mini-batches of `group` images (group
+ * a multiple of 4, n a multiple of group; headline shape, 28x28 inputs): each is forwarded and back-propagated exactly as
+ * vt_model_train_step would do it alone from the same weights -- its own statistics in all four BatchNorm layers, its
+ * own attention groups of `group` consecutive token rows, its own row-0 term in the BatchNorm backward -- in ONE launch
+ * set; the gradients of all mini-batches are summed and one update w <- w - lr * sum / divisor is applied, which with
+ * divisor = (n / group) * batch_size is the update of n / group data-parallel ranks (utils/trainer.hpp:53 per rank).
+ * At the reference's batch of 32 a step is bound by its chain of dependent launches, not by arithmetic: 32 mini-batches
+ * side by side cost about what one costs.  Running statistics are updated in group order.  group >= n is
+ * vt_model_train_step. */
+int vt_model_train_step_grouped(vt_model *m, const float *d_images, int n, int group, const int *d_labels, float lr,
+                                float divisor, float *d_probs, vt_stream s);
 /* One fused Adam pass over the trainable region (g scaled by 1/divisor first, as update_weights
  * scales it; bias-corrected moments; gradients cleared), the moments kept by the model and the step
  * count advanced by every call.  The reference trains with SGD only (utils/optimizer.hpp:14-28):
@@ -386,6 +402,14 @@ int vt_fc_wgrad_static(const float *pooled, const float *d_logits, float *gw, fl
  * delta_in = delta * scale + shift, including the reference's row-0 variance term. */
 int vt_bn_bwd_finalize(const float *part, int nblocks, int C, long rows_total, const float *gamma, const float *stat,
                        const float *in_row0, float *ggamma, float *gbeta, float *coef, vt_stream s);
+/* The same reduction for consecutive groups of blocks_per_group partial blocks (several independent mini-batches side
+ * by side, each normalised with its own statistics; the last group may be short): group g covers rows
+ * [g*rows_per_group, ...) of the layer input `in` [rows_total, C] (its first row supplies the row-0 term), takes
+ * stat[g][2][C] and writes coef[g][2][C] and gpart[g][2][C] = (grad gamma | grad beta) of that mini-batch alone; the
+ * caller adds the groups' gradients (vt_reduce_rows over gpart). */
+int vt_bn_bwd_finalize_grouped(const float *part, int nblocks, int blocks_per_group, int C, long rows_per_group,
+                               long rows_total, const float *gamma, const float *stat, const float *in, float *gpart,
+                               float *coef, vt_stream s);
 /* ProjectorLayer::backward, pixel side (projector_layer.hpp:133-184, 204-213).  The attention map
  * is recomputed from conv_out and the per-sample token block pk, not read back. */
 int vt_projector_bwd(const float *du, const float *pn_coef, const float *conv_out, const float *bn_stat,

@@ -50,6 +50,7 @@ SIGNATURES = {
     "vt_model_is_fused": (i, [p]),
     "vt_model_set_fused_reductions": (i, [p, i]),
     "vt_model_train_step": (i, [p, p, i, p, C.c_float, C.c_float, p, p]),
+    "vt_model_train_step_grouped": (i, [p, p, i, i, p, C.c_float, C.c_float, p, p]),
     "vt_model_init_seed": (i, [p, u]),
     "vt_model_set_arena": (i, [p, p]),
     "vt_model_get_arena": (i, [p, p]),
@@ -118,6 +119,7 @@ SIGNATURES = {
     "vt_dp_allreduce_rank_async": (i, [p, i, p, l, l, p]),
     "vt_dp_wait": (i, [p]),
     "vt_bn_bwd_finalize": (i, [p, i, i, l, p, p, p, p, p, p, p]),
+    "vt_bn_bwd_finalize_grouped": (i, [p, i, i, i, l, l, p, p, p, p, p, p]),
     "vt_projector_bwd": (i, [p] * 13 + [i, i, p]),
     "vt_projector_bwd_windows": (i, [p] * 13 + [i, i, p]),
     "vt_head_bwd_windows_blocks": (i, [i]),

@@ -147,13 +147,29 @@ __global__ __launch_bounds__(1024) void k_reduce_multi_sgd(const ReduceBatch bat
 // (tensor_cpu.hpp:1050-1084).  coef = (scale, shift) with delta_in = delta*scale + shift.
 // ---------------------------------------------------------------------------------------------
 // One workgroup per channel; a thread takes every FIN_T-th block with eight loads in flight.
+// Grouped form (blockIdx.y = statistics group, several independent mini-batches side by side): group g owns blocks
+// [g*nbpg, (g+1)*nbpg) and rows [g*rows_group, ...); it takes stat[g][2C], row 0 of ITS rows, writes coef[g][2C] and,
+// instead of the gradient arena, gpart[g][2C] = (grad gamma | grad beta) of its own mini-batch; the caller sums those
+// over the groups.  gpart == nullptr (one group): the gradients go to ggamma / gbeta.
 constexpr int FIN_T = 256;
-__global__ __launch_bounds__(FIN_T) void k_bn_bwd_finalize(const float *__restrict__ part, int nb, int C, long rows_total,
+__global__ __launch_bounds__(FIN_T) void k_bn_bwd_finalize(const float *__restrict__ part, int nb_total, int nbpg, int C,
+                                                           long rows_group, long rows_total,
                                                            const float *__restrict__ gamma, const float *__restrict__ stat,
                                                            const float *__restrict__ in_row0, float *__restrict__ ggamma,
-                                                           float *__restrict__ gbeta, float *__restrict__ coef) {
+                                                           float *__restrict__ gbeta, float *__restrict__ coef,
+                                                           float *__restrict__ gpart) {
   __shared__ double sh[2][FIN_T / 64];
-  const int tid = threadIdx.x, c = blockIdx.x;
+  const int tid = threadIdx.x, c = blockIdx.x, grp = blockIdx.y;
+  part += (size_t)grp * nbpg * 2 * C;
+  stat += (size_t)grp * 2 * C;
+  coef += (size_t)grp * 2 * C;
+  in_row0 += (size_t)grp * rows_group * C;
+  const int nb = min(nbpg, nb_total - grp * nbpg);
+  rows_total = min(rows_group, rows_total - (long)grp * rows_group);
+  if (gpart) {
+    ggamma = gpart + (size_t)grp * 2 * C;
+    gbeta = ggamma + C;
+  }
   // operands of the closing arithmetic, requested before the partial loads so that their round trip is hidden
   float gm = 0.f, mean = 0.f, inv = 0.f, x0 = 0.f;
   if (tid == 0) {
@@ -370,8 +386,21 @@ extern "C" int vt_bn_bwd_finalize(const float *part, int nblocks, int C, long ro
                                   const float *stat, const float *in_row0, float *ggamma, float *gbeta, float *coef,
                                   vt_stream s) {
   if (C < 1 || C > 1024 || nblocks < 1 || rows_total < 1) return VT_EUNSUPPORTED;
-  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(C), dim3(FIN_T), 0, (hipStream_t)s, part, nblocks, C, rows_total, gamma,
-                     stat, in_row0, ggamma, gbeta, coef);
+  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(C, 1), dim3(FIN_T), 0, (hipStream_t)s, part, nblocks, nblocks, C, rows_total,
+                     rows_total, gamma, stat, in_row0, ggamma, gbeta, coef, (float *)nullptr);
+  VT_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int vt_bn_bwd_finalize_grouped(const float *part, int nblocks, int blocks_per_group, int C, long rows_per_group,
+                                          long rows_total, const float *gamma, const float *stat, const float *in,
+                                          float *gpart, float *coef, vt_stream s) {
+  if (C < 1 || C > 1024 || nblocks < 1 || blocks_per_group < 1 || rows_per_group < 1 || rows_total < 1 || !gpart)
+    return VT_EUNSUPPORTED;
+  const int groups = (nblocks + blocks_per_group - 1) / blocks_per_group;
+  if ((long)(groups - 1) * rows_per_group >= rows_total) return VT_EINVAL;
+  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(C, groups), dim3(FIN_T), 0, (hipStream_t)s, part, nblocks, blocks_per_group, C,
+                     rows_per_group, rows_total, gamma, stat, in, (float *)nullptr, (float *)nullptr, coef, gpart);
   VT_CHECK_LAUNCH();
   return 0;
 }

@@ -312,7 +312,7 @@ __global__ __launch_bounds__(TPB) void k_head_bwd_win(const float *__restrict__ 
                                                       const float *__restrict__ st, const float *__restrict__ g,
                                                       const float *__restrict__ b, float *__restrict__ dlogits,
                                                       float *__restrict__ dpair, float *__restrict__ part, int N, int nb,
-                                                      const BnBwdTail tail) {
+                                                      int sgroup, const BnBwdTail tail) {
   constexpr int W = 28, P = 784, Q = C2 * 196;
   __shared__ __attribute__((aligned(16))) float sbin[HW_B1 + TPB * HW_RS];  // [sum d | sum d*x_hat][thread][channel]
   __shared__ float sred[8][2 * C2];
@@ -320,6 +320,7 @@ __global__ __launch_bounds__(TPB) void k_head_bwd_win(const float *__restrict__ 
   const int f = blockIdx.x * TPB + tid, fc = min(f, Q - 1);
   const bool okf = f < Q;
   const int n0 = blockIdx.y * nb, nn = min(nb, N - n0);
+  if (sgroup > 0) st += (size_t)(n0 / sgroup) * 2 * C2;  // a chunk never straddles two statistics groups
   // every load of the workgroup is requested before anything waits: the window maxima and slot bytes of all its
   // images (one trip to memory for the whole chunk) and the weight row
   float mv[HW_NB];
@@ -389,9 +390,11 @@ __global__ __launch_bounds__(TPB) void k_head_bwd_win(const float *__restrict__ 
     const int F = F00 + (q >> 1) * W + (q & 1), c = cq[q];
     const float gq = gq4[q], bq = bq4[q];
     float ax;
-    if (gq != 0.f) {
+    // x_hat from the post-BatchNorm maximum is (mv - beta) / gamma: its rounding error is eps * |beta| / |gamma|, so a
+    // gamma that is small against beta (or zero) takes x_hat from z instead
+    if (fabsf(gq) >= 1e-3f * fmaxf(1.0f, fabsf(bq))) {
       ax = (am[q] - bq * ad[q]) / gq;
-    } else {  // the BatchNorm output no longer determines x_hat: take it from z (never in practice)
+    } else {
       ax = 0.f;
       for (int u = 0; u < nn; ++u) {
         const size_t o = (size_t)(n0 + u) * Q + fc;
@@ -498,26 +501,40 @@ extern "C" int vt_head_bwd(const float *probs, const int *labels, const float *w
 
 // Images per workgroup and workgroups of k_head_bwd_win for a mini-batch of N: about 64 chunks of images at
 // most HW_NB long, times the 13 window blocks.
-static int head_win_chunk(int N) { return std::max(1, std::min(HW_NB, N / 64)); }
+// With statistics groups of sgroup images a chunk must not straddle two groups: the chunk length divides sgroup.
+static int head_win_chunk(int N, int sgroup = 0) {
+  int nb = std::max(1, std::min(HW_NB, N / 64));
+  if (sgroup > 0) {
+    nb = std::min(nb, sgroup);
+    while (sgroup % nb != 0) --nb;
+  }
+  return nb;
+}
 extern "C" int vt_head_bwd_windows_blocks(int N) {
   if (N < 1) return VT_EINVAL;
   const int nb = head_win_chunk(N);
   return ((C2 * 196 + TPB - 1) / TPB) * ((N + nb - 1) / nb);
 }
+// partial records of the grouped launch: total, and per full statistics group
+int vt::head_bwd_windows_blocks_grouped(int N, int sgroup, int *per_group) {
+  const int nb = head_win_chunk(N, sgroup), wb = (C2 * 196 + TPB - 1) / TPB;
+  if (per_group) *per_group = sgroup > 0 ? wb * (sgroup / nb) : wb * ((N + nb - 1) / nb);
+  return wb * ((N + nb - 1) / nb);
+}
 int vt::head_bwd_windows_tail(const float *probs, const int *labels, const float *wfc, const unsigned char *pool_idx,
                               const float *pooled, const float *z, const float *pn_stat, const float *pn_gamma,
                               const float *pn_beta, float *d_logits, float *dpair, float *part, int N, int H, int K,
-                              const BnBwdTail &tail, hipStream_t s) {
-  if (N < 1 || H != 28 || K < 1 || K > KMAX) return VT_EUNSUPPORTED;
-  const int nb = head_win_chunk(N);
+                              const BnBwdTail &tail, hipStream_t s, int sgroup) {
+  if (N < 1 || H != 28 || K < 1 || K > KMAX || sgroup < 0 || (sgroup > 0 && tail.ticket)) return VT_EUNSUPPORTED;
+  const int nb = head_win_chunk(N, sgroup);
   const dim3 grid((C2 * 196 + TPB - 1) / TPB, (N + nb - 1) / nb);
 #define CALL(KK)                                                                                                        \
   if (tail.ticket)                                                                                                      \
     hipLaunchKernelGGL((k_head_bwd_win<KK, true>), grid, dim3(TPB), 0, s, probs, labels, wfc, pool_idx, pooled, z, pn_stat, \
-                       pn_gamma, pn_beta, d_logits, dpair, part, N, nb, tail);                                          \
+                       pn_gamma, pn_beta, d_logits, dpair, part, N, nb, 0, tail);                                       \
   else                                                                                                                  \
     hipLaunchKernelGGL((k_head_bwd_win<KK, false>), grid, dim3(TPB), 0, s, probs, labels, wfc, pool_idx, pooled, z, pn_stat, \
-                       pn_gamma, pn_beta, d_logits, dpair, part, N, nb, tail)
+                       pn_gamma, pn_beta, d_logits, dpair, part, N, nb, sgroup, tail)
   VT_FOR_K(CALL)
 #undef CALL
   VT_CHECK_LAUNCH();
@@ -528,7 +545,7 @@ extern "C" int vt_head_bwd_windows(const float *probs, const int *labels, const 
                                    const float *pn_beta, float *d_logits, float *dpair, float *part, int N, int H, int K,
                                    vt_stream s) {
   return head_bwd_windows_tail(probs, labels, wfc, pool_idx, pooled, z, pn_stat, pn_gamma, pn_beta, d_logits, dpair, part, N, H, K,
-                               BnBwdTail{}, (hipStream_t)s);
+                               BnBwdTail{}, (hipStream_t)s, 0);
 }
 
 extern "C" int vt_head_expand_windows(const float *dpair, float *du, int N, int H, vt_stream s) {

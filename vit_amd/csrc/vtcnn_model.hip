@@ -66,7 +66,9 @@ struct vt_model {
   float *conv, *tokA = nullptr, *tokstat, *tok, *a, *hdn, *s2, *o, *pk, *projA = nullptr, *z, *pooled, *logits, *probs;
   unsigned char *pool_idx;
   float *part, *part_side = nullptr, *stat_bn, *stat_n1, *stat_n2, *stat_pn, *batch_mv;
-  bool last_grouped = false;  // the last forward was a grouped one: no backward for it
+  bool last_grouped = false;  // the last forward was a grouped evaluation sweep: no backward for it
+  int last_group = 0;         // images per statistics group of the last (training-mode) forward; 0 = one mini-batch
+  float *gpart_pn = nullptr, *gpart_n2 = nullptr, *gpart_n1 = nullptr, *gpart_bn = nullptr;  // per-group BatchNorm gradients
   bool attention_pending = false;  // vt_model_backward_main ran, vt_model_backward_attention has not yet
   const float *last_images = nullptr;
   float *last_probs = nullptr;  // where the last forward left the probabilities (the caller's buffer or m->probs)
@@ -203,11 +205,13 @@ extern "C" int vt_model_create(const vt_dims *dims, int max_batch, int device, f
   const size_t nrb = (NL + RB - 1) / RB;
   // partial-sum records: one per image or row block, or the head backward's window-major count, which is not
   // monotonic in the batch size (at most 13 * 128 workgroups for any batch up to N)
-  rc |= dalloc(m, &m->part, std::max<size_t>(std::max(N, nrb) * 64, std::min<size_t>(13 * N, 13 * 128) * 2 * C2));
+  // (with statistics groups a chunk of the head backward divides the group: at most N/4 + 1 chunks of 13 records)
+  rc |= dalloc(m, &m->part, std::max<size_t>(std::max<size_t>(std::max(N, nrb) * 64, std::min<size_t>(13 * N, 13 * 128) * 2 * C2),
+                                              (size_t)13 * (N / 4 + 2) * 2 * C2));
   rc |= dalloc(m, &m->part_side, std::max(N, nrb) * 64);
-  rc |= dalloc(m, &m->stat_bn, 2 * C1, "stat.bn");
   // one (mean, inv) record per statistics group: grouped forward runs up to maxN/4 groups
   const size_t max_groups = N / 4 + 1;
+  rc |= dalloc(m, &m->stat_bn, max_groups * 2 * C1, "stat.bn");
   rc |= dalloc(m, &m->stat_n1, max_groups * 2 * D, "stat.norm1");
   rc |= dalloc(m, &m->stat_n2, max_groups * 2 * D, "stat.norm2");
   rc |= dalloc(m, &m->stat_pn, max_groups * 2 * C2, "stat.proj.norm");
@@ -240,11 +244,16 @@ extern "C" int vt_model_create(const vt_dims *dims, int max_batch, int device, f
   rc |= dalloc(m, &m->sc_ffn, nrb * 2112);
   rc |= dalloc(m, &m->sc_pt, nrb * 1552);
   rc |= dalloc(m, &m->sc_fc, ((N + 127) / 128) * (Q * K + K));
-  rc |= dalloc(m, &m->sc_mha, (size_t)HEADS * 4 * (2 * D + 3) * NL + (size_t)HEADS * nrb * 1536 + (size_t)L * D);
-  rc |= dalloc(m, &m->coef_pn, 2 * C2, "coef.proj.norm");
-  rc |= dalloc(m, &m->coef_n2, 2 * D, "coef.norm2");
-  rc |= dalloc(m, &m->coef_n1, 2 * D, "coef.norm1");
-  rc |= dalloc(m, &m->coef_bn, 2 * C1, "coef.bn");
+  // (the attention groups of a grouped step: L per statistics group, one [D] pivot each)
+  rc |= dalloc(m, &m->sc_mha, (size_t)HEADS * 4 * (2 * D + 3) * NL + (size_t)HEADS * nrb * 1536 + (size_t)L * D * max_groups);
+  rc |= dalloc(m, &m->coef_pn, max_groups * 2 * C2, "coef.proj.norm");
+  rc |= dalloc(m, &m->coef_n2, max_groups * 2 * D, "coef.norm2");
+  rc |= dalloc(m, &m->coef_n1, max_groups * 2 * D, "coef.norm1");
+  rc |= dalloc(m, &m->coef_bn, max_groups * 2 * C1, "coef.bn");
+  rc |= dalloc(m, &m->gpart_pn, max_groups * 2 * C2);
+  rc |= dalloc(m, &m->gpart_n2, max_groups * 2 * D);
+  rc |= dalloc(m, &m->gpart_n1, max_groups * 2 * D);
+  rc |= dalloc(m, &m->gpart_bn, max_groups * 2 * C1);
   rc |= dalloc(m, &m->loss_buf, 4);
   if (rc == 0 && (hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking) != hipSuccess ||
                   hipEventCreateWithFlags(&m->ev_rows, hipEventDisableTiming) != hipSuccess ||
@@ -860,7 +869,10 @@ extern "C" int vt_model_attention_join(vt_model *m, vt_stream s) {
 // batch after batch (utils/trainer.hpp:104-127), at one launch set per sweep instead of one per batch.
 static int forward_impl(vt_model *m, const float *d_images, int n, int group, float *d_probs, vt_stream s) {
   if (!m || !d_images || n < 1 || n > m->maxN) return VT_EINVAL;
-  if (group > 0 && (m->training || group % 4 != 0)) return VT_EUNSUPPORTED;
+  if (group > 0 && group % 4 != 0) return VT_EUNSUPPORTED;
+  // training mode: the groups are independent mini-batches that will be trained side by side (every BatchNorm layer,
+  // BatchNorm2D included, normalises each with its own batch statistics), and all of them must be full
+  if (group > 0 && group < n && m->training && (n % group != 0 || m->d.input_dim != 28 || m->gen)) return VT_EUNSUPPORTED;
   if (m->gen) {
     if (group > 0) return VT_EUNSUPPORTED;
     m->lastN = n;
@@ -884,7 +896,9 @@ static int forward_impl(vt_model *m, const float *d_images, int n, int group, fl
   const int nrb = (int)((NL + RB - 1) / RB);
   m->lastN = n;
   m->last_images = d_images;
-  m->last_grouped = group > 0;
+  m->last_grouped = group > 0 && !m->training;
+  m->last_group = m->training ? group : 0;
+  const int bn_group = m->last_group;  // BatchNorm2D: per-group batch statistics in training mode, running ones otherwise
   // conv + BatchNorm2D statistics (training: batch stats; eval: running stats)
   // With m->tails the last workgroup of each producer kernel closes the statistic it feeds (vtcnn_tail.h) and the
   // separate finalize launch is skipped; grouped sweeps keep the launches (their statistics are per group).
@@ -905,7 +919,10 @@ static int forward_impl(vt_model *m, const float *d_images, int n, int group, fl
   STEP("conv3x3_fwd", conv3x3_fwd_tail(d_images, m->P_("conv.W"), m->P_("conv.b"), m->conv, m->training ? m->part : nullptr, n, Ci, H, H,
                                        fwd_tail(0, "bn.running_mean", "bn.running_var", m->stat_bn, P, (long)n * P), hs));
   if (m->training && tails) {
-  } else if (m->training)
+  } else if (m->training && bn_group > 0)
+    STEP("bn_stats_finalize", vt_bn_stats_finalize_grouped(m->part, n, bn_group, C1, P, (long)n * P, m->P_("bn.running_mean"), m->P_("bn.running_var"),
+                               m->stat_bn, m->batch_mv, s));
+  else if (m->training)
     STEP("bn_stats_finalize", vt_bn_stats_finalize(m->part, n, C1, P, (long)n * P, m->P_("bn.running_mean"), m->P_("bn.running_var"), m->stat_bn, s));
   else
     STEP("bn_stats_eval", vt_bn_stats_eval(m->P_("bn.running_mean"), m->P_("bn.running_var"), C1, m->stat_bn, s));
@@ -913,7 +930,7 @@ static int forward_impl(vt_model *m, const float *d_images, int n, int group, fl
   STEP("tokenizer_fwd", tokenizer_fwd_tail(m->conv, m->stat_bn, m->P_("bn.gamma"), m->P_("bn.beta"), m->P_("tok.linear1.W"),
                          m->P_("tok.linear1.b"), m->P_("tok.linear2.W"), m->P_("tok.linear2.b"), m->keep_internals ? m->tokA : nullptr, m->tokstat,
                          m->tok, m->part, n, P,
-                         fwd_tail(1, "norm1.running_mean", "norm1.running_var", m->stat_n1, L, NL), hs));
+                         fwd_tail(1, "norm1.running_mean", "norm1.running_var", m->stat_n1, L, NL), hs, bn_group));
   if (tails) {
   } else if (group > 0)
     STEP("bn_stats_finalize", vt_bn_stats_finalize_grouped(m->part, n, group, D, L, NL, m->P_("norm1.running_mean"), m->P_("norm1.running_var"), m->stat_n1, m->batch_mv, s));
@@ -937,7 +954,7 @@ static int forward_impl(vt_model *m, const float *d_images, int n, int group, fl
   STEP("projector_fwd", projector_fwd_tail(m->conv, m->stat_bn, m->P_("bn.gamma"), m->P_("bn.beta"), m->pk, m->P_("proj.downsample.W"),
                          m->P_("proj.downsample.b"), m->P_("proj.norm.running_mean"),
                          m->keep_internals ? m->projA : nullptr, m->z, m->part, n, P,
-                         fwd_tail(3, "proj.norm.running_mean", "proj.norm.running_var", m->stat_pn, P, (long)n * P), hs));
+                         fwd_tail(3, "proj.norm.running_mean", "proj.norm.running_var", m->stat_pn, P, (long)n * P), hs, bn_group));
   if (tails) {
   } else if (group > 0)
     STEP("bn_stats_finalize", vt_bn_stats_finalize_grouped(m->part, n, group, C2, P, (long)n * P, m->P_("proj.norm.running_mean"), m->P_("proj.norm.running_var"),
@@ -996,8 +1013,22 @@ static int backward_main(vt_model *m, const int *d_labels, vt_stream s) {
     const char *e = getenv("VT_HEAD_DENSE");
     return e && *e && *e != '0';
   }();
-  const bool windows = H == 28 && !dense_delta;
+  // statistics groups of the last forward (independent mini-batches side by side): sg images, gr token rows each
+  const int sg = m->last_group;
+  const long gr = (long)sg * L;
+  const int ngroups = sg > 0 ? n / sg : 1;
+  const bool windows = H == 28 && (!dense_delta || sg > 0);
+  if (sg > 0 && !windows) return VT_EUNSUPPORTED;
   m->du_windows = windows;
+  // closes one BatchNorm backward reduction: one finalize launch, per group where the step has groups (the groups'
+  // gamma / beta gradients are then added up by a queued slab reduction)
+  auto bn_bwd_close_launch = [&](vt_stream st, const float *part, int nblocks, int blocks_per_group, int C, long rows_group,
+                                 long rows_total, const char *gamma, const char *beta, const float *stat, const float *in,
+                                 float *gpart, float *coef) -> int {
+    if (sg == 0) return vt_bn_bwd_finalize(part, nblocks, C, rows_total, m->P_(gamma), stat, in, m->G_(gamma), m->G_(beta), coef, st);
+    VTCHK(vt_bn_bwd_finalize_grouped(part, nblocks, blocks_per_group, C, rows_group, rows_total, m->P_(gamma), stat, in, gpart, coef, st));
+    return vt_reduce_rows(gpart, ngroups, 2 * C, 2 * C, m->G_(gamma), st);  // queued; gamma | beta are neighbours in the arena
+  };
   auto bwd_tail = [&](int site, const char *gamma, const float *stat, const float *in_row0, float *coef, long rows_total) {
     BnBwdTail t;
     t.ticket = m->tickets + site * TAIL_WORDS;
@@ -1010,25 +1041,28 @@ static int backward_main(vt_model *m, const int *d_labels, vt_stream s) {
     t.rows_total = rows_total;
     return t;
   };
-  const bool tails = m->tails;
+  const bool tails = m->tails && sg == 0;
   if (windows && tails)
     STEP("head_bwd", head_bwd_windows_tail(m->last_probs, d_labels, m->P_("fc.W"), m->pool_idx, m->pooled, m->z, m->stat_pn,
                       m->P_("proj.norm.gamma"), m->P_("proj.norm.beta"), m->dlogits, m->dpair, m->part, n, H, K,
                       bwd_tail(4, "proj.norm.gamma", m->stat_pn, m->z, m->coef_pn, (long)n * P), hs));
   else if (windows)
-    STEP("head_bwd", vt_head_bwd_windows(m->last_probs, d_labels, m->P_("fc.W"), m->pool_idx, m->pooled, m->z, m->stat_pn,
-                      m->P_("proj.norm.gamma"), m->P_("proj.norm.beta"), m->dlogits, m->dpair, m->part, n, H, K, s));
+    STEP("head_bwd", head_bwd_windows_tail(m->last_probs, d_labels, m->P_("fc.W"), m->pool_idx, m->pooled, m->z, m->stat_pn,
+                      m->P_("proj.norm.gamma"), m->P_("proj.norm.beta"), m->dlogits, m->dpair, m->part, n, H, K, BnBwdTail{}, hs, sg));
   else
     STEP("head_bwd", vt_head_bwd(m->last_probs, d_labels, m->P_("fc.W"), m->pool_idx, m->z, m->stat_pn, m->P_("proj.norm.gamma"),
                       m->P_("proj.norm.beta"), m->dlogits, m->du, m->part, n, H, K, s));
-  if (!(windows && tails))
-    STEP("bn_bwd_finalize", vt_bn_bwd_finalize(m->part, windows ? vt_head_bwd_windows_blocks(n) : n, C2, (long)n * P, m->P_("proj.norm.gamma"), m->stat_pn, m->z,
-                           m->G_("proj.norm.gamma"), m->G_("proj.norm.beta"), m->coef_pn, s));
+  if (!(windows && tails)) {
+    int per_group = 0;
+    const int nblk = windows ? head_bwd_windows_blocks_grouped(n, sg, &per_group) : n;
+    STEP("bn_bwd_finalize", bn_bwd_close_launch(s, m->part, nblk, per_group, C2, (long)sg * P, (long)n * P, "proj.norm.gamma", "proj.norm.beta",
+                                                m->stat_pn, m->z, m->gpart_pn, m->coef_pn));
+  }
   // projector
   if (windows)
-    STEP("projector_bwd", vt_projector_bwd_windows(m->dpair, m->coef_pn, m->conv, m->stat_bn, m->P_("bn.gamma"),
+    STEP("projector_bwd", projector_bwd_grouped(m->dpair, 1, m->coef_pn, m->conv, m->stat_bn, m->P_("bn.gamma"),
                            m->P_("bn.beta"), m->pk, m->P_("proj.linear1.W"), m->P_("proj.downsample.W"), m->pdx, m->dv, m->dk,
-                           m->gslab, n, P, s));
+                           m->gslab, n, P, sg, hs));
   else
     STEP("projector_bwd", vt_projector_bwd(m->du, m->coef_pn, m->conv, m->stat_bn, m->P_("bn.gamma"), m->P_("bn.beta"), m->pk,
                            m->P_("proj.linear1.W"), m->P_("proj.downsample.W"), m->pdx, m->dv, m->dk, m->gslab, n, P, s));
@@ -1046,7 +1080,7 @@ static int backward_main(vt_model *m, const int *d_labels, vt_stream s) {
   }
   STEP("projector_tokens_bwd", projector_tokens_bwd_transformer_a_tail(m->o, m->dv, m->dk, m->P_("proj.linear3.W"), m->P_("proj.linear2.W"),
                                 m->pdt, m->G_("proj.linear2.W"), m->sc_pt, m->s2, m->stat_n2, m->P_("tok.linear2.W"), m->part,
-                                m->dT0, NL, tails ? bwd_tail(5, "norm2.gamma", m->stat_n2, m->s2, m->coef_n2, NL) : BnBwdTail{}, hs));
+                                m->dT0, NL, tails ? bwd_tail(5, "norm2.gamma", m->stat_n2, m->s2, m->coef_n2, NL) : BnBwdTail{}, hs, gr));
   if (fork) {
     const bool signalled = !capturing && m->signal_launches && vt::g_stop_event == nullptr;
     vt::g_stop_event = nullptr;
@@ -1058,11 +1092,11 @@ static int backward_main(vt_model *m, const int *d_labels, vt_stream s) {
   // partial sums of their own (norm2's are still waiting in m->part for their finalize)
   STEP_ON("tokenizer_bwd", t, tokenizer_bwd_tail(m->conv, m->stat_bn, m->P_("bn.gamma"), m->P_("bn.beta"), m->tokstat, m->dT0,
                          m->P_("tok.linear1.W"), m->P_("tok.linear1.b"), m->pdx, m->dy, m->part_side, n, P,
-                         tails ? bwd_tail(6, "bn.gamma", m->stat_bn, m->conv, m->coef_bn, (long)n * P) : BnBwdTail{}, (hipStream_t)t));
+                         tails ? bwd_tail(6, "bn.gamma", m->stat_bn, m->conv, m->coef_bn, (long)n * P) : BnBwdTail{}, (hipStream_t)t, sg));
   if (!tails)
-    STEP_ON("bn_bwd_finalize", t, vt_bn_bwd_finalize(m->part_side, n, C1, (long)n * P, m->P_("bn.gamma"), m->stat_bn, m->conv,
-                           m->G_("bn.gamma"), m->G_("bn.beta"), m->coef_bn, t));
-  STEP_ON("conv3x3_wgrad", t, vt_conv3x3_wgrad(m->last_images, m->dy, m->coef_bn, m->gslab_conv, n, Ci, H, H, t));
+    STEP_ON("bn_bwd_finalize", t, bn_bwd_close_launch(t, m->part_side, n, sg, C1, (long)sg * P, (long)n * P, "bn.gamma", "bn.beta", m->stat_bn,
+                                                     m->conv, m->gpart_bn, m->coef_bn));
+  STEP_ON("conv3x3_wgrad", t, conv3x3_wgrad_grouped(m->last_images, m->dy, m->coef_bn, m->gslab_conv, n, Ci, H, H, sg, (hipStream_t)t));
   VTCHK(vt_reduce_rows(m->gslab_conv, n, C1 * Ci * 9 + C1, C1 * Ci * 9 + C1, m->G_("conv.W"), s));  // queued
   // the fc weight gradient only needs the head's delta: it rides at the end of the shorter chain
   m->join_signalled = false;
@@ -1072,14 +1106,14 @@ static int backward_main(vt_model *m, const int *d_labels, vt_stream s) {
   vt::g_stop_event = nullptr;
   // feed-forward half of the transformer layer
   if (!tails)
-    STEP("bn_bwd_finalize", vt_bn_bwd_finalize(m->part, nrb, D, NL, m->P_("norm2.gamma"), m->stat_n2, m->s2, m->G_("norm2.gamma"),
-                             m->G_("norm2.beta"), m->coef_n2, s));
+    STEP("bn_bwd_finalize", bn_bwd_close_launch(s, m->part, nrb, (int)(gr / RB), D, gr, NL, "norm2.gamma", "norm2.beta", m->stat_n2, m->s2,
+                                                m->gpart_n2, m->coef_n2));
   STEP("transformer_bwd_b", transformer_bwd_b_tail(m->o, m->pdt, m->coef_n2, m->hdn, m->a, m->tok, m->stat_n1, m->P_("ffn.linear1.W"),
                              m->P_("ffn.linear2.W"), m->ds2, m->da, m->G_("ffn.linear1.W"), m->sc_ffn, m->part, NL,
-                             tails ? bwd_tail(7, "norm1.gamma", m->stat_n1, m->tok, m->coef_n1, NL) : BnBwdTail{}, hs));
+                             tails ? bwd_tail(7, "norm1.gamma", m->stat_n1, m->tok, m->coef_n1, NL) : BnBwdTail{}, hs, gr));
   if (!tails)
-    STEP("bn_bwd_finalize", vt_bn_bwd_finalize(m->part, nrb, D, NL, m->P_("norm1.gamma"), m->stat_n1, m->tok, m->G_("norm1.gamma"),
-                             m->G_("norm1.beta"), m->coef_n1, s));
+    STEP("bn_bwd_finalize", bn_bwd_close_launch(s, m->part, nrb, (int)(gr / RB), D, gr, NL, "norm1.gamma", "norm1.beta", m->stat_n1, m->tok,
+                                                m->gpart_n1, m->coef_n1));
   // the output projection's cached input is the zero concat: its gradient is exactly zero
   // (a reduction over zero slab rows writes the zeros: it rides in the fused reduction launch and keeps
   // memset nodes, which did not replay reliably, out of the captured step graph)
@@ -1095,11 +1129,15 @@ static int backward_attention(vt_model *m, float *g_out, vt_stream s) {
     STEP("generic_backward_attention", gen_backward(m->gen, m->arena, &m->lo, m->grads, m->last_images, nullptr, m->lastN, 2, (hipStream_t)s));
     return 0;
   }
-  const int n = m->lastN;
+  const int n = m->lastN, sg = m->last_group;
   const long NL = (long)n * L;
-  STEP("transformer_bwd_c", vt_transformer_bwd_c(m->da, m->coef_n1, m->P_("mha.o.W"), m->tok, m->P_("mha.q0.W"), m->dr, m->dc, m->qkv, NL, s));
-  STEP("mha_bwd_rows", vt_mha_bwd_rows(m->qkv, m->dc, m->tok, m->sc_mha, n, L, s));
-  STEP("mha_bwd_wgrad", vt_mha_bwd_wgrad(m->qkv, m->dc, m->tok, m->P_("mha.q0.W"), g_out ? g_out : m->G_("mha.q0.W"), m->sc_mha, n, L, s));
+  // the attention groups are chunks of T consecutive token rows, T = the mini-batch size (the reference's permute
+  // relabels, it does not move data): with statistics groups of sg images, L chunks of sg rows per group
+  const int T = sg > 0 ? sg : n, chunks = sg > 0 ? L * (n / sg) : L;
+  STEP("transformer_bwd_c", transformer_bwd_c_grouped(m->da, m->coef_n1, m->P_("mha.o.W"), m->tok, m->P_("mha.q0.W"), m->dr, m->dc, m->qkv, NL,
+                                                      (long)sg * L, (hipStream_t)s));
+  STEP("mha_bwd_rows", vt_mha_bwd_rows(m->qkv, m->dc, m->tok, m->sc_mha, T, chunks, s));
+  STEP("mha_bwd_wgrad", vt_mha_bwd_wgrad(m->qkv, m->dc, m->tok, m->P_("mha.q0.W"), g_out ? g_out : m->G_("mha.q0.W"), m->sc_mha, T, chunks, s));
   return 0;
 }
 
@@ -1141,10 +1179,11 @@ extern "C" int vt_model_backward(vt_model *m, const int *d_labels, vt_stream s) 
   return 0;
 }
 
-extern "C" int vt_model_train_step(vt_model *m, const float *d_images, int n, const int *d_labels, float lr, float divisor,
-                                   float *d_probs, vt_stream s) {
+static int train_step_impl(vt_model *m, const float *d_images, int n, int group, const int *d_labels, float lr, float divisor,
+                           float *d_probs, vt_stream s) {
   if (!m || !d_labels || divisor == 0.f) return VT_EINVAL;
-  VTCHK(forward_impl(m, d_images, n, 0, d_probs, s));
+  if (group > 0 && !m->training) return VT_EINVAL;
+  VTCHK(forward_impl(m, d_images, n, group, d_probs, s));
   if (m->gen || m->defer_attn) {  // no queued reductions to fold the update into / the attention update trails
     VTCHK(vt_model_backward(m, d_labels, s));
     return vt_model_sgd_step(m, lr, divisor, s);
@@ -1157,6 +1196,16 @@ extern "C" int vt_model_train_step(vt_model *m, const float *d_images, int n, co
   STEP("reduce_rows_sgd", reduce_batch_flush_sgd(m->arena, m->grads, m->lo.n_trainable, lr, divisor, (hipStream_t)s));
   m->attention_pending = false;
   return 0;
+}
+
+extern "C" int vt_model_train_step(vt_model *m, const float *d_images, int n, const int *d_labels, float lr, float divisor,
+                                   float *d_probs, vt_stream s) {
+  return train_step_impl(m, d_images, n, 0, d_labels, lr, divisor, d_probs, s);
+}
+extern "C" int vt_model_train_step_grouped(vt_model *m, const float *d_images, int n, int group, const int *d_labels, float lr,
+                                           float divisor, float *d_probs, vt_stream s) {
+  if (group < 1) return VT_EINVAL;
+  return train_step_impl(m, d_images, n, group, d_labels, lr, divisor, d_probs, s);
 }
 
 extern "C" int vt_model_backward_main(vt_model *m, const int *d_labels, vt_stream s) {

@@ -896,14 +896,14 @@ using namespace vt;
 
 int vt::projector_fwd_tail(const float *conv_out, const float *bn_stat, const float *bn_gamma, const float *bn_beta,
                            const float *pk, const float *wd, const float *bd, const float *pivot, float *proj_a, float *z,
-                           float *part_pn, int N, int P, const BnFwdTail &tail, hipStream_t s) {
-  if (N < 1 || P < 1 || P > 16 * NW * TK_MAXT || !pivot) return VT_EUNSUPPORTED;
-  if (part_pn && tail.ticket)
+                           float *part_pn, int N, int P, const BnFwdTail &tail, hipStream_t s, int sgroup) {
+  if (N < 1 || P < 1 || P > 16 * NW * TK_MAXT || !pivot || sgroup < 0) return VT_EUNSUPPORTED;
+  if (part_pn && tail.ticket && sgroup == 0)
     hipLaunchKernelGGL(k_proj_fwd<true>, dim3(N), dim3(TPB), 0, s, conv_out, bn_stat, bn_gamma, bn_beta, pk, wd, bd, pivot, proj_a,
-                       z, part_pn, P, tail);
+                       z, part_pn, P, 0, tail);
   else
     hipLaunchKernelGGL(k_proj_fwd<false>, dim3(N), dim3(TPB), 0, s, conv_out, bn_stat, bn_gamma, bn_beta, pk, wd, bd, pivot, proj_a,
-                       z, part_pn, P, BnFwdTail{});
+                       z, part_pn, P, sgroup, BnFwdTail{});
   VT_CHECK_LAUNCH();
   return 0;
 }
@@ -911,41 +911,50 @@ extern "C" int vt_projector_fwd(const float *conv_out, const float *bn_stat, con
                                 const float *pk, const float *wd, const float *bd, const float *pivot, float *proj_a,
                                 float *z, float *part_pn, int N, int P, vt_stream s) {
   return projector_fwd_tail(conv_out, bn_stat, bn_gamma, bn_beta, pk, wd, bd, pivot, proj_a, z, part_pn, N, P, BnFwdTail{},
-                            (hipStream_t)s);
+                            (hipStream_t)s, 0);
 }
 
 
+// windows: du is the pair-form delta of k_head_bwd_win (P must be 784); sgroup: images per statistics group
+// (pn_coef and bn_stat then hold one record per group), 0 = the whole mini-batch is one group
+int vt::projector_bwd_grouped(const float *du, int windows, const float *pn_coef, const float *conv_out, const float *bn_stat,
+                              const float *bn_gamma, const float *bn_beta, const float *pk, const float *wq, const float *wd,
+                              float *pdx, float *dv, float *dk, float *gslab, int N, int P, int sgroup, hipStream_t s) {
+  if (N < 1 || P < 1 || sgroup < 0 || (windows && P != 784)) return VT_EUNSUPPORTED;
+  if (windows)
+    hipLaunchKernelGGL(k_proj_bwd<true>, dim3(N), dim3(TPB), 0, s, du, pn_coef, conv_out, bn_stat, bn_gamma, bn_beta, pk, wq, wd,
+                       pdx, dv, dk, gslab, P, sgroup);
+  else
+    hipLaunchKernelGGL(k_proj_bwd<false>, dim3(N), dim3(TPB), 0, s, du, pn_coef, conv_out, bn_stat, bn_gamma, bn_beta, pk, wq, wd,
+                       pdx, dv, dk, gslab, P, sgroup);
+  VT_CHECK_LAUNCH();
+  return 0;
+}
 extern "C" int vt_projector_bwd(const float *du, const float *pn_coef, const float *conv_out, const float *bn_stat,
                                 const float *bn_gamma, const float *bn_beta, const float *pk, const float *wq,
                                 const float *wd, float *pdx, float *dv, float *dk, float *gslab, int N, int P,
                                 vt_stream s) {
-  if (N < 1 || P < 1) return VT_EUNSUPPORTED;
-  hipLaunchKernelGGL(k_proj_bwd<false>, dim3(N), dim3(TPB), 0, (hipStream_t)s, du, pn_coef, conv_out, bn_stat, bn_gamma,
-                     bn_beta, pk, wq, wd, pdx, dv, dk, gslab, P);
-  VT_CHECK_LAUNCH();
-  return 0;
+  return projector_bwd_grouped(du, 0, pn_coef, conv_out, bn_stat, bn_gamma, bn_beta, pk, wq, wd, pdx, dv, dk, gslab, N, P, 0,
+                               (hipStream_t)s);
 }
 
 extern "C" int vt_projector_bwd_windows(const float *dpair, const float *pn_coef, const float *conv_out,
                                         const float *bn_stat, const float *bn_gamma, const float *bn_beta, const float *pk,
                                         const float *wq, const float *wd, float *pdx, float *dv, float *dk, float *gslab,
                                         int N, int P, vt_stream s) {
-  if (N < 1 || P != 784) return VT_EUNSUPPORTED;
-  hipLaunchKernelGGL(k_proj_bwd<true>, dim3(N), dim3(TPB), 0, (hipStream_t)s, dpair, pn_coef, conv_out, bn_stat, bn_gamma,
-                     bn_beta, pk, wq, wd, pdx, dv, dk, gslab, P);
-  VT_CHECK_LAUNCH();
-  return 0;
+  return projector_bwd_grouped(dpair, 1, pn_coef, conv_out, bn_stat, bn_gamma, bn_beta, pk, wq, wd, pdx, dv, dk, gslab, N, P, 0,
+                               (hipStream_t)s);
 }
 
 
 int vt::tokenizer_fwd_tail(const float *conv_out, const float *bn_stat, const float *bn_gamma, const float *bn_beta,
                            const float *w1, const float *b1, const float *w2, const float *b2, float *tok_A, float *tok_stat,
-                           float *tokens, float *part_n1, int N, int P, const BnFwdTail &tail, hipStream_t s) {
-  if (N < 1 || P < 1 || P > 16 * NW * TK_MAXT || !tok_stat) return VT_EUNSUPPORTED;
-  const bool tl = part_n1 != nullptr && tail.ticket != nullptr;
+                           float *tokens, float *part_n1, int N, int P, const BnFwdTail &tail, hipStream_t s, int sgroup) {
+  if (N < 1 || P < 1 || P > 16 * NW * TK_MAXT || !tok_stat || sgroup < 0) return VT_EUNSUPPORTED;
+  const bool tl = part_n1 != nullptr && tail.ticket != nullptr && sgroup == 0;
 #define VT_TOKFWD(MAP, TL)                                                                                                  \
   hipLaunchKernelGGL((k_tokenizer_fwd<MAP, TL>), dim3(N), dim3(TPB), 0, s, conv_out, bn_stat, bn_gamma, bn_beta, w1, b1, w2, \
-                     b2, tok_A, tok_stat, tokens, part_n1, P, TL ? tail : BnFwdTail{})
+                     b2, tok_A, tok_stat, tokens, part_n1, P, sgroup, TL ? tail : BnFwdTail{})
   if (tok_A != nullptr && tl) VT_TOKFWD(true, true);
   else if (tok_A != nullptr) VT_TOKFWD(true, false);
   else if (tl) VT_TOKFWD(false, true);
@@ -958,19 +967,19 @@ extern "C" int vt_tokenizer_fwd(const float *conv_out, const float *bn_stat, con
                                 const float *w1, const float *b1, const float *w2, const float *b2, float *tok_A,
                                 float *tok_stat, float *tokens, float *part_n1, int N, int P, vt_stream s) {
   return tokenizer_fwd_tail(conv_out, bn_stat, bn_gamma, bn_beta, w1, b1, w2, b2, tok_A, tok_stat, tokens, part_n1, N, P,
-                            BnFwdTail{}, (hipStream_t)s);
+                            BnFwdTail{}, (hipStream_t)s, 0);
 }
 
 int vt::tokenizer_bwd_tail(const float *conv_out, const float *bn_stat, const float *bn_gamma, const float *bn_beta,
                            const float *tok_stat, const float *dT0, const float *w1, const float *b1, const float *pdx,
-                           float *dy, float *part, int N, int P, const BnBwdTail &tail, hipStream_t s) {
-  if (N < 1 || P < 1 || !tok_stat) return VT_EUNSUPPORTED;
-  if (tail.ticket)
+                           float *dy, float *part, int N, int P, const BnBwdTail &tail, hipStream_t s, int sgroup) {
+  if (N < 1 || P < 1 || !tok_stat || sgroup < 0) return VT_EUNSUPPORTED;
+  if (tail.ticket && sgroup == 0)
     hipLaunchKernelGGL(k_tokenizer_bwd<true>, dim3(N), dim3(TPB), 0, s, conv_out, bn_stat, bn_gamma, bn_beta, tok_stat, dT0, w1,
-                       b1, pdx, dy, part, P, tail);
+                       b1, pdx, dy, part, P, 0, tail);
   else
     hipLaunchKernelGGL(k_tokenizer_bwd<false>, dim3(N), dim3(TPB), 0, s, conv_out, bn_stat, bn_gamma, bn_beta, tok_stat, dT0, w1,
-                       b1, pdx, dy, part, P, tail);
+                       b1, pdx, dy, part, P, sgroup, BnBwdTail{});
   VT_CHECK_LAUNCH();
   return 0;
 }
@@ -978,21 +987,26 @@ extern "C" int vt_tokenizer_bwd(const float *conv_out, const float *bn_stat, con
                                 const float *tok_stat, const float *dT0, const float *w1, const float *b1,
                                 const float *pdx, float *dy, float *part, int N, int P, vt_stream s) {
   return tokenizer_bwd_tail(conv_out, bn_stat, bn_gamma, bn_beta, tok_stat, dT0, w1, b1, pdx, dy, part, N, P, BnBwdTail{},
-                            (hipStream_t)s);
+                            (hipStream_t)s, 0);
 }
 
 
-extern "C" int vt_conv3x3_wgrad(const float *x, const float *dy, const float *bn_coef, float *gslab, int N, int Ci,
-                                int H, int W, vt_stream s) {
-  if (N < 1 || Ci < 1 || Ci > CW_MAXCI || H < 1 || W < 1) return VT_EUNSUPPORTED;
+// sgroup: images per statistics group (bn_coef then holds one record per group), 0 = one group
+int vt::conv3x3_wgrad_grouped(const float *x, const float *dy, const float *bn_coef, float *gslab, int N, int Ci, int H, int W,
+                              int sgroup, hipStream_t s) {
+  if (N < 1 || Ci < 1 || Ci > CW_MAXCI || H < 1 || W < 1 || sgroup < 0) return VT_EUNSUPPORTED;
   const int ld = C1 * Ci * 9 + C1;
   const size_t lds = (size_t)Ci * (H + 2) * (W + 2) * sizeof(float);
   if (W % 4 == 0 && lds <= 32 * 1024)
-    hipLaunchKernelGGL(k_conv_wgrad<true>, dim3(N), dim3(TPB), lds, (hipStream_t)s, x, dy, bn_coef, gslab, Ci, H, W, ld);
+    hipLaunchKernelGGL(k_conv_wgrad<true>, dim3(N), dim3(TPB), lds, s, x, dy, bn_coef, gslab, Ci, H, W, ld, sgroup);
   else
-    hipLaunchKernelGGL(k_conv_wgrad<false>, dim3(N), dim3(TPB), 0, (hipStream_t)s, x, dy, bn_coef, gslab, Ci, H, W, ld);
+    hipLaunchKernelGGL(k_conv_wgrad<false>, dim3(N), dim3(TPB), 0, s, x, dy, bn_coef, gslab, Ci, H, W, ld, sgroup);
   VT_CHECK_LAUNCH();
   return 0;
+}
+extern "C" int vt_conv3x3_wgrad(const float *x, const float *dy, const float *bn_coef, float *gslab, int N, int Ci,
+                                int H, int W, vt_stream s) {
+  return conv3x3_wgrad_grouped(x, dy, bn_coef, gslab, N, Ci, H, W, 0, (hipStream_t)s);
 }
 
 

@@ -451,9 +451,11 @@ __global__ __launch_bounds__(TPB) void k_projtok_bwd_tr_a(const float *__restric
                                                           float *__restrict__ scratch, const float *__restrict__ s2,
                                                           const float *__restrict__ st2, const float *__restrict__ W2tok,
                                                           float *__restrict__ part, float *__restrict__ dT0, long rows,
-                                                          const BnBwdTail tail) {
+                                                          long group_rows, const BnBwdTail tail) {
   __shared__ float sbuf[PT_SLOTS * TILE_SLOT];
   __shared__ float sred[NW][2 * D];
+  // statistics group of this workgroup's rows (group_rows is a multiple of RB; 0 = one group)
+  if (group_rows > 0) st2 += ((long)blockIdx.x * RB / group_rows) * 2 * D;
   TTile<2> pt;
   projtok_bwd_body(o, dv, dk, Wv, Wk, pdt, scratch, rows, sbuf, pt);
   tr_bwd_a_body<TAIL>(o, pt, s2, st2, W2tok, part, dT0, rows, sred, tail);
@@ -476,9 +478,15 @@ __global__ __launch_bounds__(TPB) void k_tr_bwd_b(const float *__restrict__ o, c
                                                   const float *__restrict__ st1, const float *__restrict__ W1,
                                                   const float *__restrict__ W2, float *__restrict__ ds2_out,
                                                   float *__restrict__ da_out, float *__restrict__ scratch,
-                                                  float *__restrict__ part, long rows, const BnBwdTail tail) {
+                                                  float *__restrict__ part, long rows, long group_rows,
+                                                  const BnBwdTail tail) {
   __shared__ float sbuf[9 * TILE_SLOT];
   __shared__ float sred[NW][2 * D];
+  if (group_rows > 0) {  // statistics group of this workgroup's rows (group_rows is a multiple of RB; 0 = one group)
+    const long grp = (long)blockIdx.x * RB / group_rows;
+    coef2 += grp * 2 * D;
+    st1 += grp * 2 * D;
+  }
   const Lane ln;
   const int wave = threadIdx.x >> 6;
   const long row0 = ((long)blockIdx.x * NW + wave) * 16;
@@ -596,8 +604,10 @@ __global__ __launch_bounds__(TPB) void k_tr_bwd_b(const float *__restrict__ o, c
 __global__ __launch_bounds__(TPB) void k_tr_bwd_c(const float *__restrict__ da, const float *__restrict__ coef1,
                                                   const float *__restrict__ Wo, const float *__restrict__ tok,
                                                   const float *__restrict__ Wqkv, float *__restrict__ dr_out,
-                                                  float *__restrict__ dc, float *__restrict__ qkv, long rows) {
+                                                  float *__restrict__ dc, float *__restrict__ qkv, long rows,
+                                                  long group_rows) {
   static_assert(HD == 16, "one output tile per head");
+  if (group_rows > 0) coef1 += ((long)blockIdx.x * RB / group_rows) * 2 * D;  // this workgroup's statistics group
   const Lane ln;
   const int wave = threadIdx.x >> 6;
   const long row0 = ((long)blockIdx.x * NW + wave) * 16;
@@ -714,15 +724,16 @@ extern "C" int vt_transformer_bwd_a(const float *o, const float *pdt, const floa
 int vt::projector_tokens_bwd_transformer_a_tail(const float *o, const float *dv, const float *dk, const float *wv,
                                                 const float *wk, float *pdt, float *g_wk_wv_bv, float *scratch,
                                                 const float *s2, const float *n2_stat, const float *tok_w2, float *part,
-                                                float *dT0, long rows, const BnBwdTail &tail, hipStream_t s) {
-  if (rows < 1) return VT_EINVAL;
+                                                float *dT0, long rows, const BnBwdTail &tail, hipStream_t s,
+                                                long group_rows) {
+  if (rows < 1 || group_rows < 0 || group_rows % RB != 0) return VT_EINVAL;
   const int nb = (int)((rows + RB - 1) / RB);
-  if (tail.ticket)
+  if (tail.ticket && group_rows == 0)
     VT_LAUNCH_SIGNALLING(k_projtok_bwd_tr_a<true>, dim3(nb), dim3(TPB), 0, s, o, dv, dk, wv, wk, pdt, scratch, s2, n2_stat, tok_w2,
-                         part, dT0, rows, tail);
+                         part, dT0, rows, 0L, tail);
   else
     VT_LAUNCH_SIGNALLING(k_projtok_bwd_tr_a<false>, dim3(nb), dim3(TPB), 0, s, o, dv, dk, wv, wk, pdt, scratch, s2, n2_stat,
-                         tok_w2, part, dT0, rows, tail);
+                         tok_w2, part, dT0, rows, group_rows, BnBwdTail{});
   VT_CHECK_LAUNCH();
   return reduce_rows(scratch, nb, PT_STRIDE, PT_STRIDE, g_wk_wv_bv, s);
 }
@@ -731,21 +742,22 @@ extern "C" int vt_projector_tokens_bwd_transformer_a(const float *o, const float
                                                      const float *s2, const float *n2_stat, const float *tok_w2,
                                                      float *part, float *dT0, long rows, vt_stream s) {
   return projector_tokens_bwd_transformer_a_tail(o, dv, dk, wv, wk, pdt, g_wk_wv_bv, scratch, s2, n2_stat, tok_w2, part, dT0,
-                                                 rows, BnBwdTail{}, (hipStream_t)s);
+                                                 rows, BnBwdTail{}, (hipStream_t)s, 0);
 }
 
 // g_ffn: gradient block [gW1 | gb1 | gW2 | gb2] (2112 floats, arena order); scratch >= nb*2112.
 int vt::transformer_bwd_b_tail(const float *o, const float *pdt, const float *n2_coef, const float *hdn, const float *a,
                                const float *tok, const float *n1_stat, const float *w1, const float *w2, float *ds2, float *da,
-                               float *g_ffn, float *scratch, float *part, long rows, const BnBwdTail &tail, hipStream_t s) {
-  if (rows < 1) return VT_EINVAL;
+                               float *g_ffn, float *scratch, float *part, long rows, const BnBwdTail &tail, hipStream_t s,
+                               long group_rows) {
+  if (rows < 1 || group_rows < 0 || group_rows % RB != 0) return VT_EINVAL;
   const int nb = (int)((rows + RB - 1) / RB);
-  if (tail.ticket)
+  if (tail.ticket && group_rows == 0)
     hipLaunchKernelGGL(k_tr_bwd_b<true>, dim3(nb), dim3(TPB), 0, s, o, pdt, n2_coef, hdn, a, tok, n1_stat, w1, w2, ds2, da, scratch,
-                       part, rows, tail);
+                       part, rows, 0L, tail);
   else
     hipLaunchKernelGGL(k_tr_bwd_b<false>, dim3(nb), dim3(TPB), 0, s, o, pdt, n2_coef, hdn, a, tok, n1_stat, w1, w2, ds2, da, scratch,
-                       part, rows, tail);
+                       part, rows, group_rows, BnBwdTail{});
   VT_CHECK_LAUNCH();
   return reduce_rows(scratch, nb, FF_STRIDE, FF_STRIDE, g_ffn, s);
 }
@@ -754,14 +766,19 @@ extern "C" int vt_transformer_bwd_b(const float *o, const float *pdt, const floa
                                     const float *w2, float *ds2, float *da, float *g_ffn, float *scratch, float *part,
                                     long rows, vt_stream s) {
   return transformer_bwd_b_tail(o, pdt, n2_coef, hdn, a, tok, n1_stat, w1, w2, ds2, da, g_ffn, scratch, part, rows, BnBwdTail{},
-                                (hipStream_t)s);
+                                (hipStream_t)s, 0);
 }
 
-extern "C" int vt_transformer_bwd_c(const float *da, const float *n1_coef, const float *wo, const float *tok,
-                                    const float *wqkv, float *dr, float *dc, float *qkv, long rows, vt_stream s) {
-  if (rows < 1) return VT_EINVAL;
+// group_rows: token rows per statistics group (n1_coef then holds one record per group; a multiple of 64), 0 = one group
+int vt::transformer_bwd_c_grouped(const float *da, const float *n1_coef, const float *wo, const float *tok, const float *wqkv,
+                                  float *dr, float *dc, float *qkv, long rows, long group_rows, hipStream_t s) {
+  if (rows < 1 || group_rows < 0 || group_rows % RB != 0) return VT_EINVAL;
   const int nb = (int)((rows + RB - 1) / RB);
-  hipLaunchKernelGGL(k_tr_bwd_c, dim3(nb), dim3(TPB), 0, (hipStream_t)s, da, n1_coef, wo, tok, wqkv, dr, dc, qkv, rows);
+  hipLaunchKernelGGL(k_tr_bwd_c, dim3(nb), dim3(TPB), 0, s, da, n1_coef, wo, tok, wqkv, dr, dc, qkv, rows, group_rows);
   VT_CHECK_LAUNCH();
   return 0;
+}
+extern "C" int vt_transformer_bwd_c(const float *da, const float *n1_coef, const float *wo, const float *tok,
+                                    const float *wqkv, float *dr, float *dc, float *qkv, long rows, vt_stream s) {
+  return transformer_bwd_c_grouped(da, n1_coef, wo, tok, wqkv, dr, dc, qkv, rows, 0, (hipStream_t)s);
 }

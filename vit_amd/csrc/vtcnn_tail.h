@@ -43,28 +43,40 @@ int conv3x3_fwd_tail(const float *x, const float *w, const float *b, float *conv
                      int W, const BnFwdTail &tail, hipStream_t s);
 int tokenizer_fwd_tail(const float *conv_out, const float *bn_stat, const float *bn_gamma, const float *bn_beta,
                        const float *w1, const float *b1, const float *w2, const float *b2, float *tok_A, float *tok_stat,
-                       float *tokens, float *part_n1, int N, int P, const BnFwdTail &tail, hipStream_t s);
+                       float *tokens, float *part_n1, int N, int P, const BnFwdTail &tail, hipStream_t s, int sgroup = 0);
 int transformer_ffn_fwd_tail(const float *tok, const float *n1_stat, const float *n1_gamma, const float *n1_beta,
                              const float *w1, const float *b1, const float *w2, const float *b2, float *a, float *hdn, float *s2,
                              float *part, long rows, const BnFwdTail &tail, hipStream_t s);
 int projector_fwd_tail(const float *conv_out, const float *bn_stat, const float *bn_gamma, const float *bn_beta,
                        const float *pk, const float *wd, const float *bd, const float *pivot, float *proj_A, float *z,
-                       float *part_pn, int N, int P, const BnFwdTail &tail, hipStream_t s);
+                       float *part_pn, int N, int P, const BnFwdTail &tail, hipStream_t s, int sgroup = 0);
 
 int projector_tokens_bwd_transformer_a_tail(const float *o, const float *dv, const float *dk, const float *wv, const float *wk,
                                             float *pdt, float *g_wk_wv_bv, float *scratch, const float *s2,
                                             const float *n2_stat, const float *tok_w2, float *part, float *dT0, long rows,
-                                            const BnBwdTail &tail, hipStream_t s);
+                                            const BnBwdTail &tail, hipStream_t s, long group_rows = 0);
 int transformer_bwd_b_tail(const float *o, const float *pdt, const float *n2_coef, const float *hdn, const float *a,
                            const float *tok, const float *n1_stat, const float *w1, const float *w2, float *ds2, float *da,
-                           float *g_ffn, float *scratch, float *part, long rows, const BnBwdTail &tail, hipStream_t s);
+                           float *g_ffn, float *scratch, float *part, long rows, const BnBwdTail &tail, hipStream_t s,
+                           long group_rows = 0);
 int tokenizer_bwd_tail(const float *conv_out, const float *bn_stat, const float *bn_gamma, const float *bn_beta,
                        const float *tok_stat, const float *dT0, const float *w1, const float *b1, const float *pdx, float *dy,
-                       float *part, int N, int P, const BnBwdTail &tail, hipStream_t s);
+                       float *part, int N, int P, const BnBwdTail &tail, hipStream_t s, int sgroup = 0);
 int head_bwd_windows_tail(const float *probs, const int *labels, const float *wfc, const unsigned char *pool_idx,
                           const float *pooled, const float *z, const float *pn_stat, const float *pn_gamma,
                           const float *pn_beta, float *d_logits, float *dpair, float *part, int N, int H, int K,
-                          const BnBwdTail &tail, hipStream_t s);
+                          const BnBwdTail &tail, hipStream_t s, int sgroup = 0);
+int head_bwd_windows_blocks_grouped(int N, int sgroup, int *per_group);
+
+// Launchers with one statistics record per group of `sgroup` consecutive images (sgroup = 0: one group), for steps
+// whose mini-batch is several independent reference mini-batches side by side.
+int projector_bwd_grouped(const float *du, int windows, const float *pn_coef, const float *conv_out, const float *bn_stat,
+                          const float *bn_gamma, const float *bn_beta, const float *pk, const float *wq, const float *wd,
+                          float *pdx, float *dv, float *dk, float *gslab, int N, int P, int sgroup, hipStream_t s);
+int transformer_bwd_c_grouped(const float *da, const float *n1_coef, const float *wo, const float *tok, const float *wqkv,
+                              float *dr, float *dc, float *qkv, long rows, long group_rows, hipStream_t s);
+int conv3x3_wgrad_grouped(const float *x, const float *dy, const float *bn_coef, float *gslab, int N, int Ci, int H, int W,
+                          int sgroup, hipStream_t s);
 
 // write-through store / L1-bypassing load of one float of a partial record
 __device__ __forceinline__ void tail_store(float *p, float v) {

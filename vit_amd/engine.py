@@ -158,9 +158,30 @@ class VTCNN:
               "vt_model_train_step")
         return self._probs[:n]
 
+    def train_step_grouped(self, x, labels, group, batch_size=32.0):
+        """n / group independent reference mini-batches of `group` images trained side by side in one launch set
+        (vt_model_train_step_grouped): per-mini-batch statistics and attention groups, gradients summed, ONE update with
+        divisor (n / group) * batch_size.  Returns the softmax probabilities [N,K]."""
+        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+        assert labels.is_cuda and labels.dtype == torch.int32 and labels.is_contiguous()
+        n = x.shape[0]
+        d = self.dims
+        if tuple(x.shape[1:]) != (d.image_channels, d.input_dim, d.input_dim) or labels.numel() != n:
+            raise ValueError("input shape %s / labels %s do not match the model" % (tuple(x.shape), tuple(labels.shape)))
+        if n < 1 or n > self.max_batch or n % int(group) != 0:
+            raise ValueError("batch %d is not a multiple of group %d inside [1, max_batch=%d]" % (n, group, self.max_batch))
+        self._n = n
+        self._x = x
+        divisor = float(batch_size) * (n // int(group))
+        check(lib.vt_model_train_step_grouped(self._h, C.c_void_p(x.data_ptr()), n, int(group), C.c_void_p(labels.data_ptr()),
+                                              self.lr, divisor, C.c_void_p(self._probs.data_ptr()), _stream_handle(self.device)),
+              "vt_model_train_step_grouped")
+        return self._probs[:n]
+
     def forward_grouped(self, x, group):
-        """Eval-mode forward of consecutive mini-batches of `group` images in one launch set;
-        equal to forward() on each batch up to rounding of the statistics (vt_model_forward_grouped)."""
+        """Forward of consecutive mini-batches of `group` images in one launch set, each with its own batch statistics
+        (vt_model_forward_grouped): an evaluation sweep in eval mode; in training mode the forward half of a grouped
+        training step (backward() afterwards leaves the sum of the mini-batches' gradients)."""
         assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
         n = x.shape[0]
         if n < 1 or n > self.max_batch:
