@@ -9,7 +9,8 @@
 // one loader batch at a time, which is bit-identical to the host loop, while chunks differ from it in the
 // last bits of the running statistics), VTCNN_HOST_LOOP=1 (the reference's per-batch host loop instead of the
 // device-resident one), VTCNN_GPUS (train data-parallel over that many GPUs of the node: one replica and one
-// loader batch per GPU and round, gradients summed over RCCL, see utils/trainer.hpp).
+// loader batch per GPU and round, gradients summed over RCCL, see utils/trainer.hpp), VTCNN_VIRTUAL_RANKS (train that
+// many consecutive loader batches per step on one GPU as independent mini-batches with one summed update).
 #include <algorithm>
 #include <cstdlib>
 #include <fstream>
@@ -65,7 +66,9 @@ void run_pipeline(const DatasetInfo &ds, bool train_mode, const std::string &dev
 
   VTCNN model(image_channels, input_dim, vt_layers_num, tokens, token_channels, vt_channels, transformer_enc_layers,
               transformer_heads, transformer_fc_dim, transformer_dropout, num_classes,
-              std::max(batch_size, env_int("VTCNN_EVAL_CHUNK", 0)));  // workspace: evaluation runs this many images per launch set
+              // workspace: evaluation runs VTCNN_EVAL_CHUNK images per launch set, a grouped training step
+              // VTCNN_VIRTUAL_RANKS loader batches
+              std::max({batch_size, env_int("VTCNN_EVAL_CHUNK", 0), batch_size * std::max(1, env_int("VTCNN_VIRTUAL_RANKS", 1))}));
   Trainer trainer(model, train_loader, val_loader, num_classes, batch_size, &test_loader);
   if (train_mode) {
     std::cout << "🚀 Entrenando modelo por " << epochs << " épocas...\n";

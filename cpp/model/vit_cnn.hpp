@@ -221,6 +221,21 @@ class VTCNN : public Model {
           "vt_eval_accumulate");
     last_n_ = n;
   }
+  // `n / group` consecutive loader batches of `group` images as independent mini-batches in ONE launch set
+  // (vt_model_train_step_grouped): each with its own BatchNorm statistics and attention groups, the gradients summed,
+  // one update with divisor (n / group) * batch_size -- one step of n / group data-parallel ranks on this one GPU.
+  // The batches' loss sums / correct counts go to slots slot0 .. of the two device arrays.
+  void train_group_resident(const unsigned char *d_images_u8, const int *d_all_labels, const int *d_indices, int n, int group,
+                            float batch_size, int slot0, float *d_loss_sums, int *d_correct) {
+    const int pixels = dims_.image_channels * dims_.input_dim * dims_.input_dim;
+    check(vt_loader_gather(d_images_u8, d_all_labels, d_indices, n, pixels, d_in_, d_labels_, stream_), "vt_loader_gather");
+    check(vt_model_train_step_grouped(h_, d_in_, n, group, d_labels_, lr_, batch_size * (float)(n / group), d_probs_, stream_),
+          "VTCNN::train_step_grouped");
+    check(vt_eval_accumulate_grouped(d_probs_, d_labels_, n, dims_.num_classes, group, slot0, d_loss_sums, d_correct, nullptr,
+                                     nullptr, stream_),
+          "vt_eval_accumulate_grouped");
+    last_n_ = n;
+  }
   // the same iteration up to and including backward: the summed gradients of the batch stay in the gradient arena
   // (a data-parallel caller exchanges them before update_weights)
   void gradients_resident(const unsigned char *d_images_u8, const int *d_all_labels, const int *d_indices, int n, int slot,

@@ -118,6 +118,46 @@ class Trainer {
     return (long)total;
   }
 
+  // ---- several loader batches per step on ONE GPU (environment VTCNN_VIRTUAL_RANKS = V; no counterpart in the
+  // reference): round t trains loader batches t*V .. t*V+V-1 as V independent mini-batches in one launch set, their
+  // gradients summed, one update_weights(V * batch_size): the step of V data-parallel ranks, at about the cost of one
+  // batch-of-32 step (which is bound by its chain of dependent launches, not by arithmetic).  The full batches of a last,
+  // shorter round are trained the same way; a short last batch is trained alone, as the reference trains it.
+  int virtual_ranks(VTCNN &m) const {
+    const char *want = std::getenv("VTCNN_VIRTUAL_RANKS");
+    const int V = want && *want ? std::atoi(want) : 0;
+    if (V < 2) return 1;
+    const size_t bs = train_loader.batch();
+    if (bs % 4 != 0 || m.dims().input_dim != 28) throw std::runtime_error("VTCNN_VIRTUAL_RANKS needs a batch size that is a multiple of 4 and 28x28 inputs");
+    if ((size_t)m.max_batch() < bs * V) throw std::runtime_error("VTCNN_VIRTUAL_RANKS: the model's max_batch is smaller than V * batch_size");
+    return V;
+  }
+  long train_epoch_grouped(VTCNN &m, int V, Pass &p) {
+    const size_t total = train_loader.size(), bs = train_loader.batch(), nb = train_loader.total_batches();
+    DeviceCounters dc((int)nb, num_classes, 0);
+    const DataLoader::Resident &r = train_loader.resident(m.stream());
+    const size_t full = total / bs;  // batches of exactly bs images
+    for (size_t b = 0; b < full; b += V) {
+      const size_t k = std::min<size_t>(V, full - b);
+      if (k >= 2)
+        m.train_group_resident(r.images_u8, r.labels, r.indices + b * bs, (int)(k * bs), (int)bs, (float)batch_size, (int)b, dc.loss_sums,
+                               dc.correct);
+      else
+        m.train_batch_resident(r.images_u8, r.labels, r.indices + b * bs, (int)bs, (float)batch_size, (int)b, dc.loss_sums, dc.correct);
+    }
+    if (full < nb)  // the short last batch, alone, with the constant divisor (utils/trainer.hpp:53)
+      m.train_batch_resident(r.images_u8, r.labels, r.indices + full * bs, (int)(total - full * bs), (float)batch_size, (int)full,
+                             dc.loss_sums, dc.correct);
+    std::vector<float> ls(nb);
+    std::vector<int> ok(nb);
+    vt_host::hip_check(hipMemcpyAsync(ls.data(), dc.loss_sums, sizeof(float) * nb, hipMemcpyDeviceToHost, m.stream()), "D2H");
+    vt_host::hip_check(hipMemcpyAsync(ok.data(), dc.correct, sizeof(int) * nb, hipMemcpyDeviceToHost, m.stream()), "D2H");
+    vt_host::hip_check(hipStreamSynchronize(m.stream()), "sync");
+    fold_batches(ls, ok, total, bs, p);
+    train_loader.skip_to_end();
+    return (long)total;
+  }
+
   // ---- data parallel over the GPUs of the node from this one process (environment VTCNN_GPUS = G; unset: the
   // single-device loops above.  No counterpart in the reference).  Rank r owns a replica of the model and of the
   // resident training set on a device of its own and a host thread that issues its work; round t trains loader
@@ -152,6 +192,10 @@ class Trainer {
     vt_host::hip_check(hipGetDeviceCount(&have), "hipGetDeviceCount");
     const int G = std::atoi(want);
     if (G < 1 || G > have) throw std::runtime_error("VTCNN_GPUS must be between 1 and the number of visible GPUs");
+    // one rank has nothing to exchange: the single-device loop, without opening the collective library
+    // (VTCNN_DP_FORCE=1 keeps the data-parallel driver even then: a test aid)
+    const char *force = std::getenv("VTCNN_DP_FORCE");
+    if (G == 1 && !(force && *force && *force != '0')) return nullptr;
     std::unique_ptr<DataParallel> g(new DataParallel);
     std::vector<int> devices{m.device()};
     for (int d = 0; d < have && (int)devices.size() < G; ++d)
@@ -192,7 +236,6 @@ class Trainer {
     (void)train_loader.resident(g.models[0]->stream());  // this epoch's order on rank 0's device
     std::vector<std::vector<float>> ls(G, std::vector<float>(rounds));
     std::vector<std::vector<int>> ok(G, std::vector<int>(rounds));
-    std::vector<std::exception_ptr> failure(G);
     auto rank_epoch = [&](size_t r) {
       try {
         VTCNN &m = *g.models[r];
@@ -211,16 +254,20 @@ class Trainer {
         vt_host::hip_check(hipMemcpyAsync(ls[r].data(), dc.loss_sums, sizeof(float) * rounds, hipMemcpyDeviceToHost, m.stream()), "D2H");
         vt_host::hip_check(hipMemcpyAsync(ok[r].data(), dc.correct, sizeof(int) * rounds, hipMemcpyDeviceToHost, m.stream()), "D2H");
         vt_host::hip_check(hipStreamSynchronize(m.stream()), "sync");
+      } catch (const std::exception &e) {
+        // the other ranks are (or will be) blocked inside the exchange waiting for this one: joining them would hang,
+        // so the run ends here, loudly
+        std::cerr << "❌ data-parallel rank " << r << " failed: " << e.what() << std::endl;
+        std::_Exit(3);
       } catch (...) {
-        failure[r] = std::current_exception();
+        std::cerr << "❌ data-parallel rank " << r << " failed" << std::endl;
+        std::_Exit(3);
       }
     };
     std::vector<std::thread> workers;
     for (size_t r = 1; r < G; ++r) workers.emplace_back(rank_epoch, r);
     rank_epoch(0);
     for (std::thread &w : workers) w.join();
-    for (const std::exception_ptr &e : failure)
-      if (e) std::rethrow_exception(e);
     long images = 0;
     for (size_t t = 0; t < rounds; ++t)  // per-batch means folded in loader order, as the single-device loop does
       for (size_t r = 0; r < G; ++r) {
@@ -274,7 +321,8 @@ class Trainer {
       if (VTCNN *m = device_model(train_loader)) {
         Pass p;
         DataParallel *g = data_parallel(*m);
-        images = g ? train_epoch_data_parallel(*g, p) : train_epoch_resident(*m, p);
+        const int V = g ? 1 : virtual_ranks(*m);
+        images = g ? train_epoch_data_parallel(*g, p) : (V > 1 ? train_epoch_grouped(*m, V, p) : train_epoch_resident(*m, p));
         epoch_loss = p.loss;
         epoch_acc = p.acc;
         batches = p.batches;

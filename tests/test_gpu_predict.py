@@ -209,11 +209,55 @@ def test_cpp_cli_train_one_epoch_runs_and_saves(tmp_path):
     assert cm(r.stdout) == cm(r2.stdout)
     # The data-parallel driver with one rank (replica threads, gradient arena through an RCCL all-reduce, divisor
     # ranks * batch_size) is the single-device run, byte for byte.
-    r3 = subprocess.run([exe, "bloodmnist", "train", "1"], env=dict(env, VTCNN_GPUS="1"), capture_output=True, text=True, timeout=110)
+    r3 = subprocess.run([exe, "bloodmnist", "train", "1"], env=dict(env, VTCNN_GPUS="1", VTCNN_DP_FORCE="1"), capture_output=True,
+                        text=True, timeout=110)
     assert r3.returncode == 0, r3.stderr[-2000:]
     assert ck.read_bytes() == first
     assert numbers(r3.stdout, "Train Loss:") == numbers(r.stdout, "Train Loss:")
     assert cm(r3.stdout) == cm(r.stdout)
+    # VTCNN_GPUS=1 without the test switch has nothing to exchange and never opens the collective library
+    r4 = subprocess.run([exe, "bloodmnist", "train", "1"], env=dict(env, VTCNN_GPUS="1", VT_RCCL_LIBRARY="/nonexistent/librccl.so"),
+                        capture_output=True, text=True, timeout=110)
+    assert r4.returncode == 0, r4.stderr[-2000:]
+    assert ck.read_bytes() == first
+
+
+def test_cpp_cli_virtual_ranks_match_the_python_grouped_steps(tmp_path):
+    """VTCNN_VIRTUAL_RANKS=3: one epoch over 204 images = two grouped steps of three loader batches (one summed update each,
+    divisor 3 * 32) and the short last batch alone; the checkpoint equals, byte for byte, the arena of the same steps
+    driven through vt_model_train_step_grouped from Python on the same loader order."""
+    import torch
+    from vit_amd import VTCNN, Dims
+    from vit_amd.engine import load_dataset, loader_indices
+    exe = os.path.join(ROOT, "cpp", "build", "main")
+    assert os.access(exe, os.X_OK)
+    img, lbl, _ = _paths()
+    data = tmp_path / "blood_data"
+    data.mkdir()
+    for stem in ("train", "t10k"):
+        shutil.copy(img, data / ("%s-images-idx3-ubyte" % stem))
+        shutil.copy(lbl, data / ("%s-labels-idx1-ubyte" % stem))
+    env = dict(os.environ, VTCNN_DATA_ROOT=str(tmp_path), VTCNN_NUM_CLASSES="8", VTCNN_VIRTUAL_RANKS="3")
+    r = subprocess.run([exe, "bloodmnist", "train", "1"], env=env, capture_output=True, text=True, timeout=110)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "Epoch 1/1" in r.stdout and "Train Loss:" in r.stdout and "Val Loss:" in r.stdout
+    ck = tmp_path / "model_bloodmnist.bin"
+    assert ck.exists() and ck.stat().st_size == 110838
+    ds = load_dataset(img, lbl, 60000)
+    ntrain = int(256 * 0.8)
+    order = loader_indices(ntrain, 42, 1)  # the constructor's shuffle, then the epoch's reset()
+    x = torch.from_numpy(np.ascontiguousarray(ds.images[:ntrain][order].reshape(ntrain, 1, 28, 28))).cuda()
+    y = torch.from_numpy(np.ascontiguousarray(ds.labels[:ntrain][order].astype(np.int32))).cuda()
+    m = VTCNN(Dims(num_classes=8), max_batch=96, seed=42)
+    for first in (0, 96):
+        m.train_step_grouped(x[first:first + 96].contiguous(), y[first:first + 96].contiguous(), 32, 32.0)
+    m.train_step(x[192:].contiguous(), y[192:].contiguous(), 32.0)
+    m.save(str(tmp_path / "python.bin"))
+    assert ck.read_bytes() == (tmp_path / "python.bin").read_bytes()
+    # and it is not the one-batch-at-a-time run
+    r2 = subprocess.run([exe, "bloodmnist", "train", "1"], env=dict(env, VTCNN_VIRTUAL_RANKS="1"), capture_output=True, text=True,
+                        timeout=110)
+    assert r2.returncode == 0 and ck.read_bytes() != (tmp_path / "python.bin").read_bytes()
 
 
 def test_dp_entry_points_sum_over_visible_gpus():
