@@ -626,41 +626,34 @@ __global__ __launch_bounds__(GT) void k_pool_fwd(const float *__restrict__ z, co
 
 // MaxPool2DLayer::backward (pooling_layer.hpp:68-97) as a gather + the ReLU mask on the flat
 // reinterpretation (relu_layer.hpp:20-33): du[F] = dpool[window(F)] if F is the window's arg-max and
-// the activation was positive.  One wave per image row of one plane.
-__global__ __launch_bounds__(GT) void k_pool_bwd(const float *__restrict__ z, const float *__restrict__ stat,
-                                                 const float *__restrict__ g, const float *__restrict__ b,
-                                                 const float *__restrict__ dpool, const int *__restrict__ pool_idx,
-                                                 float *__restrict__ du, long rows, int C2, int H, int pk) {
-  const int W = H, P = H * W, lane = threadIdx.x & 63;
+// the activation was positive.  The window's arg-max was active exactly when the pooled maximum the forward kept is
+// positive: the same decision the step's own delta kernels take (window_delta, k_pool_delta_windows), so the exported
+// array is the delta the step used even where the activation rounds to zero.  One wave per image row of one plane.
+__global__ __launch_bounds__(GT) void k_pool_bwd(const float *__restrict__ pooled, const float *__restrict__ dpool,
+                                                 const int *__restrict__ pool_idx, float *__restrict__ du, long rows,
+                                                 int H, int pk) {
+  const int W = H, lane = threadIdx.x & 63;
   const long rid = (long)blockIdx.x * (GT / 64) + (threadIdx.x >> 6);  // (n * C2 + ch) * H + h
   if (rid >= rows) return;
   const long nc = rid / H;
   const int h = (int)(rid - nc * H);
-  const int c_row = (int)(((nc % C2) * (long)P + (long)h * W) % C2);
   const long win0 = nc * 196 + (h / pk) * 14;
-  const float *__restrict__ zr = z + rid * W;
   float *__restrict__ dr = du + rid * W;
-  if ((W & 3) == 0) {  // four pixels per lane: one 16-byte load and store
+  if ((W & 3) == 0) {  // four pixels per lane: one 16-byte store
     for (int w = lane * 4; w < W; w += 256) {
-      const float4 zv = *reinterpret_cast<const float4 *>(zr + w);
-      const float zz[4] = {zv.x, zv.y, zv.z, zv.w};
       float o[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int c = (c_row + w + e) % C2;
-        const float y = (zz[e] - stat[c]) * stat[C2 + c] * g[c] + b[c];
         const long win = win0 + (w + e) / pk;
-        o[e] = (y > 0.f && pool_idx[win] == h * W + w + e) ? dpool[win] : 0.f;
+        o[e] = (pooled[win] > 0.f && pool_idx[win] == h * W + w + e) ? dpool[win] : 0.f;
       }
       *reinterpret_cast<float4 *>(dr + w) = make_float4(o[0], o[1], o[2], o[3]);
     }
     return;
   }
   for (int w = lane; w < W; w += 64) {
-    const int c = (c_row + w) % C2;
-    const float y = (zr[w] - stat[c]) * stat[C2 + c] * g[c] + b[c];
     const long win = win0 + w / pk;
-    dr[w] = (y > 0.f && pool_idx[win] == h * W + w) ? dpool[win] : 0.f;
+    dr[w] = (pooled[win] > 0.f && pool_idx[win] == h * W + w) ? dpool[win] : 0.f;
   }
 }
 
@@ -1488,10 +1481,11 @@ int gen_expand_tdx(GenModel *g, int n, hipStream_t s) {
 // MaxPool2DLayer::backward + ReLU mask as the dense array [n*P, C2] the reference holds between the pooling
 // layer and the projector (vit_cnn.hpp:225-233); the step itself never needs it
 int gen_expand_du(GenModel *g, const float *arena, const vt_layout *lo, int n, hipStream_t s) {
-  auto W = [&](const char *name) { return arena + lo->t[vt_find(lo, name)].offset; };
   const long rows = (long)n * g->C2 * g->H;
-  hipLaunchKernelGGL(k_pool_bwd, dim3((unsigned)((rows + 3) / 4)), dim3(GT), 0, s, g->z, g->stat_pn, W("proj.norm.gamma"),
-                     W("proj.norm.beta"), g->dpool, g->pool_idx, g->du, rows, g->C2, g->H, g->pk);
+  (void)arena;
+  (void)lo;
+  hipLaunchKernelGGL(k_pool_bwd, dim3((unsigned)((rows + 3) / 4)), dim3(GT), 0, s, g->pooled, g->dpool, g->pool_idx, g->du, rows,
+                     g->H, g->pk);
   VT_CHECK_LAUNCH();
   return 0;
 }
