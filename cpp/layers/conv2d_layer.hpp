@@ -4,7 +4,7 @@
 // ("im2col": one row per output pixel holding its Ci*kh*kw window, zeros outside the image):
 //   forward   out_rows = col . W^T + b                     (:35-87)
 //   backward  gW = delta_rows^T . col, gb = column sums,   (:115-147)
-//             input deltas = fold(delta_rows . W)          (:150-190)
+//             input deltas = fold(delta_rows . W_flipped)  (:150-190; the reference flips the kernel here)
 // get_type() is not overridden: a checkpoint names this layer "Layer" (layers/layer.hpp:29).
 #pragma once
 #include "dense_layer.hpp"
@@ -66,7 +66,18 @@ class Conv2DLayer : public Layer {
     const Tensor rows = delta.reshape({N, out_channels, Ho_ * Wo_}).transpose({0, 2, 1}).reshape({N * Ho_ * Wo_, out_channels});
     grad_weights = rows.matmul_tn(col_).reshape(weights.shape);
     grad_biases = rows.sum(0);
-    const Tensor dcol = rows.matmul(weights.reshape({out_channels, CK}));  // [rows, CK]
+    // The reference scatters delta * W[co][ci][K-1-kh][K-1-kw] to padded position (ho*stride + kh, wo*stride + kw)
+    // (:150-176): the kernel is flipped where the forward pass (:62-81) used it unflipped, so the input delta is the
+    // gradient of a convolution with the flipped kernel.  Reproduced as is (a model's first convolution never uses it;
+    // the CNN model's second one does).
+    Tensor flipped(weights.shape);
+    for (int co = 0; co < out_channels; ++co)
+      for (int ci = 0; ci < in_channels; ++ci)
+        for (int kh = 0; kh < kernel_h; ++kh)
+          for (int kw = 0; kw < kernel_w; ++kw)
+            flipped.data[((size_t)(co * in_channels + ci) * kernel_h + kh) * kernel_w + kw] =
+                weights.data[((size_t)(co * in_channels + ci) * kernel_h + (kernel_h - 1 - kh)) * kernel_w + (kernel_w - 1 - kw)];
+    const Tensor dcol = rows.matmul(flipped.reshape({out_channels, CK}));  // [rows, CK]
     input_deltas = Tensor::zeros(input.shape);
     for_each_window_element([&](long row, int c, long src) { input_deltas.data[src] += dcol.data[row * CK + c]; });
   }

@@ -16,6 +16,8 @@ class MLP : public Model {
     for (Layer *l : layers)
       if (l->has_weights()) l->set_optimizer(new SGD(0.01f));
   }
+  // the input is taken as [batch, 784] whatever its shape (:130-138)
+  Tensor forward(const Tensor &input) override { return Model::forward(input.reshape({input.shape.at(0), 784})); }
   void backward(const Tensor &target) override {
     layers.back()->backward(&target, nullptr);
     for (int i = (int)layers.size() - 2; i >= 0; --i) layers[i]->backward(nullptr, layers[i + 1]);

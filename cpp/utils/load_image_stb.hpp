@@ -1,7 +1,7 @@
 // load_image_as_vector with the reference's signature, texts and pixel values
-// (utils/load_image_stb.hpp:9-26: stbi_load(..., 1) then pixel / 255.0f).  The PNG decode is the C
-// ABI's vt_image_read_gray, which reproduces that decoder's grey conversion for every PNG colour
-// type; JPEG files are rejected with the reference's "could not load" text.
+// (utils/load_image_stb.hpp:9-26: stbi_load(..., 1) then pixel / 255.0f).  The decode is the C ABI's
+// vt_image_read_gray, which reproduces that decoder's grey byte for every PNG colour type and for baseline
+// JPEG files; what it does not decode is rejected with the reference's "could not load" text.
 #pragma once
 #include <stdexcept>
 #include <string>

@@ -264,11 +264,12 @@ int vt_model_load_v2(vt_model *m, vt_train_state *state, const char *path);
 int vt_idx_read_images(const char *path, int max_images, float *out, int *n, int *rows, int *cols);
 int vt_idx_read_labels(const char *path, int max_labels, int *out, int *n);
 /* load_image_as_vector's decode step (utils/load_image_stb.hpp:9-26: stbi_load(path, &w, &h, &n, 1)):
- * one grey byte per pixel of a PNG file, mapped from every PNG colour type and depth exactly as
- * that decoder maps them ((77 r + 150 g + 29 b) >> 8 for colour, alpha dropped, 16-bit samples cut
- * to their high byte).  Host only.  out == NULL queries the size; capacity = bytes available at out.
- * VT_EIO: cannot open; VT_EFORMAT: not a decodable PNG; VT_EUNSUPPORTED: a JPEG file (the reference
- * accepts .jpg through the same decoder; JPEG is not decoded here). */
+ * one grey byte per pixel of a PNG or baseline JPEG file.  PNG: mapped from every colour type and depth exactly as
+ * that decoder maps them ((77 r + 150 g + 29 b) >> 8 for colour, alpha dropped, 16-bit samples cut to their high
+ * byte).  JPEG (sequential Huffman, 8-bit): the decoder's integer inverse DCT bit for bit; the luma plane of a YCbCr
+ * file, the same grey formula on an RGB-coded one.  Host only.  out == NULL queries the size; capacity = bytes
+ * available at out.  VT_EIO: cannot open; VT_EFORMAT: neither a decodable PNG nor JPEG; VT_EUNSUPPORTED: a JPEG
+ * file in a mode that is not decoded here (progressive or arithmetic coding, four components, subsampled luma). */
 int vt_image_read_gray(const char *path, unsigned char *out, int capacity, int *width, int *height);
 /* DataLoader shuffling (utils/load_dataset.hpp:112-127, 155-159): indices = iota(n), shuffled
  * once by the constructor and once more by every reset(), all from one mt19937(seed) with

@@ -534,11 +534,92 @@ static int cmd_selfattn(int argc, char **argv)
   return 0;
 }
 
+// models <out.bundle> <N> <seed>: one training step (forward, backward, update_weights(32), zero_grad:
+// utils/trainer.hpp:41-56) of the reference's two other models, CNN (model/cnn.hpp:13-119) and MLP (model/mlp.hpp:13-178,
+// with its DropoutLayer, layers/dropout_layer.hpp:4-52), each constructed right after Tensor::set_seed(42), on one
+// synthetic batch; dumps the weights before and after, the gradients, the training-mode probabilities of the step,
+// those of a second training-mode forward (for the MLP a second dropout mask from the generator as it then stands)
+// and the eval-mode probabilities.
+template <typename M>
+static void model_step(Bundle &b, const std::string &pfx, M &m, const Tensor &X, const Tensor &yoh)
+{
+  auto dump = [&](const std::string &tag, bool grads) {
+    int li = 0;
+    for (Layer *l : m.layers)
+    {
+      const std::string n = pfx + "." + tag + ".l" + std::to_string(li++);
+      if (auto *d = dynamic_cast<DenseLayer *>(l))
+      {
+        b.put(n + ".W", grads ? d->grad_weights : d->weights);
+        b.put(n + ".b", grads ? d->grad_bias : d->bias);
+      }
+      else if (auto *c = dynamic_cast<Conv2DLayer *>(l))
+      {
+        b.put(n + ".W", grads ? c->grad_weights : c->weights);
+        b.put(n + ".b", grads ? c->grad_biases : c->biases);
+      }
+      else if (auto *n2 = dynamic_cast<BatchNorm2DLayer *>(l))
+      {
+        b.put(n + ".gamma", grads ? n2->grad_gamma : n2->gamma);
+        b.put(n + ".beta", grads ? n2->grad_beta : n2->beta);
+        if (!grads)
+        {
+          b.put(n + ".running_mean", n2->running_mean);
+          b.put(n + ".running_var", n2->running_var);
+        }
+      }
+    }
+  };
+  dump("p0", false);
+  b.put(pfx + ".preds", m.forward(X));
+  m.backward(yoh);
+  dump("g", true);
+  m.update_weights(32.0f);
+  m.zero_grad();
+  dump("p1", false);
+  b.put(pfx + ".preds2", m.forward(X));
+  m.set_training(false);
+  b.put(pfx + ".preds_eval", m.forward(X));
+  m.set_training(true);
+}
+
+static int cmd_models(int argc, char **argv)
+{
+  const int N = std::atoi(argv[3]);
+  const unsigned seed = (unsigned)std::atoi(argv[4]);
+  Bundle b(argv[2]);
+  for (int which = 0; which < 2; ++which)
+  {
+    const int K = which == 0 ? 10 : 8;
+    std::vector<float> xs;
+    std::vector<int> ys;
+    synth_batch(N, 1, 784, K, seed + (unsigned)which, xs, ys);
+    Tensor X({N, 1, 28, 28}, xs);
+    std::vector<float> yf(ys.begin(), ys.end());
+    Tensor yoh = Tensor::one_hot(Tensor({N, 1}, yf), K);
+    const std::string pfx = which == 0 ? "cnn" : "mlp";
+    b.put(pfx + ".X", X);
+    b.puti(pfx + ".labels", ys);
+    Tensor::set_seed(42);
+    if (which == 0)
+    {
+      CNN m;
+      model_step(b, pfx, m, X, yoh);
+    }
+    else
+    {
+      MLP m;
+      model_step(b, pfx, m, X, yoh);
+    }
+  }
+  return 0;
+}
+
 int main(int argc, char **argv)
 {
   if (argc < 2)
   {
-    std::fprintf(stderr, "usage: ref_harness step|dp|kat|blood|bench|images|traj|mha|selfattn ...\n");
+    std::fprintf(stderr, "usage: ref_harness step|dp|kat|blood|bench|images|traj|mha|selfattn|models ...\n");
     return 2;
   }
   std::string c = argv[1];
@@ -562,6 +643,8 @@ int main(int argc, char **argv)
       return cmd_traj(argc, argv);
     if (c == "selfattn" && argc == 8)
       return cmd_selfattn(argc, argv);
+    if (c == "models" && argc == 5)
+      return cmd_models(argc, argv);
   }
   catch (const std::exception &e)
   {

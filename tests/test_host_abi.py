@@ -252,7 +252,7 @@ def test_png_decode_matches_reference_loader(tmp_path):
     assert lib.vt_image_read_gray(str(junk).encode(), None, 0, C.byref(w), C.byref(h)) == -5
     jpg = tmp_path / "a.jpg"
     jpg.write_bytes(b"\xff\xd8\xff\xe0" + b"\0" * 64)
-    assert lib.vt_image_read_gray(str(jpg).encode(), None, 0, C.byref(w), C.byref(h)) == -2
+    assert lib.vt_image_read_gray(str(jpg).encode(), None, 0, C.byref(w), C.byref(h)) == -5  # a JPEG start, then junk
     cut = tmp_path / "cut.png"
     data = open(os.path.join(folder, "rgb16.png"), "rb").read()
     cut.write_bytes(data[:len(data) // 2])
@@ -271,6 +271,58 @@ def test_png_decode_matches_reference_loader(tmp_path):
     assert ds.images.shape == (2, 784)
     assert np.array_equal(ds.images[0], g["images"][names.index("gray08.png")])
     assert np.array_equal(ds.images[1], g["images"][names.index("rgb16.png")])
+
+
+def test_jpeg_decode_matches_reference_loader(tmp_path):
+    """vt_image_read_gray on baseline JPEG files against the real reference's load_image_as_vector
+    (utils/load_image_stb.hpp:9-26, stbi_load(..., 1)): 14 files made by tools/make_jpeg_golden.py (grey; YCbCr 4:4:4,
+    4:2:2 and 4:2:0, whose grey output is the luma plane; restart intervals; one scan per component; 16-bit quantiser
+    tables; flat Huffman tables; RGB-coded files by component ids and by an Adobe segment; blocks that saturate the
+    clamp), every pixel bit-exact.  When the harness is present (build container) it is run again on the same folder.
+    Modes that are not decoded (progressive, arithmetic, four components, subsampled luma) are refused, not guessed."""
+    import subprocess
+    from vit_amd._lib import lib
+    from vit_amd.engine import load_custom_images_from_folder, load_image_as_vector
+    g = np.load(os.path.join(GOLD, "jpeg_expected.npz"))
+    folder = os.path.join(GOLD, "jpeg")
+    names = [str(n) for n in g["names"]]
+    assert sorted(os.listdir(folder)) == names and len(names) == 14
+    for nm, exp in zip(names, g["images"]):
+        got = load_image_as_vector(os.path.join(folder, nm))
+        assert got.dtype == np.float32 and np.array_equal(got, exp), nm
+    ds = load_custom_images_from_folder(folder)
+    assert np.array_equal(ds.images, g["images"])
+    harness = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+    if os.access(harness, os.X_OK) and os.path.isdir("/root/reference"):
+        out = tmp_path / "ref.bin"
+        subprocess.run([harness, "images", folder + "/", str(out)], check=True, capture_output=True, timeout=60)
+        assert np.array_equal(np.fromfile(str(out), dtype=np.float32).reshape(-1, 784), ds.images)
+    w, h = C.c_int(0), C.c_int(0)
+    data = open(os.path.join(folder, "a_grey.jpg"), "rb").read()
+    sof = data.index(b"\xff\xc0")
+    prog = tmp_path / "progressive.jpg"
+    prog.write_bytes(data[:sof + 1] + b"\xc2" + data[sof + 2:])  # the same frame header announced as progressive
+    assert lib.vt_image_read_gray(str(prog).encode(), None, 0, C.byref(w), C.byref(h)) == -2
+    arith = tmp_path / "arithmetic.jpg"
+    arith.write_bytes(data[:sof + 1] + b"\xc9" + data[sof + 2:])
+    assert lib.vt_image_read_gray(str(arith).encode(), None, 0, C.byref(w), C.byref(h)) == -2
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from make_jpeg_golden import encode
+    rng = np.random.default_rng(3)
+    planes = [rng.integers(0, 256, size=(28, 28), dtype=np.uint8) for _ in range(3)]
+    sub = tmp_path / "luma_subsampled.jpg"
+    sub.write_bytes(encode([planes[0][::2, ::2].copy(), planes[1], planes[2]], [(1, 1), (2, 2), (2, 2)]))
+    assert lib.vt_image_read_gray(str(sub).encode(), None, 0, C.byref(w), C.byref(h)) == -2
+    with pytest.raises(RuntimeError, match="No se pudo cargar la imagen"):
+        load_image_as_vector(str(sub))
+    wide = tmp_path / "wide.jpg"
+    wide.write_bytes(encode([rng.integers(0, 256, size=(19, 45), dtype=np.uint8)], [(1, 1)], width=45, height=19))
+    assert lib.vt_image_read_gray(str(wide).encode(), None, 0, C.byref(w), C.byref(h)) == 0 and (w.value, h.value) == (45, 19)
+    with pytest.raises(RuntimeError, match="28x28"):
+        load_image_as_vector(str(wide))
+    cut = tmp_path / "cut.jpg"
+    cut.write_bytes(data[:sof + 6])
+    assert lib.vt_image_read_gray(str(cut).encode(), None, 0, C.byref(w), C.byref(h)) != 0
 
 
 def test_reference_main_compiles_unchanged_against_the_mirror_headers(tmp_path):

@@ -8,7 +8,7 @@
 //   RGB / RGBA / palette -> (77 r + 150 g + 29 b) >> 8 on the (palette-expanded) colour, alpha and
 //                    tRNS dropped;
 //   16-bit        -> the same formula on 16-bit samples, truncated to 16 bits, then the high byte.
-// PNG is decoded here (zlib inflate + the five scanline filters + Adam7); JPEG is not.
+// PNG is decoded here (zlib inflate + the five scanline filters + Adam7); baseline JPEG in vtcnn_jpeg.hip.
 #include <zlib.h>
 
 #include <cstdint>
@@ -17,6 +17,10 @@
 #include <vector>
 
 #include "../../include/vtcnn_hip.h"
+
+namespace vt {
+int jpeg_decode_gray(const std::vector<unsigned char> &file, std::vector<unsigned char> &out, int *width, int *height);
+}
 
 namespace {
 
@@ -106,7 +110,14 @@ extern "C" int vt_image_read_gray(const char *path, unsigned char *out, int capa
   while ((got = std::fread(buf, 1, sizeof buf, f)) > 0) file.insert(file.end(), buf, buf + got);
   std::fclose(f);
   static const unsigned char sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
-  if (file.size() >= 2 && file[0] == 0xff && file[1] == 0xd8) return VT_EUNSUPPORTED;  // JPEG
+  if (file.size() >= 2 && file[0] == 0xff && file[1] == 0xd8) {  // JPEG
+    std::vector<unsigned char> grey;
+    const int rc = vt::jpeg_decode_gray(file, grey, width, height);
+    if (rc != 0 || !out) return rc;
+    if ((long)grey.size() > capacity) return VT_EINVAL;
+    std::memcpy(out, grey.data(), grey.size());
+    return 0;
+  }
   if (file.size() < 8 || std::memcmp(file.data(), sig, 8) != 0) return VT_EFORMAT;
   Png p;
   std::vector<unsigned char> idat;
