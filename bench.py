@@ -242,8 +242,10 @@ def algorithmic_flops_per_image(d, batch, forward_only=False):
 GENERIC_EMULATION = ("fp32 storage and accumulation; products of depth >= 32 that do not feed an exponential (activation x "
                      "weight, delta x weight, gradient contractions) run as bf16x3 hi/lo split products with fp32 accumulate "
                      "(about 2^-17 relative per product), the others on exact fp32 MFMA; VT_GEMM_EXACT=1 keeps every product exact")
-BF16_EMULATION = ("--bf16: the dense-layer products (feed-forward, projector linear layers, classifier, recomputed q/k/v) round "
-                  "their operands to bf16 (fp32 accumulate); everything else as in the fp32 mode of the general step")
+BF16_EMULATION = ("--bf16: the projector's value projection, the classifier and the backward's recomputed q/k/v projections round "
+                  "their operands to bf16 (fp32 accumulate); products upstream of an exponential (feed-forward block, keys, "
+                  "scores) and everything else as in the fp32 mode of the general step (VT_BF16_PRODUCTS=31 adds them, "
+                  "outside the 1e-2 bar)")
 
 
 def emulation_note(generic, bf16):

@@ -84,14 +84,15 @@ int vt_model_keep_internals(vt_model *m, int on);
 /* VTCNN::set_training (model/vit_cnn.hpp:262-269): only BatchNorm2D honours eval mode; the three
  * BatchNorm1D layers always use batch statistics (layers/visual_transformer.hpp:221). */
 int vt_model_set_training(vt_model *m, int training);
-/* Optional reduced-precision mode of the general-shape step: bf16 != 0 sends the dense-layer products of
- * the feed-forward block, the projector's three linear layers, the classifier and the backward's
- * recomputed query / key / value projections through vt_gemm_bf16_mfma; the convolution, every product
- * that feeds an exponential, the delta products of the backward pass, gradient contractions, statistics
- * and softmax stay fp32.  Predictions, loss and updated weights then agree with the reference to 1e-2
- * instead of 1e-4; gradient tensors to 1e-2 except those upstream of the pooling and fc.W, which reach
- * 2e-2 .. 5e-2 on a two-image batch.  Models of the headline shape run fused fp32 kernels and accept only
- * 0.  No counterpart in the reference. */
+/* Optional reduced-precision mode of the general-shape step: bf16 != 0 sends the projector's value projection
+ * (linear3), the classifier and the backward's recomputed query / key / value projections through vt_gemm_bf16_mfma;
+ * the convolution, every product upstream of an exponential (feed-forward block, projector keys and scores), the
+ * delta products of the backward pass, gradient contractions, statistics and softmax stay fp32.  Predictions, loss,
+ * updated weights and every gradient tensor then agree with exact arithmetic to 1e-2 instead of 1e-4 (gradients under
+ * the run's own pooling decisions).  The feed-forward block and the keys can be added through the environment
+ * (VT_BF16_PRODUCTS=31); their rounding is multiplied by the score magnitudes in the projector's exponential and
+ * leaves seven gradient tensors at 2e-2 .. 4e-2.  Models of the headline shape run fused fp32 kernels and accept
+ * only 0.  No counterpart in the reference. */
 int vt_model_set_matmul_precision(vt_model *m, int bf16);
 /* Launch order of the headline-shape backward.  on != 0 (the default): once the projector's deltas
  * exist, the tokenizer / BatchNorm2D / convolution backward (and the fc weight gradient after it)
