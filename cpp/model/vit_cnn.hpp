@@ -248,6 +248,21 @@ class VTCNN : public Model {
     check(vt_model_backward(h_, d_labels_, stream_), "VTCNN::backward");
     last_n_ = n;
   }
+  // the same in two calls, for a data-parallel caller that exchanges gradients while the backward still runs:
+  // after gradients_main_resident every gradient outside attention_range() is final; gradients_attention() then
+  // writes the attention block's (vt_model_backward_main / vt_model_backward_attention: together the bytes of
+  // vt_model_backward)
+  void gradients_main_resident(const unsigned char *d_images_u8, const int *d_all_labels, const int *d_indices, int n, int slot,
+                               float *d_loss_sums, int *d_correct) {
+    const int pixels = dims_.image_channels * dims_.input_dim * dims_.input_dim;
+    check(vt_loader_gather(d_images_u8, d_all_labels, d_indices, n, pixels, d_in_, d_labels_, stream_), "vt_loader_gather");
+    check(vt_model_forward(h_, d_in_, n, d_probs_, stream_), "VTCNN::forward");
+    check(vt_eval_accumulate(d_probs_, d_labels_, n, dims_.num_classes, slot, d_loss_sums, d_correct, nullptr, nullptr, stream_),
+          "vt_eval_accumulate");
+    check(vt_model_backward_main(h_, d_labels_, stream_), "VTCNN::backward_main");
+    last_n_ = n;
+  }
+  void gradients_attention() { check(vt_model_backward_attention(h_, nullptr, stream_), "VTCNN::backward_attention"); }
   // forward-only over n gathered images that are consecutive loader batches of `group` images each (the last
   // may be short), every batch with its own BatchNorm1D statistics as Trainer::evaluate sees them; per-batch
   // loss sums / correct counts into slots slot0.., confusion matrix and arg-max labels (may be null) on the device

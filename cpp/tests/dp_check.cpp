@@ -89,6 +89,51 @@ int main() {
   CHECK(vt_dp_wait(dp) == 0);
   CHECK(verify());
 
+  // the overlapped form: three buckets per rank on the exchange streams, ordered behind an asynchronous refill of the
+  // buffers on the compute streams and joined before an asynchronous read-back on them
+  {
+    std::vector<std::vector<float>> mine(G, std::vector<float>(n)), got(G, std::vector<float>(n));
+    std::vector<float *> pin_in(G), pin_out(G);
+    for (int r = 0; r < G; ++r) {
+      CHECK(hipSetDevice(r) == hipSuccess);
+      CHECK(hipHostMalloc((void **)&pin_in[r], n * sizeof(float)) == hipSuccess);
+      CHECK(hipHostMalloc((void **)&pin_out[r], n * sizeof(float)) == hipSuccess);
+      for (long i = 0; i < n; ++i) pin_in[r][i] = (r + 1) * pattern[i];
+    }
+    const long cut1 = first + count / 3, cut2 = first + 2 * (count / 3), end = first + count;
+    std::vector<int> brc(G, -100);
+    std::vector<std::thread> bw;
+    for (int r = 0; r < G; ++r)
+      bw.emplace_back([&, r]() {
+        int rc = 0;
+        if (hipSetDevice(r) != hipSuccess) rc = -99;
+        hipStream_t cs = (hipStream_t)streams[r];
+        if (rc == 0 && hipMemcpyAsync(bufs[r], pin_in[r], n * sizeof(float), hipMemcpyHostToDevice, cs) != hipSuccess) rc = -98;
+        // reverse order of the arena, as gradients become final
+        if (rc == 0) rc = vt_dp_exchange_begin(dp, r, bufs[r], cut2, end - cut2, streams[r]);
+        if (rc == 0) rc = vt_dp_exchange_begin(dp, r, bufs[r], cut1, cut2 - cut1, streams[r]);
+        if (rc == 0) rc = vt_dp_exchange_begin(dp, r, bufs[r], first, cut1 - first, streams[r]);
+        if (rc == 0) rc = vt_dp_exchange_join(dp, r, streams[r]);
+        if (rc == 0 && hipMemcpyAsync(pin_out[r], bufs[r], n * sizeof(float), hipMemcpyDeviceToHost, cs) != hipSuccess) rc = -97;
+        if (rc == 0 && hipStreamSynchronize(cs) != hipSuccess) rc = -96;
+        brc[r] = rc;
+      });
+    for (std::thread &w : bw) w.join();
+    for (int r = 0; r < G; ++r) CHECK(brc[r] == 0);
+    const float total = (float)(G * (G + 1) / 2);
+    for (int r = 0; r < G; ++r)
+      for (long i = 0; i < n; ++i) {
+        const bool inside = i >= first && i < first + count;
+        CHECK(pin_out[r][i] == (inside ? total * pattern[i] : (r + 1) * pattern[i]));
+      }
+    CHECK(vt_dp_exchange_begin(dp, G, bufs[0], 0, 4, streams[0]) == VT_EINVAL);
+    CHECK(vt_dp_exchange_join(dp, -1, streams[0]) == VT_EINVAL);
+    for (int r = 0; r < G; ++r) {
+      (void)hipHostFree(pin_in[r]);
+      (void)hipHostFree(pin_out[r]);
+    }
+  }
+
   CHECK(vt_dp_allreduce_async(dp, bufs.data(), -1, 4, streams.data()) == VT_EINVAL);
   CHECK(vt_dp_allreduce_rank_async(dp, G, bufs[0], 0, 4, streams[0]) == VT_EINVAL);
   CHECK(vt_dp_allreduce_async(dp, bufs.data(), 0, 0, streams.data()) == 0);

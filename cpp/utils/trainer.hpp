@@ -9,6 +9,7 @@
 
 #include <cstdlib>
 #include <exception>
+#include <map>
 #include <memory>
 #include <thread>
 
@@ -173,8 +174,24 @@ class Trainer {
     std::vector<unsigned char *> images;           // rank -> resident u8 image matrix on that rank's device
     std::vector<int *> labels, indices;
     int trainable = 0;
+    // bucket boundaries of the overlapped exchange inside the gradient arena: [0, att_first) BatchNorm2D + convolution,
+    // [att_first, att_end) the attention block, [att_end, fc_first) projector + feed-forward + norms, [fc_first, trainable) fc
+    int att_first = 0, att_end = 0, fc_first = 0;
+    bool overlap = false;
+    // per evaluated loader and rank: a copy of its resident dataset on that rank's device (rank 0: the loader's own)
+    struct EvalCopy {
+      std::vector<unsigned char *> images;
+      std::vector<int *> labels, indices;
+    };
+    std::map<const DataLoader *, EvalCopy> eval_copies;
     ~DataParallel() {
-      for (size_t r = 1; r < models.size(); ++r) {  // rank 0's buffers belong to the loader
+      for (auto &kv : eval_copies)
+        for (size_t r = 1; r < kv.second.images.size(); ++r) {
+          (void)hipFree(kv.second.images[r]);
+          (void)hipFree(kv.second.labels[r]);
+          (void)hipFree(kv.second.indices[r]);
+        }
+      for (size_t r = 1; r < images.size(); ++r) {  // rank 0's buffers belong to the loader
         (void)hipFree(images[r]);
         (void)hipFree(labels[r]);
         (void)hipFree(indices[r]);
@@ -205,34 +222,51 @@ class Trainer {
     vt_layout lo;
     vt_model_layout(m.handle(), &lo);
     g->trainable = lo.n_trainable;
-    const DataLoader::Resident &r0 = train_loader.resident(m.stream());
-    const size_t count = train_loader.size(), bytes = count * (size_t)r0.pixels;
+    {
+      int count = 0;
+      vt_model_attention_range(m.handle(), &g->att_first, &count);
+      g->att_end = g->att_first + count;
+      g->fc_first = lo.t[vt_find(&lo, "fc.W")].offset;
+      const char *ov = std::getenv("VTCNN_DP_OVERLAP");
+      g->overlap = ov && *ov && *ov != '0';
+    }
     g->models.push_back(&m);
-    g->images.push_back(r0.images_u8);
-    g->labels.push_back(r0.labels);
-    g->indices.push_back(r0.indices);
     for (int r = 1; r < G; ++r) {
       g->replicas.push_back(m.replica_on(devices[r]));
       g->models.push_back(g->replicas.back().get());
-      vt_host::DeviceScope on_device(devices[r]);
+    }
+    dp_ = std::move(g);
+    return dp_.get();
+  }
+  // every rank's copy of the resident training set (rank 0: the loader's own), made before the first training epoch
+  void replicate_training_set(DataParallel &g) {
+    if (!g.images.empty()) return;
+    VTCNN &m = *g.models[0];
+    const DataLoader::Resident &r0 = train_loader.resident(m.stream());
+    const size_t count = train_loader.size(), bytes = count * (size_t)r0.pixels;
+    g.images.push_back(r0.images_u8);
+    g.labels.push_back(r0.labels);
+    g.indices.push_back(r0.indices);
+    for (size_t r = 1; r < g.models.size(); ++r) {
+      const int dev = g.models[r]->device();
+      vt_host::DeviceScope on_device(dev);
       unsigned char *img = nullptr;
       int *lab = nullptr, *idx = nullptr;
       vt_host::hip_check(hipMalloc((void **)&img, bytes), "hipMalloc dataset");
       vt_host::hip_check(hipMalloc((void **)&lab, count * sizeof(int)), "hipMalloc labels");
       vt_host::hip_check(hipMalloc((void **)&idx, count * sizeof(int)), "hipMalloc indices");
-      g->images.push_back(img);
-      g->labels.push_back(lab);
-      g->indices.push_back(idx);
-      vt_host::hip_check(hipMemcpyPeer(img, devices[r], r0.images_u8, m.device(), bytes), "dataset to peer");
-      vt_host::hip_check(hipMemcpyPeer(lab, devices[r], r0.labels, m.device(), count * sizeof(int)), "labels to peer");
+      g.images.push_back(img);
+      g.labels.push_back(lab);
+      g.indices.push_back(idx);
+      vt_host::hip_check(hipMemcpyPeer(img, dev, r0.images_u8, m.device(), bytes), "dataset to peer");
+      vt_host::hip_check(hipMemcpyPeer(lab, dev, r0.labels, m.device(), count * sizeof(int)), "labels to peer");
     }
-    dp_ = std::move(g);
-    return dp_.get();
   }
   long train_epoch_data_parallel(DataParallel &g, Pass &p) {
     const size_t total = train_loader.size(), bs = train_loader.batch(), nb = train_loader.total_batches();
     const size_t G = g.models.size(), rounds = nb / G;
     if (rounds == 0) throw std::runtime_error("VTCNN_GPUS: the training set has fewer batches than GPUs");
+    replicate_training_set(g);
     (void)train_loader.resident(g.models[0]->stream());  // this epoch's order on rank 0's device
     std::vector<std::vector<float>> ls(G, std::vector<float>(rounds));
     std::vector<std::vector<int>> ok(G, std::vector<int>(rounds));
@@ -246,9 +280,27 @@ class Trainer {
                                             m.stream()), "H2D indices");
         for (size_t t = 0; t < rounds; ++t) {
           const size_t first = (t * G + r) * bs, n = std::min(bs, total - first);
-          m.gradients_resident(g.images[r], g.labels[r], g.indices[r] + first, (int)n, (int)t, dc.loss_sums, dc.correct);
-          const int rc = vt_dp_allreduce_rank_async(g.dp, (int)r, vt_model_grads_ptr(m.handle()), 0, g.trainable, m.stream());
-          if (rc != 0) throw std::runtime_error(std::string("vt_dp_allreduce_rank_async: ") + vt_error_string(rc));
+          float *grads = vt_model_grads_ptr(m.handle());
+          if (g.overlap) {
+            // VTCNN_DP_OVERLAP=1: the exchange in buckets on a stream of its own, in the order in which gradients
+            // become final, beside the attention backward (the longest kernels of the step); the update waits for all
+            auto bucket = [&](int lo_, int hi_) {
+              const int rc = vt_dp_exchange_begin(g.dp, (int)r, grads, lo_, hi_ - lo_, m.stream());
+              if (rc != 0) throw std::runtime_error(std::string("vt_dp_exchange_begin: ") + vt_error_string(rc));
+            };
+            m.gradients_main_resident(g.images[r], g.labels[r], g.indices[r] + first, (int)n, (int)t, dc.loss_sums, dc.correct);
+            bucket(g.fc_first, g.trainable);
+            bucket(g.att_end, g.fc_first);
+            bucket(0, g.att_first);
+            m.gradients_attention();
+            bucket(g.att_first, g.att_end);
+            const int rc = vt_dp_exchange_join(g.dp, (int)r, m.stream());
+            if (rc != 0) throw std::runtime_error(std::string("vt_dp_exchange_join: ") + vt_error_string(rc));
+          } else {
+            m.gradients_resident(g.images[r], g.labels[r], g.indices[r] + first, (int)n, (int)t, dc.loss_sums, dc.correct);
+            const int rc = vt_dp_allreduce_rank_async(g.dp, (int)r, grads, 0, g.trainable, m.stream());
+            if (rc != 0) throw std::runtime_error(std::string("vt_dp_allreduce_rank_async: ") + vt_error_string(rc));
+          }
           m.update_weights((float)(G * (size_t)batch_size));
         }
         vt_host::hip_check(hipMemcpyAsync(ls[r].data(), dc.loss_sums, sizeof(float) * rounds, hipMemcpyDeviceToHost, m.stream()), "D2H");
@@ -281,9 +333,96 @@ class Trainer {
     return images;
   }
 
+  // Evaluation sharded over the replicas ("replicas only": no collective).  The chunks of consecutive loader batches
+  // that sweep_resident would run one after another are dealt round-robin to the ranks, each on its own device with a
+  // copy of rank 0's weights and BatchNorm2D running statistics; every loader batch keeps its own BatchNorm1D
+  // statistics, so the per-batch losses, hit counts and predicted labels are what the single-device sweep computes.
+  // The ranks' per-batch numbers and label arrays are merged on the host by owner.
+  Pass sweep_data_parallel(DataParallel &g, DataLoader &loader, bool keep_labels) {
+    Pass p;
+    const size_t total = loader.size(), bs = loader.batch(), nb = loader.total_batches(), G = g.models.size();
+    VTCNN &m0 = *g.models[0];
+    const DataLoader::Resident &r0 = loader.resident(m0.stream());
+    DataParallel::EvalCopy &ec = g.eval_copies[&loader];
+    if (ec.images.empty()) {
+      const size_t bytes = total * (size_t)r0.pixels;
+      ec.images.assign(G, nullptr);
+      ec.labels.assign(G, nullptr);
+      ec.indices.assign(G, nullptr);
+      ec.images[0] = r0.images_u8;
+      ec.labels[0] = r0.labels;
+      for (size_t r = 1; r < G; ++r) {
+        vt_host::DeviceScope on_device(g.models[r]->device());
+        vt_host::hip_check(hipMalloc((void **)&ec.images[r], bytes), "hipMalloc dataset");
+        vt_host::hip_check(hipMalloc((void **)&ec.labels[r], total * sizeof(int)), "hipMalloc labels");
+        vt_host::hip_check(hipMalloc((void **)&ec.indices[r], total * sizeof(int)), "hipMalloc indices");
+        vt_host::hip_check(hipMemcpyPeer(ec.images[r], g.models[r]->device(), r0.images_u8, m0.device(), bytes), "dataset to peer");
+        vt_host::hip_check(hipMemcpyPeer(ec.labels[r], g.models[r]->device(), r0.labels, m0.device(), total * sizeof(int)), "labels to peer");
+      }
+    }
+    ec.indices[0] = r0.indices;
+    for (size_t r = 1; r < G; ++r) g.models[r]->copy_weights_from(m0);  // also rank 0's running statistics
+    const size_t per_chunk = (bs % 4 == 0) ? std::max<size_t>(1, (size_t)m0.max_batch() / bs) : 1;
+    std::vector<std::vector<float>> ls(G, std::vector<float>(nb));
+    std::vector<std::vector<int>> ok(G, std::vector<int>(nb)), am(G);
+    auto rank_sweep = [&](size_t r) {
+      try {
+        VTCNN &m = *g.models[r];
+        vt_host::DeviceScope on_device(m.device());
+        DeviceCounters dc((int)nb, num_classes, (int)total);
+        if (r > 0)
+          vt_host::hip_check(hipMemcpyAsync(ec.indices[r], loader.order().data(), total * sizeof(int), hipMemcpyHostToDevice, m.stream()),
+                             "H2D indices");
+        m.set_training(false);
+        size_t chunk = 0;
+        for (size_t b0 = 0; b0 < nb; b0 += per_chunk, ++chunk) {
+          if (chunk % G != r) continue;
+          const size_t first = b0 * bs, n = std::min(per_chunk * bs, total - first);
+          m.eval_chunk_resident(ec.images[r], ec.labels[r], ec.indices[r] + first, (int)n, (int)bs, (int)b0, dc.loss_sums, dc.correct,
+                                dc.confusion, dc.argmax + first);
+        }
+        m.set_training(true);
+        vt_host::hip_check(hipMemcpyAsync(ls[r].data(), dc.loss_sums, sizeof(float) * nb, hipMemcpyDeviceToHost, m.stream()), "D2H");
+        vt_host::hip_check(hipMemcpyAsync(ok[r].data(), dc.correct, sizeof(int) * nb, hipMemcpyDeviceToHost, m.stream()), "D2H");
+        if (keep_labels) {
+          am[r].resize(total);
+          vt_host::hip_check(hipMemcpyAsync(am[r].data(), dc.argmax, sizeof(int) * total, hipMemcpyDeviceToHost, m.stream()), "D2H");
+        }
+        vt_host::hip_check(hipStreamSynchronize(m.stream()), "sync");
+      } catch (const std::exception &e) {
+        std::cerr << "❌ evaluation on rank " << r << " failed: " << e.what() << std::endl;
+        std::_Exit(3);
+      }
+    };
+    std::vector<std::thread> workers;
+    for (size_t r = 1; r < G; ++r) workers.emplace_back(rank_sweep, r);
+    rank_sweep(0);
+    for (std::thread &w : workers) w.join();
+    std::vector<float> lsm(nb);
+    std::vector<int> okm(nb);
+    if (keep_labels) {
+      p.pred.resize(total);
+      p.truth.resize(total);
+      for (size_t i = 0; i < total; ++i) p.truth[i] = loader.all_labels()[loader.order()[i]];
+    }
+    for (size_t b = 0; b < nb; ++b) {
+      const size_t owner = (b / per_chunk) % G;
+      lsm[b] = ls[owner][b];
+      okm[b] = ok[owner][b];
+      if (keep_labels)
+        for (size_t i = b * bs; i < std::min(total, (b + 1) * bs); ++i) p.pred[i] = am[owner][i];
+    }
+    fold_batches(lsm, okm, total, bs, p);
+    loader.skip_to_end();
+    return p;
+  }
+
   // forward-only sweep over a loader in eval mode
   Pass sweep(DataLoader &loader, bool keep_labels) {
-    if (VTCNN *m = device_model(loader)) return sweep_resident(*m, loader, keep_labels);
+    if (VTCNN *m = device_model(loader)) {
+      if (DataParallel *g = data_parallel(*m)) return sweep_data_parallel(*g, loader, keep_labels);
+      return sweep_resident(*m, loader, keep_labels);
+    }
     Pass p;
     model.set_training(false);
     while (loader.has_next()) {

@@ -628,6 +628,16 @@ int vt_dp_allreduce_async(vt_dp *dp, float *const *d_bufs, long first, long coun
  * thread makes this call with the same first / count, in the same order; the exchange runs once all of
  * them have.  Calls for different ranks may run concurrently; calls for one rank may not. */
 int vt_dp_allreduce_rank_async(vt_dp *dp, int rank, float *d_buf, long first, long count, vt_stream stream);
+/* The same share as an OVERLAPPED exchange, in buckets.  vt_dp_exchange_begin orders the sum of floats
+ * [first, first + count) of d_buf behind what `compute` (rank's compute stream) holds at the time of the call and runs
+ * it on a stream of the exchange's own, so that kernels issued on `compute` afterwards run beside it: a caller issues
+ * one bucket per group of gradients as soon as they are final (vt_model_backward_main leaves everything but the
+ * attention block final: fc | projector + feed-forward | BatchNorm2D + convolution, then vt_model_backward_attention,
+ * then the attention block), and vt_dp_exchange_join makes `compute` wait for every bucket begun so far before the
+ * update reads the sums.  Every rank's thread issues the same buckets in the same order.  Buckets of one rank run one
+ * after another on its exchange stream. */
+int vt_dp_exchange_begin(vt_dp *dp, int rank, float *d_buf, long first, long count, vt_stream compute);
+int vt_dp_exchange_join(vt_dp *dp, int rank, vt_stream compute);
 /* Blocks the host until the exchanges issued so far have finished on every rank.  Work issued on
  * streams[r] after vt_dp_allreduce_async is ordered behind the exchange without this call. */
 int vt_dp_wait(vt_dp *dp);

@@ -164,6 +164,13 @@ def test_cpp_cli_predict_matches_reference(tmp_path):
     assert mt, line
     assert abs(float(mt.group(1)) - float(g["loss"][0])) < 2e-4 * max(1.0, float(g["loss"][0])), line
     assert abs(float(mt.group(2)) - 100.0 * float(g["acc"][0])) < 1e-3, line
+    # the same sweep dealt over the data-parallel replicas (one replica here): same labels, same printed numbers
+    out2 = tmp_path / "labels_dp.txt"
+    r2 = subprocess.run([exe, "bloodmnist", "predict"], env=dict(env, VTCNN_LABELS_OUT=str(out2), VTCNN_GPUS="1", VTCNN_DP_FORCE="1"),
+                        capture_output=True, text=True, timeout=110)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    assert np.array_equal(np.loadtxt(str(out2), dtype=np.int32), g["pred"])
+    assert [s for s in r2.stdout.splitlines() if s.startswith("[TEST]")][0] == line
 
 
 def test_cpp_cli_train_one_epoch_runs_and_saves(tmp_path):
@@ -215,6 +222,15 @@ def test_cpp_cli_train_one_epoch_runs_and_saves(tmp_path):
     assert ck.read_bytes() == first
     assert numbers(r3.stdout, "Train Loss:") == numbers(r.stdout, "Train Loss:")
     assert cm(r3.stdout) == cm(r.stdout)
+    # ... and so is its overlapped form: backward in two calls, the exchange in four buckets on a stream of its own
+    # beside the attention backward, evaluation sweeps dealt over the replicas
+    r5 = subprocess.run([exe, "bloodmnist", "train", "1"], env=dict(env, VTCNN_GPUS="1", VTCNN_DP_FORCE="1", VTCNN_DP_OVERLAP="1"),
+                        capture_output=True, text=True, timeout=110)
+    assert r5.returncode == 0, r5.stderr[-2000:]
+    assert ck.read_bytes() == first
+    assert numbers(r5.stdout, "Train Loss:") == numbers(r.stdout, "Train Loss:")
+    assert numbers(r5.stdout, "Val Loss:") == numbers(r.stdout, "Val Loss:")
+    assert cm(r5.stdout) == cm(r.stdout)
     # VTCNN_GPUS=1 without the test switch has nothing to exchange and never opens the collective library
     r4 = subprocess.run([exe, "bloodmnist", "train", "1"], env=dict(env, VTCNN_GPUS="1", VT_RCCL_LIBRARY="/nonexistent/librccl.so"),
                         capture_output=True, text=True, timeout=110)
@@ -402,3 +418,45 @@ def test_single_image_graph_replay_matches_eager():
         torch.cuda.synchronize()
         assert np.array_equal(out.cpu().numpy(), pa), k
     assert np.array_equal(a.get_arena(), b.get_arena())  # running statistics moved the same way
+
+
+def _sharded_eval_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)  # two ranks share the one GPU here, which RCCL refuses
+    from vit_amd import VTCNN, Dims
+    from vit_amd.engine import DataLoader, Trainer, load_dataset
+    img, lbl, ckpt = _paths()
+    ds = load_dataset(img, lbl, 10000)
+    m = VTCNN(Dims(num_classes=8), max_batch=96, seed=42)
+    m.load(ckpt)
+    if rank == 1:  # a rank whose BatchNorm2D running statistics drifted: the sweep must evaluate rank 0's model
+        a = m.get_arena()
+        lo = m.layout.tensors["bn.running_mean"]
+        a[lo[0]:lo[0] + lo[1]] += 0.5
+        m.set_arena(a)
+    lines = []
+    t = Trainer(m, None, None, 8, 32, test_loader=DataLoader(ds.images_u8, ds.labels, 32), out=lines.append, world=world, rank=rank)
+    loss, acc, pred, truth, cm = t.evaluate_test()
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), loss=loss, acc=acc, pred=pred, truth=truth, cm=cm, nlines=len(lines))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_python_trainer_sharded_evaluation(tmp_path):
+    """Trainer.evaluate_test with world 2 ("replicas only": chunks of loader batches dealt to the ranks, per-batch
+    numbers, labels and confusion matrix merged by one sum): every rank ends with the single-process sweep's loss,
+    accuracy, labels and confusion matrix, i.e. the reference's own numbers for the shipped checkpoint; only rank 0
+    prints.  Two processes on the one GPU, merged over gloo."""
+    import socket
+    import torch.multiprocessing as mp
+    g = load_golden("blood_t10k_256.npz")
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    mp.spawn(_sharded_eval_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r = [dict(np.load(os.path.join(str(tmp_path), "rank%d.npz" % k))) for k in range(2)]
+    for k in range(2):
+        assert np.array_equal(r[k]["pred"], g["pred"]), k
+        assert abs(float(r[k]["loss"]) - float(g["loss"][0])) < 2e-4 * max(1.0, float(g["loss"][0]))
+        assert abs(float(r[k]["acc"]) - float(g["acc"][0])) < 1e-5
+        assert int(r[k]["cm"].sum()) == 256 and np.array_equal(r[k]["cm"], r[0]["cm"])
+    assert int(r[0]["nlines"]) > 10 and int(r[1]["nlines"]) == 0

@@ -117,6 +117,8 @@ SIGNATURES = {
     "vt_dp_ranks": (i, [p]),
     "vt_dp_allreduce_async": (i, [p, p, l, l, p]),
     "vt_dp_allreduce_rank_async": (i, [p, i, p, l, l, p]),
+    "vt_dp_exchange_begin": (i, [p, i, p, l, l, p]),
+    "vt_dp_exchange_join": (i, [p, i, p]),
     "vt_dp_wait": (i, [p]),
     "vt_bn_bwd_finalize": (i, [p, i, i, l, p, p, p, p, p, p, p]),
     "vt_bn_bwd_finalize_grouped": (i, [p, i, i, i, l, l, p, p, p, p, p, p]),

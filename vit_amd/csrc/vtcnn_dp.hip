@@ -69,6 +69,10 @@ struct vt_dp {
   std::vector<nccl_comm> comms;
   std::vector<hipEvent_t> done;  // one per rank: end of the last exchange issued on that rank's stream
   std::vector<char> issued;      // per rank, so that one host thread per rank may issue without sharing a flag
+  // overlapped exchange (vt_dp_exchange_begin / _join): a stream of the exchange's own per rank, and the event that
+  // orders it behind the compute stream
+  std::vector<hipStream_t> side;
+  std::vector<hipEvent_t> ready;
 };
 
 extern "C" {
@@ -94,6 +98,8 @@ int vt_dp_init(int ranks, const int *device_ids, vt_dp **out) {
     dp->comms.assign(ranks, nullptr);
     dp->done.assign(ranks, nullptr);
     dp->issued.assign(ranks, 0);
+    dp->side.assign(ranks, nullptr);
+    dp->ready.assign(ranks, nullptr);
   } catch (...) {
     delete dp;
     return VT_ENOMEM;
@@ -106,7 +112,9 @@ int vt_dp_init(int ranks, const int *device_ids, vt_dp **out) {
   }
   for (int r = 0; r < ranks; ++r) {
     if (hipSetDevice(dp->devices[r]) != hipSuccess ||
-        hipEventCreateWithFlags(&dp->done[r], hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&dp->done[r], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&dp->ready[r], hipEventDisableTiming) != hipSuccess ||
+        hipStreamCreateWithFlags(&dp->side[r], hipStreamNonBlocking) != hipSuccess) {
       (void)hipSetDevice(keep);
       vt_dp_destroy(dp);
       return VT_ENOMEM;
@@ -125,6 +133,8 @@ int vt_dp_destroy(vt_dp *dp) {
     (void)hipSetDevice(dp->devices[r]);
     (void)hipDeviceSynchronize();
     if (dp->done[r]) (void)hipEventDestroy(dp->done[r]);
+    if (dp->ready[r]) (void)hipEventDestroy(dp->ready[r]);
+    if (dp->side[r]) (void)hipStreamDestroy(dp->side[r]);
     if (dp->comms[r]) g_rccl.CommDestroy(dp->comms[r]);
   }
   (void)hipSetDevice(keep);
@@ -178,6 +188,35 @@ int vt_dp_allreduce_rank_async(vt_dp *dp, int rank, float *d_buf, long first, lo
   if (ev != hipSuccess) return VT_EIO;
   dp->issued[rank] = 1;
   return 0;
+}
+
+// One bucket of an overlapped exchange: the sum runs on the rank's exchange stream behind everything the compute
+// stream holds at the time of the call, while later work on the compute stream runs beside it.
+int vt_dp_exchange_begin(vt_dp *dp, int rank, float *d_buf, long first, long count, vt_stream compute) {
+  if (!dp || rank < 0 || rank >= (int)dp->devices.size() || !d_buf || first < 0 || count < 0) return VT_EINVAL;
+  if (count == 0) return 0;
+  int keep = 0;
+  (void)hipGetDevice(&keep);
+  if (keep != dp->devices[rank] && hipSetDevice(dp->devices[rank]) != hipSuccess) return VT_EINVAL;
+  int out = 0;
+  float *p = d_buf + first;
+  if (hipEventRecord(dp->ready[rank], (hipStream_t)compute) != hipSuccess ||
+      hipStreamWaitEvent(dp->side[rank], dp->ready[rank], 0) != hipSuccess) {
+    out = VT_EIO;
+  } else {
+    const int rc = g_rccl.AllReduce(p, p, (size_t)count, NCCL_FLOAT32, NCCL_SUM, dp->comms[rank], dp->side[rank]);
+    if (rc != NCCL_SUCCESS) out = rccl_fail("ncclAllReduce", rc);
+    else if (hipEventRecord(dp->done[rank], dp->side[rank]) != hipSuccess) out = VT_EIO;
+    else dp->issued[rank] = 1;
+  }
+  if (keep != dp->devices[rank]) (void)hipSetDevice(keep);
+  return out;
+}
+
+int vt_dp_exchange_join(vt_dp *dp, int rank, vt_stream compute) {
+  if (!dp || rank < 0 || rank >= (int)dp->devices.size()) return VT_EINVAL;
+  if (!dp->issued[rank]) return 0;
+  return hipStreamWaitEvent((hipStream_t)compute, dp->done[rank], 0) == hipSuccess ? 0 : VT_EIO;
 }
 
 int vt_dp_wait(vt_dp *dp) {

@@ -546,6 +546,10 @@ class DataLoader:
     def total_batches(self):
         return (self.n + self.batch_size - 1) // self.batch_size
 
+    def skip(self, count_images):
+        """Advances past the next `count_images` images without gathering them (another rank evaluates them)."""
+        self.index = min(self.index + int(count_images), self.n)
+
     def next_batches(self, count):
         """`count` consecutive batches as one tensor pair (for grouped evaluation sweeps)."""
         saved = self.batch_size
@@ -606,11 +610,33 @@ def class_stats(cm):
 
 
 class Trainer:
-    """Trainer (utils/trainer.hpp:9-243): train / evaluate / evaluate_test / predict."""
+    """Trainer (utils/trainer.hpp:9-243): train / evaluate / evaluate_test / predict.
 
-    def __init__(self, model, train_loader, val_loader, num_classes, batch_size, test_loader=None, out=print):
+    world / rank (one process per GPU, torch.distributed initialised by the caller): evaluation sweeps are sharded
+    "replicas only": the chunks of consecutive loader batches are dealt round-robin to the ranks, every loader batch
+    keeps its own BatchNorm1D statistics, and the per-batch loss sums, hit counts, predicted labels and the confusion
+    matrix are merged afterwards with one sum over the ranks (each entry is written by exactly one rank); every rank
+    then holds, and rank 0 prints, what the single-process sweep computes."""
+
+    def __init__(self, model, train_loader, val_loader, num_classes, batch_size, test_loader=None, out=print, world=1, rank=0,
+                 process_group=None):
         self.model, self.train_loader, self.val_loader, self.test_loader = model, train_loader, val_loader, test_loader
         self.num_classes, self.batch_size, self.out = num_classes, batch_size, out
+        self.world, self.rank, self.group = int(world), int(rank), process_group
+        if self.world > 1 and self.rank != 0:
+            self.out = lambda *a, **k: None  # rank 0 prints
+
+    def _merge_over_ranks(self, tensors):
+        """In-place sum over the ranks of small device tensors (on the device over RCCL, through the host otherwise)."""
+        import torch.distributed as dist
+        on_device = dist.get_backend(self.group) == "nccl"
+        for t in tensors:
+            if on_device:
+                dist.all_reduce(t, group=self.group)
+            else:
+                h = t.cpu()
+                dist.all_reduce(h, group=self.group)
+                t.copy_(h)
 
     def _epoch_eval(self, loader):
         """Forward-only sweep in eval mode; per-batch loss sums, hit counts and the confusion matrix
@@ -622,6 +648,20 @@ class Trainer:
         correct = torch.zeros(nb, dtype=torch.int32, device=dev)
         cm = torch.zeros(k * k, dtype=torch.int32, device=dev)
         preds, truth, sizes = [], [], []
+        sharded = self.world > 1
+        all_pred = torch.zeros(loader.n if sharded else 0, dtype=torch.int32, device=dev)  # merged by a sum: one writer per entry
+        chunk = 0
+        if sharded:
+            # data-parallel ranks keep BatchNorm running statistics of their own; the model that is evaluated (and
+            # saved) is rank 0's, so its frozen and state tensors go to every rank first (trainable weights already agree)
+            import torch.distributed as dist
+            tail = self.model.arena[self.model.layout.n_trainable:]
+            if dist.get_backend(self.group) == "nccl":
+                dist.broadcast(tail, src=0, group=self.group)
+            else:
+                h = tail.cpu()
+                dist.broadcast(h, src=0, group=self.group)
+                tail.copy_(h)
         self.model.set_training(False)
         b = 0
         bs = loader.batch_size
@@ -632,6 +672,17 @@ class Trainer:
             # whole chunks of loader batches per launch set (vt_model_forward_grouped): each batch
             # keeps its own BatchNorm1D statistics, as in the reference's batch-by-batch loop
             while loader.has_next():
+                first_image = loader.index
+                if sharded and chunk % self.world != self.rank:  # another rank's chunk
+                    loader.skip(per_call * bs)
+                    left = loader.index - first_image
+                    while left > 0:
+                        sizes.append(min(bs, left))
+                        left -= bs
+                        b += 1
+                    chunk += 1
+                    continue
+                chunk += 1
                 x, y = loader.next_batches(per_call)
                 p = self.model.forward_grouped(x, bs)
                 am = torch.empty(y.numel(), dtype=torch.int32, device=dev)
@@ -641,12 +692,22 @@ class Trainer:
                                                      _stream_handle()), "vt_eval_accumulate_grouped")
                 preds.append(am)
                 truth.append(y)
+                if sharded:
+                    all_pred[first_image:first_image + y.numel()] = am
                 left = y.numel()
                 while left > 0:
                     sizes.append(min(bs, left))
                     left -= bs
                     b += 1
         while loader.has_next():
+            first_image = loader.index
+            if sharded and chunk % self.world != self.rank:
+                loader.skip(bs)
+                sizes.append(loader.index - first_image)
+                b += 1
+                chunk += 1
+                continue
+            chunk += 1
             x, y = loader.next_batch()
             p = self.model.forward(x)
             am = torch.empty(y.numel(), dtype=torch.int32, device=dev)
@@ -656,9 +717,15 @@ class Trainer:
                   "vt_eval_accumulate")
             preds.append(am)
             truth.append(y)
+            if sharded:
+                all_pred[first_image:first_image + y.numel()] = am
             sizes.append(y.numel())
             b += 1
         self.model.set_training(True)
+        if sharded:
+            self._merge_over_ranks([loss_sums, correct, cm, all_pred])
+            order = torch.from_numpy(loader.indices.astype(np.int64)).to(dev)
+            preds, truth = [all_pred], [loader._labels.index_select(0, order)]
         sizes = np.asarray(sizes, dtype=np.float64)
         ls = loss_sums[:b].cpu().numpy().astype(np.float64) / sizes  # per-batch means, then their mean
         ac = correct[:b].cpu().numpy().astype(np.float64) / sizes    # (utils/trainer.hpp:112-127)
