@@ -302,6 +302,43 @@ def time_extra_config(shape, batch, bf16, classes, steps=3, warmup=1):
             "weights_finite_after_run": finite, "roofline": roof}
 
 
+def time_blood_config(batch, group, classes, steps=100, warmup=20):
+    """The headline shape at another batching, under the same clock: `group` > 0 trains batch / group independent
+    reference-sized mini-batches side by side with one summed update (vt_model_train_step_grouped: the semantics of
+    that many data-parallel ranks of the reference's own loader batch on one device), 0 the plain step."""
+    from vit_amd import VTCNN, Dims
+    dims = Dims(num_classes=classes, **SHAPES["blood"])
+    m = VTCNN(dims, max_batch=batch, seed=42)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(321)
+    x = (torch.randint(0, 256, (2, batch, 1, 28, 28), device="cuda", generator=g).to(torch.float32) / 255.0).contiguous()
+    y = torch.randint(0, classes, (2, batch), device="cuda", generator=g).to(torch.int32)
+
+    def one(i):
+        if group > 0:
+            m.train_step_grouped(x[i & 1], y[i & 1], group, float(group))
+        else:
+            m.train_step(x[i & 1], y[i & 1], float(batch))
+    for i in range(warmup):
+        one(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        one(i)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    finite = bool(torch.isfinite(m.arena).all().item())
+    _, total_bytes = algorithmic_bytes_per_image(dims, False, False)
+    gbs = total_bytes * batch / dt / 1e9
+    del m, x, y
+    torch.cuda.empty_cache()
+    return {"ms_per_step": round(dt * 1e3, 4), "images_per_sec": round(batch / dt, 1), "batch": batch,
+            "statistics_group": group, "steps": steps, "warmup": warmup, "dtype": "f32", "emulation": emulation_note(False, False),
+            "weights_finite_after_run": finite,
+            "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_step": total_bytes * batch, "traffic": None}}
+
+
 def dry_run(a, world, rank):
     """VT_BENCH_DRY=1: rehearsal of everything around the device work on a machine without a GPU (CPU tests): the
     ranks rendezvous over gloo, count themselves, exchange a gradient-sized buffer, and rank 0 prints the line with
@@ -650,6 +687,15 @@ def main():
                 try:
                     extra[name] = time_extra_config(shp, bt, bf, a.classes)
                 except Exception as e:  # the headline line must survive a failure here
+                    extra[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+                    torch.cuda.empty_cache()
+            # the headline shape as the reference batches it: 32 loader batches of 32 side by side (one summed update),
+            # twice that, and one plain loader batch
+            for name, bt, grp in (("blood_b1024_group32_f32", 1024, 32), ("blood_b4096_group32_f32", 4096, 32),
+                                  ("blood_b32_f32", 32, 0)):
+                try:
+                    extra[name] = time_blood_config(bt, grp, a.classes)
+                except Exception as e:
                     extra[name] = {"error": "%s: %s" % (type(e).__name__, e)}
                     torch.cuda.empty_cache()
             res["configs"] = extra

@@ -138,6 +138,9 @@ def test_gemm_sum_of_products(form, tol):
         (2049, 45, 2, (36, 20), (0, 1), (0, 1), True, True),
         (70000, 16, 1, (64,), (0,), (1,), True, False),
         (3000, 30, 2, (8,), (1,), (0,), False, True),
+        (4100, 196, 2, (64,), (0,), (0,), True, False),      # thirteen result tiles
+        (2300, 128, 2, (64, 196), (0, 0), (1, 0), True, False),  # the wide projector output: more than 64 KB of LDS
+        (2300, 200, 1, (128, 36), (1, 0), (0, 1), False, True),
     ])
     # argument checks
     bad = (VtGemmTerm * 1)()
@@ -150,13 +153,14 @@ def test_gemm_sum_of_products(form, tol):
 @pytest.mark.parametrize("form,tol", [(0, 3e-6), (2, 3e-5)])
 def test_gemm_with_softmax_epilogues(form, tol):
     """vt_gemm_softmax_rows: product + softmax over each row, and product + softmax backward against a, where the
-    row-panel kernel applies the epilogue to its accumulators (tall M, N <= 16) and where it falls back to two
-    launches (short M, N > 16), against numpy in double precision."""
+    row-panel kernel applies the epilogue to its accumulators (tall M; N <= 16 or 129 ... 208) and where it falls back
+    to two launches (short M, other N), against numpy in double precision."""
     import torch
     from vit_amd._lib import check, lib
     rng = np.random.default_rng(3)
     for (M, N, K, batch, tb) in [(5000, 16, 64, 2, 1), (3000, 10, 20, 3, 0), (2048, 16, 128, 1, 1), (70000, 7, 36, 1, 0),
-                                 (300, 16, 64, 2, 1), (2500, 33, 64, 2, 0)]:
+                                 (300, 16, 64, 2, 1), (2500, 33, 64, 2, 0),
+                                 (4100, 196, 64, 2, 0), (2100, 196, 128, 2, 1), (2600, 150, 40, 1, 0)]:  # thirteen-tile rows
         A = rng.standard_normal((batch, M, K)).astype(np.float32)
         B = (rng.standard_normal((batch, N, K) if tb else (batch, K, N)) * 0.3).astype(np.float32)
         prod = 0.5 * (A.astype(np.float64) @ (np.swapaxes(B, 1, 2) if tb else B).astype(np.float64))

@@ -72,6 +72,20 @@ def test_sum_and_softmax_backward_from_records():
     a64 = att.astype(np.float64)
     want = a64 * (prod - (a64 * prod).sum(axis=2, keepdims=True))
     assert rel_err(out.cpu().numpy(), want) < 2e-5
+    # the same with 196 columns (thirteen result tiles, the values' copy in LDS beyond 64 KB)
+    vals2 = rng.standard_normal((batch, 196, K0)).astype(np.float32)
+    att2 = rng.random((batch, M, 196)).astype(np.float32)
+    att2 /= att2.sum(axis=2, keepdims=True)
+    dvals2, datt2 = torch.from_numpy(vals2).cuda(), torch.from_numpy(att2).cuda()
+    out2 = torch.zeros((batch, M, 196), dtype=torch.float32, device="cuda")
+    t[0] = VtGemmTerm(drec.data_ptr(), dvals2.data_ptr(), M * K0 // 8, 196 * K0, K0, K0 // 8, K0, 1)
+    check(lib.vt_gemm_sum_records(1, t, C.c_void_p(dcoef.data_ptr()), 2, C.c_void_p(datt2.data_ptr()), M, 196,
+                                  C.c_void_p(out2.data_ptr()), 196, M * 196, None, batch, s), "vt_gemm_sum_records")
+    torch.cuda.synchronize()
+    prod2 = dense @ np.swapaxes(vals2.astype(np.float64), 1, 2)
+    b64 = att2.astype(np.float64)
+    assert rel_err(out2.cpu().numpy(), b64 * (prod2 - (b64 * prod2).sum(axis=2, keepdims=True))) < 2e-5
+    t[0] = VtGemmTerm(drec.data_ptr(), dvals.data_ptr(), M * K0 // 8, 16 * K0, K0, K0 // 8, K0, 1)
     # a sum of three products into 64 columns, the first from records, with a bias
     W0 = rng.standard_normal((64, K0)).astype(np.float32)          # shared, read transposed
     A1 = rng.standard_normal((batch, M, 16)).astype(np.float32)
@@ -117,5 +131,15 @@ def test_batchnorm_apply_inside_its_first_product():
     want_x = (A.astype(np.float64) - stat[:K]) * stat[K:] * gamma + beta
     assert rel_err(x.cpu().numpy(), want_x) < 2e-6
     assert rel_err(out.cpu().numpy(), want_x @ B.astype(np.float64) + bias) < 2e-6
-    # more than 16 result columns: refused, nothing launched
+    # 17 ... 128 result columns: refused, nothing launched
     assert lib.vt_gemm_bn_apply(M, 32, K, P(d[0]), K, P(d[1]), P(d[2]), P(d[3]), P(x), P(d[4]), 32, 0, None, P(out), 32, None) == -2
+    # 196 result columns (thirteen tiles)
+    B2, bias2 = rng.standard_normal((K, 196)).astype(np.float32), rng.standard_normal(196).astype(np.float32)
+    dB2, dbias2 = torch.from_numpy(B2).cuda(), torch.from_numpy(bias2).cuda()
+    x2 = torch.zeros((M, K), dtype=torch.float32, device="cuda")
+    out2 = torch.zeros((M, 196), dtype=torch.float32, device="cuda")
+    check(lib.vt_gemm_bn_apply(M, 196, K, P(d[0]), K, P(d[1]), P(d[2]), P(d[3]), P(x2), P(dB2), 196, 0, P(dbias2), P(out2), 196,
+                               C.c_void_p(torch.cuda.current_stream().cuda_stream)), "vt_gemm_bn_apply")
+    torch.cuda.synchronize()
+    assert rel_err(x2.cpu().numpy(), want_x) < 2e-6
+    assert rel_err(out2.cpu().numpy(), want_x @ B2.astype(np.float64) + bias2) < 2e-6

@@ -17,6 +17,8 @@
 // instructions of a quarter of the fp32 instruction's duration each in place of four fp32 ones.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+#include <cstdlib>
 #include <type_traits>
 
 #include "../../include/vtcnn_hip.h"
@@ -452,7 +454,7 @@ struct GemmSumP {
   long sC;
   float alpha;
   int accumulate;
-  // row-panel kernel, N <= 16 only: 1 = softmax over the row (Tensor::softmax over the last axis), 2 = its
+  // row-panel kernel only: 1 = softmax over the row (Tensor::softmax over the last axis), 2 = its
   // backward r <- a * (r - sum_row a * r) with a = epi_a (laid out like C); 0 = none
   int epi;
   const float *epi_a;
@@ -513,7 +515,7 @@ __global__ __launch_bounds__(256) void k_gemm_sum(GemmSumP p) {
   gemm_store<BM, BN>(acc, p.C + (long)b * p.sC, p.ldc, p.M, p.N, m0, n0, p.alpha, p.bias, p.accumulate != 0, true);
 }
 
-// ---- tall and narrow results (M in the millions of pixel rows, N <= 128, total depth a few hundred): the
+// ---- tall and narrow results (M in the millions of pixel rows, N <= 208, total depth a few hundred): the
 // row-panel form of the same sum of products.  Such a product is a stream: every row of A is read once, every
 // row of C written once, and op(B) (all terms, a few tens of KB) is the only thing reused.  So B lives in LDS
 // for the whole workgroup (as bf16 hi/lo pairs [n][k] in the split form, fp32 [k][n] in the exact one), and a
@@ -527,13 +529,14 @@ struct PanelStep {
   int lda, K, k0, kofs;  // kofs: the step's first k row / column inside the LDS copy of op(B)
   int comp;              // 1: A holds delta records (kernels built with DZ), lda floats per row of records
 };
-constexpr int PANEL_STEPS = 16, PANEL_HEAD = 512;  // bytes reserved in front of B for the step table
+constexpr int PANEL_STEPS = 48, PANEL_HEAD = 1536;  // bytes reserved in front of B for the step table
 constexpr int PANEL_T = 512, PANEL_W = PANEL_T / 64;  // eight waves share one LDS copy of B
+constexpr int PANEL_NMAX = 208, PANEL_LDS_MAX = 160 * 1024;  // result columns (thirteen 16-column tiles), LDS per workgroup
 
 // AX: what term 0's A is: 0 a plain matrix, 1 delta records (GemmSumP::dz_coef), 2 a BatchNorm input normalised on
 // load and written back (GemmSumP::ax_*)
-template <int PR, int NT, int AX = 0>
-__global__ __launch_bounds__(PANEL_T) void k_gemm_panel(GemmSumP p, int rows_per_wg, int Kp, int nsteps) {
+template <int PR, int NT, int AX = 0, bool EPI = false>  // EPI: built with the row epilogues (GemmSumP::epi)
+__global__ __launch_bounds__(PANEL_T, (NT > 8 && !EPI) ? 4 : 1) void k_gemm_panel(GemmSumP p, int rows_per_wg, int Kp, int nsteps) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   PanelStep *steps = reinterpret_cast<PanelStep *>(smem);
   constexpr int NP16 = NT * 16;
@@ -727,18 +730,26 @@ __global__ __launch_bounds__(PANEL_T) void k_gemm_panel(GemmSumP p, int rows_per
             // one row of C (one 16-byte store).  All of op(B)'s fragments first, then the three partial products
             // tile by tile: consecutive matrix instructions write different accumulators, none waits for the one
             // before it
-            s16x4 bh[NT], bl[NT];
+            constexpr int JG = NT <= 8 ? NT : 7;  // tiles whose fragments are held at once
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-              bh[j] = *reinterpret_cast<const s16x4 *>(&Bh[(j * 16 + c) * ldk + kb]);
-              bl[j] = *reinterpret_cast<const s16x4 *>(&Bl[(j * 16 + c) * ldk + kb]);
+            for (int j0 = 0; j0 < NT; j0 += JG) {
+              s16x4 bh[JG], bl[JG];
+#pragma unroll
+              for (int j = 0; j < JG; ++j)
+                if (j0 + j < NT) {
+                  bh[j] = *reinterpret_cast<const s16x4 *>(&Bh[((j0 + j) * 16 + c) * ldk + kb]);
+                  bl[j] = *reinterpret_cast<const s16x4 *>(&Bl[((j0 + j) * 16 + c) * ldk + kb]);
+                }
+#pragma unroll
+              for (int j = 0; j < JG; ++j)
+                if (j0 + j < NT) acc[j0 + j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bh[j], al, acc[j0 + j], 0, 0, 0);
+#pragma unroll
+              for (int j = 0; j < JG; ++j)
+                if (j0 + j < NT) acc[j0 + j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bl[j], ah, acc[j0 + j], 0, 0, 0);
+#pragma unroll
+              for (int j = 0; j < JG; ++j)
+                if (j0 + j < NT) acc[j0 + j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bh[j], ah, acc[j0 + j], 0, 0, 0);
             }
-#pragma unroll
-            for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bh[j], al, acc[j], 0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bl[j], ah, acc[j], 0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bh[j], ah, acc[j], 0, 0, 0);
           } else {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
@@ -750,62 +761,112 @@ __global__ __launch_bounds__(PANEL_T) void k_gemm_panel(GemmSumP p, int rows_per
       }
       if (last) {
         const long gm = row0 + c;  // lane (c, g) holds C[row c][16 j + 4 g .. + 3]
+        const bool row_on = gm < p.M;
+        if constexpr (EPI) {
+          // row epilogues: a row's values sit in the four lanes c, c+16, c+32, c+48, NT * 4 in each
+          float r[NT][4];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          const int gn = j * 16 + 4 * g;
-          const bool row_on = gm < p.M;
-          float r[4];
+          for (int j = 0; j < NT; ++j) {
+            const int gn = j * 16 + 4 * g;
 #pragma unroll
-          for (int v = 0; v < 4; ++v) {
-            r[v] = acc[j][v] * p.alpha;
-            if (p.bias && gn + v < p.N) r[v] += p.bias[gn + v];
+            for (int v = 0; v < 4; ++v) {
+              r[j][v] = acc[j][v] * p.alpha;
+              if (p.bias && gn + v < p.N) r[j][v] += p.bias[gn + v];
+            }
+            acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
           }
-          if (NT == 1 && p.epi != 0) {  // a row's (at most) 16 values sit in the four lanes c, c+16, c+32, c+48
-            if (p.epi == 1) {
-              float mx = -INFINITY;
+          if (p.epi == 1) {
+            float mx = -INFINITY;
 #pragma unroll
-              for (int v = 0; v < 4; ++v)
-                if (gn + v < p.N) mx = fmaxf(mx, r[v]);
-              mx = fmaxf(mx, __shfl_xor(mx, 16));
-              mx = fmaxf(mx, __shfl_xor(mx, 32));
-              float sum = 0.f;
+            for (int j = 0; j < NT; ++j)
 #pragma unroll
               for (int v = 0; v < 4; ++v) {
-                r[v] = gn + v < p.N ? expf(r[v] - mx) : 0.f;
-                sum += r[v];
+                if (j * 16 + 4 * g + v >= p.N) r[j][v] = -INFINITY;  // columns past N: exp(-inf - mx) = 0 below
+                mx = fmaxf(mx, r[j][v]);
               }
-              sum += __shfl_xor(sum, 16);
-              sum += __shfl_xor(sum, 32);
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            float sum = 0.f;
 #pragma unroll
-              for (int v = 0; v < 4; ++v) r[v] /= sum;
-            } else {
-              float a[4], dot = 0.f;
+            for (int j = 0; j < NT; ++j)
 #pragma unroll
               for (int v = 0; v < 4; ++v) {
-                a[v] = (row_on && gn + v < p.N) ? p.epi_a[(long)b * p.sC + gm * p.ldc + gn + v] : 0.f;
-                dot += a[v] * r[v];
+                r[j][v] = expf(r[j][v] - mx);
+                sum += r[j][v];
               }
-              dot += __shfl_xor(dot, 16);
-              dot += __shfl_xor(dot, 32);
+            sum += __shfl_xor(sum, 16);
+            sum += __shfl_xor(sum, 32);
 #pragma unroll
-              for (int v = 0; v < 4; ++v) r[v] = a[v] * (r[v] - dot);
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+              for (int v = 0; v < 4; ++v) r[j][v] /= sum;
+          } else if (p.epi == 2) {
+            const float *__restrict__ arow = p.epi_a + (long)b * p.sC + gm * p.ldc;
+            const bool vecE = vecC && (reinterpret_cast<uintptr_t>(p.epi_a) & 15) == 0;
+            float dot = 0.f;
+            float a[NT][4];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+              const int gn = j * 16 + 4 * g;
+              if (vecE && row_on && gn + 3 < p.N) {
+                const float4 t = *reinterpret_cast<const float4 *>(arow + gn);
+                a[j][0] = t.x; a[j][1] = t.y; a[j][2] = t.z; a[j][3] = t.w;
+              } else {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) a[j][v] = (row_on && gn + v < p.N) ? arow[gn + v] : 0.f;
+              }
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+              for (int v = 0; v < 4; ++v) dot += a[j][v] * r[j][v];
+            dot += __shfl_xor(dot, 16);
+            dot += __shfl_xor(dot, 32);
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+              for (int v = 0; v < 4; ++v) r[j][v] = a[j][v] * (r[j][v] - dot);
+          }
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            const int gn = j * 16 + 4 * g;
+            if (row_on && gn < p.N) {
+              float *__restrict__ dst = C + gm * p.ldc + gn;
+              if (vecC && gn + 3 < p.N) {
+                *reinterpret_cast<float4 *>(dst) = make_float4(r[j][0], r[j][1], r[j][2], r[j][3]);
+              } else {
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+                  if (gn + v < p.N) dst[v] = r[j][v];
+              }
             }
           }
-          if (row_on && gn < p.N) {
-            float *__restrict__ dst = C + gm * p.ldc + gn;
-            if (vecC && gn + 3 < p.N) {
-              if (p.accumulate) {
-                const float4 o = *reinterpret_cast<const float4 *>(dst);
-                r[0] += o.x; r[1] += o.y; r[2] += o.z; r[3] += o.w;
-              }
-              *reinterpret_cast<float4 *>(dst) = make_float4(r[0], r[1], r[2], r[3]);
-            } else {
+        } else {
 #pragma unroll
-              for (int v = 0; v < 4; ++v)
-                if (gn + v < p.N) dst[v] = p.accumulate ? r[v] + dst[v] : r[v];
+          for (int j = 0; j < NT; ++j) {
+            const int gn = j * 16 + 4 * g;
+            float r[4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+              r[v] = acc[j][v] * p.alpha;
+              if (p.bias && gn + v < p.N) r[v] += p.bias[gn + v];
             }
+            if (row_on && gn < p.N) {
+              float *__restrict__ dst = C + gm * p.ldc + gn;
+              if (vecC && gn + 3 < p.N) {
+                if (p.accumulate) {
+                  const float4 o = *reinterpret_cast<const float4 *>(dst);
+                  r[0] += o.x; r[1] += o.y; r[2] += o.z; r[3] += o.w;
+                }
+                *reinterpret_cast<float4 *>(dst) = make_float4(r[0], r[1], r[2], r[3]);
+              } else {
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+                  if (gn + v < p.N) dst[v] = p.accumulate ? r[v] + dst[v] : r[v];
+              }
+            }
+            acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
           }
-          acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
       }
 #pragma unroll
@@ -834,6 +895,26 @@ __global__ __launch_bounds__(256) void k_gemm_splitk_reduce(GemmP p, int batch) 
 
 using namespace vt;
 
+// One instantiation of the row-panel kernel.  More than 64 KB of LDS per workgroup (a single workgroup may hold all of a
+// compute unit's 160 KB) is asked for once per device and instantiation.
+template <int PR, int NT, int AX, bool EPI = false>
+static hipError_t panel_go(dim3 grid, size_t lds, hipStream_t hs, const GemmSumP &p, int rows, int Kp, int nsteps) {
+  if (lds > 64 * 1024) {
+    static std::atomic<unsigned long long> asked{0};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev >= 64 || !((asked.load(std::memory_order_relaxed) >> dev) & 1)) {
+      e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_panel<PR, NT, AX, EPI>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, PANEL_LDS_MAX);
+      if (e != hipSuccess) return e;
+      if (dev < 64) asked.fetch_or(1ull << dev, std::memory_order_relaxed);
+    }
+  }
+  hipLaunchKernelGGL((k_gemm_panel<PR, NT, AX, EPI>), grid, dim3(PANEL_T), lds, hs, p, rows, Kp, nsteps);
+  return hipGetLastError();
+}
+
 // Row-panel launch of a sum of products when it is tall and narrow and every A is 16-byte loadable; returns
 // 1 when it took the job, 0 when the tiled kernels should, < 0 on a launch error.
 static int panel_launch(int form, const GemmSumP &p, int batch, hipStream_t hs, bool dz = false, bool ax = false) {
@@ -841,8 +922,13 @@ static int panel_launch(int form, const GemmSumP &p, int batch, hipStream_t hs, 
     const char *e = getenv("VT_GEMM_PANEL");
     return e && *e == '0';
   }();
-  if (off || (form != 0 && form != 2) || p.N > 128 || p.M < 2048 || batch > 65535) return 0;
-  if (p.epi != 0 && (p.N > 16 || p.accumulate)) return 0;
+  static const int rows_forced = [] {
+    const char *e = getenv("VT_PANEL_ROWS");
+    const int v = e ? atoi(e) : 0;
+    return (v >= 128 && v <= 8192 && (v & (v - 1)) == 0) ? v : 0;
+  }();
+  if (off || (form != 0 && form != 2) || p.N > PANEL_NMAX || p.M < 2048 || batch > 65535) return 0;
+  if (p.epi != 0 && p.accumulate) return 0;
   int Kp = 0, nsteps = 0;
   for (int i = 0; i < p.nterms; ++i) {
     if (!p.t[i].vecA) return 0;
@@ -851,37 +937,53 @@ static int panel_launch(int form, const GemmSumP &p, int batch, hipStream_t hs, 
     Kp += ns * 16;
   }
   if (nsteps > PANEL_STEPS) return 0;
-  const int NT = p.N <= 16 ? 1 : p.N <= 32 ? 2 : p.N <= 64 ? 4 : 8;
+  const int NT = p.N <= 16 ? 1 : p.N <= 32 ? 2 : p.N <= 64 ? 4 : p.N <= 128 ? 8 : 13;
   size_t lds = PANEL_HEAD + (form == 2 ? (size_t)2 * NT * 16 * (Kp + 8) * 2 : (size_t)Kp * (NT * 16 + 4) * 4);
   if (dz) {
-    if (form != 2 || p.t[0].K % 16 != 0 || !p.dz_coef || (NT != 1 && NT != 4)) return 0;
+    if (form != 2 || p.t[0].K % 16 != 0 || !p.dz_coef || (NT != 1 && NT != 4 && NT != 13)) return 0;
     lds += (size_t)2 * p.t[0].K * sizeof(float);
   }
-  if (ax) {  // built for the exact form with one result tile (the tokenizer's scores)
-    if (form != 0 || NT != 1 || !p.ax_stat || !p.ax_gamma || !p.ax_beta || !p.ax_out || p.t[0].K % 4 != 0) return 0;
+  if (ax) {  // built for the exact form with one or thirteen result tiles (the tokenizer's scores)
+    if (form != 0 || (NT != 1 && NT != 13) || !p.ax_stat || !p.ax_gamma || !p.ax_beta || !p.ax_out || p.t[0].K % 4 != 0) return 0;
     lds += (size_t)4 * ((p.t[0].K + 15) / 16) * 16 * sizeof(float);
   }
-  if (lds > 64 * 1024) return 0;
-  // rows per workgroup: as many as leave a few thousand workgroups (the LDS copy of B is paid once per workgroup)
+  if (lds > (size_t)PANEL_LDS_MAX) return 0;
+  // too few rows to fill the device with 128-row workgroups that each pay for a large copy of op(B): the tiled kernels
+  if (lds > 64 * 1024 && (long)((p.M + 127) / 128) * batch < 512) return 0;
+  // rows per workgroup: as many as leave a few thousand workgroups (the LDS copy of B is paid once per workgroup);
+  // a copy of more than half a compute unit's LDS leaves one workgroup per unit, which then takes at least 512 rows
   int rows = 1024;
-  while (rows > 128 && (long)((p.M + rows - 1) / rows) * batch < 2048) rows >>= 1;
+  const int rows_min = lds > 80 * 1024 ? 512 : 128;
+  while (rows > rows_min && (long)((p.M + rows - 1) / rows) * batch < 2048) rows >>= 1;
+  if (rows_forced) rows = rows_forced;
   const dim3 grid((unsigned)((p.M + rows - 1) / rows), (unsigned)batch);
-#define VT_PANEL(PR_, NT_) hipLaunchKernelGGL((k_gemm_panel<PR_, NT_>), grid, dim3(PANEL_T), lds, hs, p, rows, Kp, nsteps)
-#define VT_PANEL_NT(PR_)                 \
-  do {                                   \
-    if (NT == 1) VT_PANEL(PR_, 1);       \
-    else if (NT == 2) VT_PANEL(PR_, 2);  \
-    else if (NT == 4) VT_PANEL(PR_, 4);  \
-    else VT_PANEL(PR_, 8);               \
+  hipError_t e = hipSuccess;
+#define VT_PANEL(PR_, NT_, AX_) e = panel_go<PR_, NT_, AX_>(grid, lds, hs, p, rows, Kp, nsteps)
+#define VT_PANEL_NT(PR_)                    \
+  do {                                      \
+    if (NT == 1) VT_PANEL(PR_, 1, 0);       \
+    else if (NT == 2) VT_PANEL(PR_, 2, 0);  \
+    else if (NT == 4) VT_PANEL(PR_, 4, 0);  \
+    else if (NT == 8) VT_PANEL(PR_, 8, 0);  \
+    else VT_PANEL(PR_, 13, 0);              \
   } while (0)
-  if (ax) hipLaunchKernelGGL((k_gemm_panel<0, 1, 2>), grid, dim3(PANEL_T), lds, hs, p, rows, Kp, nsteps);
-  else if (dz && NT == 1) hipLaunchKernelGGL((k_gemm_panel<2, 1, 1>), grid, dim3(PANEL_T), lds, hs, p, rows, Kp, nsteps);
-  else if (dz) hipLaunchKernelGGL((k_gemm_panel<2, 4, 1>), grid, dim3(PANEL_T), lds, hs, p, rows, Kp, nsteps);
+  if (p.epi != 0) {  // the row epilogues are built for one and for thirteen result tiles, without the on-load forms but records
+    if ((NT != 1 && NT != 13) || ax) return 0;
+    if (dz && NT == 1) e = panel_go<2, 1, 1, true>(grid, lds, hs, p, rows, Kp, nsteps);
+    else if (dz) e = panel_go<2, 13, 1, true>(grid, lds, hs, p, rows, Kp, nsteps);
+    else if (form == 2 && NT == 1) e = panel_go<2, 1, 0, true>(grid, lds, hs, p, rows, Kp, nsteps);
+    else if (form == 2) e = panel_go<2, 13, 0, true>(grid, lds, hs, p, rows, Kp, nsteps);
+    else if (NT == 1) e = panel_go<0, 1, 0, true>(grid, lds, hs, p, rows, Kp, nsteps);
+    else e = panel_go<0, 13, 0, true>(grid, lds, hs, p, rows, Kp, nsteps);
+  } else if (ax && NT == 1) VT_PANEL(0, 1, 2);
+  else if (ax) VT_PANEL(0, 13, 2);
+  else if (dz && NT == 1) VT_PANEL(2, 1, 1);
+  else if (dz && NT == 4) VT_PANEL(2, 4, 1);
+  else if (dz) VT_PANEL(2, 13, 1);
   else if (form == 2) VT_PANEL_NT(2);
   else VT_PANEL_NT(0);
 #undef VT_PANEL_NT
 #undef VT_PANEL
-  const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 1 : -(int)e;
 }
 
@@ -1038,7 +1140,7 @@ extern "C" int vt_gemm_bn_apply(int M, int N, int K, const float *A, int lda, co
   if (M < 1 || N < 1 || K < 1 || !A || !stat || !gamma || !beta || !A_out || !B || !C || lda < K || ldc < N ||
       ldb < (transB ? K : N))
     return VT_EINVAL;
-  if (N > 16) return VT_EUNSUPPORTED;
+  if (N > 16 && (N <= 128 || N > PANEL_NMAX)) return VT_EUNSUPPORTED;  // kernels are built for one and for thirteen tiles
   auto aligned = [](const float *q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
   GemmSumP p{};
   p.t[0] = GemmTerm{A, B, 0, 0, K, lda, ldb, transB ? 1 : 0, aligned(A) && aligned(A_out) && lda % 4 == 0 && K % 4 == 0,
@@ -1202,7 +1304,6 @@ extern "C" int vt_gemm_sum_records(int nterms, const vt_gemm_term *terms, const 
                                    int N, float *C, int ldc, long strideC, const float *bias, int batch, vt_stream s) {
   if (nterms < 1 || nterms > 4 || !terms || !coef || M < 1 || N < 1 || batch < 1 || !C || ldc < N) return VT_EINVAL;
   if ((epi != 0 && epi != 2) || (epi == 2 && (!epi_a || ldc != N))) return VT_EINVAL;
-  if (epi == 2 && N > 16) return VT_EUNSUPPORTED;
   const int K0 = terms[0].K;
   if (K0 % 16 != 0 || terms[0].lda != K0 / 8 || terms[0].strideA % 2 != 0 ||
       (reinterpret_cast<uintptr_t>(terms[0].A) & 7) != 0)
