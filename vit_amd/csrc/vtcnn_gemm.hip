@@ -791,7 +791,7 @@ __global__ __launch_bounds__(PANEL_T, (NT > 8 && !EPI) ? 4 : 1) void k_gemm_pane
             for (int j = 0; j < NT; ++j)
 #pragma unroll
               for (int v = 0; v < 4; ++v) {
-                r[j][v] = expf(r[j][v] - mx);
+                r[j][v] = NT > 8 ? __expf(r[j][v] - mx) : expf(r[j][v] - mx);
                 sum += r[j][v];
               }
             sum += __shfl_xor(sum, 16);
