@@ -517,8 +517,8 @@ int vt_gemm_sum(int form, int nterms, const vt_gemm_term *terms, int M, int N, f
  * its result (the tokenizer's scores, layers/tokenizer.hpp:30-34):
  *   A_out[m][k] = (A[m][k] - stat[k]) * stat[K + k] * gamma[k] + beta[k],   C = A_out . op(B) (+ bias[n])
  * exact fp32, one pass over A (A_out laid out like A and written once; the normalised matrix is not read back for the
- * product).  Row-panel kernel only: N <= 16, M >= 2048, A and A_out 16-byte loadable, else VT_EUNSUPPORTED and nothing
- * is launched. */
+ * product).  Row-panel kernel only: N <= 16 or 129 <= N <= 208 (one or thirteen result tiles), M >= 2048, A and A_out
+ * 16-byte loadable, else VT_EUNSUPPORTED and nothing is launched. */
 int vt_gemm_bn_apply(int M, int N, int K, const float *A, int lda, const float *stat, const float *gamma, const float *beta,
                      float *A_out, const float *B, int ldb, int transB, const float *bias, float *C, int ldc, vt_stream s);
 /* Products that read the delta behind the projector's BatchNorm (MaxPool2DLayer::backward + ReLU mask + BatchNorm
@@ -532,8 +532,9 @@ int vt_gemm_bn_apply(int M, int N, int K, const float *A, int lda, const float *
  *   as in vt_gemm_f32.
  * vt_gemm_sum_records:  vt_gemm_sum (epi 0) or vt_gemm_softmax_rows' softmax backward (epi 2, epi_a laid out like C)
  *   with terms[0].A = rec (terms[0].K = N of the delta, a multiple of 16; terms[0].lda = K / 8 floats per row of
- *   records; terms[0].strideA in floats).  Row-panel kernel only, results up to 16 or exactly 33..64 columns wide:
- *   VT_EUNSUPPORTED otherwise, and nothing is launched. */
+ *   records; terms[0].strideA in floats).  Row-panel kernel only: results up to 16, 33..64 or 129..208 columns wide
+ *   without the epilogue, up to 16 or 129..208 with it, and op(B) of all terms within 160 KB of LDS: VT_EUNSUPPORTED
+ *   otherwise, and nothing is launched. */
 int vt_gemm_tn_records(int M, int N, int K, const float *A, int lda, long strideA, const float *rec, long strideRec,
                        const float *coef, float *C, int ldc, long strideC, int batch, float *workspace, long workspace_floats,
                        vt_stream s);
@@ -542,8 +543,9 @@ int vt_gemm_sum_records(int nterms, const vt_gemm_term *terms, const float *coef
 /* A product whose rows go straight through Tensor::softmax over the last axis (epi 1; the projector's attention map,
  * layers/projector_layer.hpp:80-84) or through Tensor::softmax_backward against a [batch, M, N] (epi 2: C <- a * (C -
  * sum_row a * C); layers/projector_layer.hpp:163-171, layers/tokenizer.hpp:88-91):  C[b] = epi(alpha * A[b] . op(B[b])),
- * C dense [batch, M, N] with strideC = M * N.  One launch when M is tall, N <= 16 and A is 16-byte loadable (the epilogue
- * runs on the accumulators); otherwise the product followed by vt_softmax_rows / vt_softmax_bwd_rows.  form: 0 exact
+ * C dense [batch, M, N] with strideC = M * N.  One launch when M is tall, N <= 16 or 129 <= N <= 208, and A is 16-byte
+ * loadable (the epilogue runs on the accumulators; rows of more than 128 values use the hardware exponential, about
+ * 1e-6 relative); otherwise the product followed by vt_softmax_rows / vt_softmax_bwd_rows.  form: 0 exact
  * fp32, 2 hi/lo split. */
 int vt_gemm_softmax_rows(int form, int epi, const float *a, int transB, int M, int N, int K, float alpha, const float *A,
                          int lda, long strideA, const float *B, int ldb, long strideB, float *C, long strideC, int batch,
