@@ -16,9 +16,12 @@ template <int KIND>
 __global__ __launch_bounds__(512) void k_rate(float *out, int iters) {
   // eight independent chains so that latency never limits
   float x[8], y[8];
+  floatx2 p2[8], q2[8];  // register pairs of the packed instructions (in place: no moves between them)
   for (int j = 0; j < 8; ++j) {
     x[j] = 1.0f + 0.001f * (threadIdx.x + j);
     y[j] = 0.5f + 0.002f * (threadIdx.x + 2 * j);
+    p2[j] = floatx2{x[j], y[j]};
+    q2[j] = floatx2{1.0f, 0.999f};
   }
   for (int i = 0; i < iters; ++i) {
 #pragma unroll
@@ -30,13 +33,9 @@ __global__ __launch_bounds__(512) void k_rate(float *out, int iters) {
           asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(x[j]), "v"(y[j]));
           x[j] = __uint_as_float(r);
         } else if (KIND == 1) {
-          floatx2 a = {x[j], y[j]}, b = {y[j], x[j]}, r;
-          asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-          x[j] = r.x; y[j] = r.y;
+          asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p2[j]) : "v"(q2[j]));
         } else if (KIND == 2) {
-          floatx2 a = {x[j], y[j]}, b = {y[j], x[j]}, r;
-          asm volatile("v_pk_fma_f32 %0, %1, %2, %1" : "=v"(r) : "v"(a), "v"(b));
-          x[j] = r.x; y[j] = r.y;
+          asm volatile("v_pk_fma_f32 %0, %0, %1, %0" : "+v"(p2[j]) : "v"(q2[j]));
         } else if (KIND == 3) {
           asm volatile("v_exp_f32 %0, %1" : "=v"(x[j]) : "v"(x[j]));
         } else if (KIND == 4) {
@@ -46,9 +45,7 @@ __global__ __launch_bounds__(512) void k_rate(float *out, int iters) {
         } else if (KIND == 6) {
           asm volatile("v_fma_f32 %0, %1, %2, %1" : "=v"(x[j]) : "v"(x[j]), "v"(y[j]));
         } else if (KIND == 7) {
-          floatx2 a = {x[j], y[j]}, b = {y[j], x[j]}, r;
-          asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-          x[j] = r.x; y[j] = r.y;
+          asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p2[j]) : "v"(q2[j]));
         } else if (KIND == 8) {
           asm volatile("v_max3_f32 %0, %1, %2, %1" : "=v"(x[j]) : "v"(x[j]), "v"(y[j]));
         } else {
@@ -57,7 +54,7 @@ __global__ __launch_bounds__(512) void k_rate(float *out, int iters) {
       }
   }
   float s = 0.f;
-  for (int j = 0; j < 8; ++j) s += x[j] + y[j];
+  for (int j = 0; j < 8; ++j) s += x[j] + y[j] + p2[j].x + p2[j].y;
   out[blockIdx.x * 512 + threadIdx.x] = s;
 }
 

@@ -535,8 +535,10 @@ constexpr int PANEL_NMAX = 208, PANEL_LDS_MAX = 160 * 1024;  // result columns (
 
 // AX: what term 0's A is: 0 a plain matrix, 1 delta records (GemmSumP::dz_coef), 2 a BatchNorm input normalised on
 // load and written back (GemmSumP::ax_*)
-template <int PR, int NT, int AX = 0, bool EPI = false>  // EPI: built with the row epilogues (GemmSumP::epi)
-__global__ __launch_bounds__(PANEL_T, (NT > 8 && !EPI) ? 4 : 1) void k_gemm_panel(GemmSumP p, int rows_per_wg, int Kp, int nsteps) {
+// EPI: built with the row epilogue GemmSumP::epi (1 or 2); WV: waves per workgroup (sixteen where a copy of op(B) leaves
+// room for one workgroup per compute unit and the kernel fits four waves on a SIMD)
+template <int PR, int NT, int AX = 0, int EPI = 0, int WV = PANEL_W>
+__global__ __launch_bounds__(64 * WV, (WV > 8 || (NT > 8 && EPI != 2)) ? 4 : 1) void k_gemm_panel(GemmSumP p, int rows_per_wg, int Kp, int nsteps) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   PanelStep *steps = reinterpret_cast<PanelStep *>(smem);
   constexpr int NP16 = NT * 16;
@@ -571,11 +573,11 @@ __global__ __launch_bounds__(PANEL_T, (NT > 8 && !EPI) ? 4 : 1) void k_gemm_pane
       };
       if (t.vecB) {  // 16-byte loads, eight per thread in flight before the first LDS store
         const int qrow = t.tb ? K16 / 4 : NP16 / 4, Q = K16 * NP16 / 4;
-        for (int e0 = tid; e0 < Q; e0 += PANEL_T * 8) {
+        for (int e0 = tid; e0 < Q; e0 += (64 * WV) * 8) {
           float4 v[8];
 #pragma unroll
           for (int u = 0; u < 8; ++u) {
-            const int e = e0 + u * PANEL_T, major = e / qrow, minor = 4 * (e - major * qrow);
+            const int e = e0 + u * (64 * WV), major = e / qrow, minor = 4 * (e - major * qrow);
             const int k = t.tb ? minor : major, n = t.tb ? major : minor;
             v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (e < Q && k < t.K && n < p.N)
@@ -583,7 +585,7 @@ __global__ __launch_bounds__(PANEL_T, (NT > 8 && !EPI) ? 4 : 1) void k_gemm_pane
           }
 #pragma unroll
           for (int u = 0; u < 8; ++u) {
-            const int e = e0 + u * PANEL_T, major = e / qrow, minor = 4 * (e - major * qrow);
+            const int e = e0 + u * (64 * WV), major = e / qrow, minor = 4 * (e - major * qrow);
             if (e >= Q) continue;
             const float x[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
             if (t.tb) {  // four consecutive k of row n
@@ -613,17 +615,17 @@ __global__ __launch_bounds__(PANEL_T, (NT > 8 && !EPI) ? 4 : 1) void k_gemm_pane
           }
         }
       } else {
-        for (int e0 = tid; e0 < K16 * NP16; e0 += PANEL_T * 4) {
+        for (int e0 = tid; e0 < K16 * NP16; e0 += (64 * WV) * 4) {
           float v[4];
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
-            const int e = e0 + u * PANEL_T;
+            const int e = e0 + u * (64 * WV);
             const int k = t.tb ? e % K16 : e / NP16, n = t.tb ? e / K16 : e % NP16;
             v[u] = (e < K16 * NP16 && k < t.K && n < p.N) ? B[t.tb ? (long)n * t.ldb + k : (long)k * t.ldb + n] : 0.f;
           }
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
-            const int e = e0 + u * PANEL_T;
+            const int e = e0 + u * (64 * WV);
             if (e < K16 * NP16) put(t.tb ? e % K16 : e / NP16, t.tb ? e / K16 : e % NP16, v[u]);
           }
         }
@@ -637,11 +639,11 @@ __global__ __launch_bounds__(PANEL_T, (NT > 8 && !EPI) ? 4 : 1) void k_gemm_pane
                            (PR == 2 ? NP16 * ldk : Kp * ldn);  // floats: the hi / lo halves together are NP16 * ldk floats
   if constexpr (AX == 1) {
     const int K0 = p.t[0].K;
-    for (int i = tid; i < 2 * K0; i += PANEL_T) zc[i] = p.dz_coef[i];
+    for (int i = tid; i < 2 * K0; i += (64 * WV)) zc[i] = p.dz_coef[i];
   }
   if constexpr (AX == 2) {  // mean [K0p], 1/sigma [K0p], gamma [K0p], beta [K0p] (K0p = K padded to 16: zeros)
     const int K0 = p.t[0].K, K0p = ((K0 + 15) >> 4) * 16;
-    for (int i = tid; i < 4 * K0p; i += PANEL_T) {
+    for (int i = tid; i < 4 * K0p; i += (64 * WV)) {
       const int w = i / K0p, k = i - w * K0p;
       zc[i] = k >= K0 ? 0.f : w == 0 ? p.ax_stat[k] : w == 1 ? p.ax_stat[K0 + k] : w == 2 ? p.ax_gamma[k] : p.ax_beta[k];
     }
@@ -650,8 +652,8 @@ __global__ __launch_bounds__(PANEL_T, (NT > 8 && !EPI) ? 4 : 1) void k_gemm_pane
 
   const int G = (nsteps + 3) >> 2;  // groups of four steps: one group is in the matrix cores, the next in flight
   const long wg_row0 = (long)blockIdx.x * rows_per_wg;
-  const int ntiles = rows_per_wg / (16 * PANEL_W);  // 16-row tiles per wave: tile i of this wave is tile wave + PANEL_W i of the workgroup
-  auto tile_row0 = [&](int i) { return wg_row0 + (long)(wave + PANEL_W * i) * 16; };
+  const int ntiles = rows_per_wg / (16 * WV);  // 16-row tiles per wave: tile i of this wave is tile wave + WV i of the workgroup
+  auto tile_row0 = [&](int i) { return wg_row0 + (long)(wave + WV * i) * 16; };
   auto fetch = [&](long row0, int gi, float4 (&dst)[4]) {
     const long row = row0 + c;
 #pragma unroll
@@ -679,7 +681,10 @@ __global__ __launch_bounds__(PANEL_T, (NT > 8 && !EPI) ? 4 : 1) void k_gemm_pane
   float4 cur[4], nxt[4];
   fetch(tile_row0(0), 0, cur);
   float *__restrict__ C = p.C + (long)b * p.sC;
-  const bool vecC = (reinterpret_cast<uintptr_t>(p.C) & 15) == 0 && p.ldc % 4 == 0 && p.sC % 4 == 0;
+  // kernels of more than eight tiles with an epilogue are only launched on 16-byte rows (C, epi_a) with N % 4 == 0:
+  // no element-wise paths in them
+  constexpr bool QUAD = NT > 8 && EPI != 0;
+  const bool vecC = QUAD || ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0 && p.ldc % 4 == 0 && p.sC % 4 == 0);
   for (int i = 0; i < ntiles; ++i) {
     const long row0 = tile_row0(i);
     for (int gi = 0; gi < G; ++gi) {
@@ -730,7 +735,7 @@ __global__ __launch_bounds__(PANEL_T, (NT > 8 && !EPI) ? 4 : 1) void k_gemm_pane
             // one row of C (one 16-byte store).  All of op(B)'s fragments first, then the three partial products
             // tile by tile: consecutive matrix instructions write different accumulators, none waits for the one
             // before it
-            constexpr int JG = NT <= 8 ? NT : 7;  // tiles whose fragments are held at once
+            constexpr int JG = NT <= 8 ? NT : (EPI == 1 ? 4 : 7);  // tiles whose fragments are held at once
 #pragma unroll
             for (int j0 = 0; j0 < NT; j0 += JG) {
               s16x4 bh[JG], bl[JG];
@@ -762,7 +767,7 @@ __global__ __launch_bounds__(PANEL_T, (NT > 8 && !EPI) ? 4 : 1) void k_gemm_pane
       if (last) {
         const long gm = row0 + c;  // lane (c, g) holds C[row c][16 j + 4 g .. + 3]
         const bool row_on = gm < p.M;
-        if constexpr (EPI) {
+        if constexpr (EPI != 0) {
           // row epilogues: a row's values sit in the four lanes c, c+16, c+32, c+48, NT * 4 in each
           float r[NT][4];
 #pragma unroll
@@ -771,17 +776,17 @@ __global__ __launch_bounds__(PANEL_T, (NT > 8 && !EPI) ? 4 : 1) void k_gemm_pane
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
               r[j][v] = acc[j][v] * p.alpha;
-              if (p.bias && gn + v < p.N) r[j][v] += p.bias[gn + v];
+              if (p.bias && (QUAD ? gn : gn + v) < p.N) r[j][v] += p.bias[gn + v];
             }
             acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
           }
-          if (p.epi == 1) {
+          if constexpr (EPI == 1) {
             float mx = -INFINITY;
 #pragma unroll
             for (int j = 0; j < NT; ++j)
 #pragma unroll
               for (int v = 0; v < 4; ++v) {
-                if (j * 16 + 4 * g + v >= p.N) r[j][v] = -INFINITY;  // columns past N: exp(-inf - mx) = 0 below
+                if (j * 16 + 4 * g + (QUAD ? 0 : v) >= p.N) r[j][v] = -INFINITY;  // columns past N: exp(-inf - mx) = 0 below
                 mx = fmaxf(mx, r[j][v]);
               }
             mx = fmaxf(mx, __shfl_xor(mx, 16));
@@ -800,15 +805,18 @@ __global__ __launch_bounds__(PANEL_T, (NT > 8 && !EPI) ? 4 : 1) void k_gemm_pane
             for (int j = 0; j < NT; ++j)
 #pragma unroll
               for (int v = 0; v < 4; ++v) r[j][v] /= sum;
-          } else if (p.epi == 2) {
+          } else {
             const float *__restrict__ arow = p.epi_a + (long)b * p.sC + gm * p.ldc;
-            const bool vecE = vecC && (reinterpret_cast<uintptr_t>(p.epi_a) & 15) == 0;
-            float dot = 0.f;
-            float a[NT][4];
+            const bool vecE = QUAD || (vecC && (reinterpret_cast<uintptr_t>(p.epi_a) & 15) == 0);
+            float a[NT][4], dot = 0.f;
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
               const int gn = j * 16 + 4 * g;
-              if (vecE && row_on && gn + 3 < p.N) {
+              if constexpr (QUAD) {
+                float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (row_on && gn < p.N) t = *reinterpret_cast<const float4 *>(arow + gn);
+                a[j][0] = t.x; a[j][1] = t.y; a[j][2] = t.z; a[j][3] = t.w;
+              } else if (vecE && row_on && gn + 3 < p.N) {
                 const float4 t = *reinterpret_cast<const float4 *>(arow + gn);
                 a[j][0] = t.x; a[j][1] = t.y; a[j][2] = t.z; a[j][3] = t.w;
               } else {
@@ -832,7 +840,7 @@ __global__ __launch_bounds__(PANEL_T, (NT > 8 && !EPI) ? 4 : 1) void k_gemm_pane
             const int gn = j * 16 + 4 * g;
             if (row_on && gn < p.N) {
               float *__restrict__ dst = C + gm * p.ldc + gn;
-              if (vecC && gn + 3 < p.N) {
+              if (QUAD || (vecC && gn + 3 < p.N)) {
                 *reinterpret_cast<float4 *>(dst) = make_float4(r[j][0], r[j][1], r[j][2], r[j][3]);
               } else {
 #pragma unroll
@@ -897,7 +905,7 @@ using namespace vt;
 
 // One instantiation of the row-panel kernel.  More than 64 KB of LDS per workgroup (a single workgroup may hold all of a
 // compute unit's 160 KB) is asked for once per device and instantiation.
-template <int PR, int NT, int AX, bool EPI = false>
+template <int PR, int NT, int AX, int EPI = 0, int WV = PANEL_W>
 static hipError_t panel_go(dim3 grid, size_t lds, hipStream_t hs, const GemmSumP &p, int rows, int Kp, int nsteps) {
   if (lds > 64 * 1024) {
     static std::atomic<unsigned long long> asked{0};
@@ -905,13 +913,13 @@ static hipError_t panel_go(dim3 grid, size_t lds, hipStream_t hs, const GemmSumP
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev >= 64 || !((asked.load(std::memory_order_relaxed) >> dev) & 1)) {
-      e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_panel<PR, NT, AX, EPI>),
+      e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_panel<PR, NT, AX, EPI, WV>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, PANEL_LDS_MAX);
       if (e != hipSuccess) return e;
       if (dev < 64) asked.fetch_or(1ull << dev, std::memory_order_relaxed);
     }
   }
-  hipLaunchKernelGGL((k_gemm_panel<PR, NT, AX, EPI>), grid, dim3(PANEL_T), lds, hs, p, rows, Kp, nsteps);
+  hipLaunchKernelGGL((k_gemm_panel<PR, NT, AX, EPI, WV>), grid, dim3(64 * WV), lds, hs, p, rows, Kp, nsteps);
   return hipGetLastError();
 }
 
@@ -926,6 +934,10 @@ static int panel_launch(int form, const GemmSumP &p, int batch, hipStream_t hs, 
     const char *e = getenv("VT_PANEL_ROWS");
     const int v = e ? atoi(e) : 0;
     return (v >= 128 && v <= 8192 && (v & (v - 1)) == 0) ? v : 0;
+  }();
+  static const bool wide16 = [] {
+    const char *e = getenv("VT_PANEL_WAVES16");
+    return !(e && *e == '0');
   }();
   if (off || (form != 0 && form != 2) || p.N > PANEL_NMAX || p.M < 2048 || batch > 65535) return 0;
   if (p.epi != 0 && p.accumulate) return 0;
@@ -949,7 +961,8 @@ static int panel_launch(int form, const GemmSumP &p, int batch, hipStream_t hs, 
   }
   if (lds > (size_t)PANEL_LDS_MAX) return 0;
   // too few rows to fill the device with 128-row workgroups that each pay for a large copy of op(B): the tiled kernels
-  if (lds > 64 * 1024 && (long)((p.M + 127) / 128) * batch < 512) return 0;
+  // (plain sums only: the record and epilogue forms have no tiled counterpart of one launch)
+  if (lds > 64 * 1024 && !dz && p.epi == 0 && (long)((p.M + 127) / 128) * batch < 512) return 0;
   // rows per workgroup: as many as leave a few thousand workgroups (the LDS copy of B is paid once per workgroup);
   // a copy of more than half a compute unit's LDS leaves one workgroup per unit, which then takes at least 512 rows
   int rows = 1024;
@@ -968,18 +981,28 @@ static int panel_launch(int form, const GemmSumP &p, int batch, hipStream_t hs, 
     else VT_PANEL(PR_, 13, 0);              \
   } while (0)
   if (p.epi != 0) {  // the row epilogues are built for one and for thirteen result tiles, without the on-load forms but records
-    if ((NT != 1 && NT != 13) || ax) return 0;
-    if (dz && NT == 1) e = panel_go<2, 1, 1, true>(grid, lds, hs, p, rows, Kp, nsteps);
-    else if (dz) e = panel_go<2, 13, 1, true>(grid, lds, hs, p, rows, Kp, nsteps);
-    else if (form == 2 && NT == 1) e = panel_go<2, 1, 0, true>(grid, lds, hs, p, rows, Kp, nsteps);
-    else if (form == 2) e = panel_go<2, 13, 0, true>(grid, lds, hs, p, rows, Kp, nsteps);
-    else if (NT == 1) e = panel_go<0, 1, 0, true>(grid, lds, hs, p, rows, Kp, nsteps);
-    else e = panel_go<0, 13, 0, true>(grid, lds, hs, p, rows, Kp, nsteps);
+    if ((NT != 1 && NT != 13) || ax || (dz && p.epi != 2)) return 0;
+    if (NT == 13 && (p.N % 4 != 0 || p.ldc % 4 != 0 || p.sC % 4 != 0 || (reinterpret_cast<uintptr_t>(p.C) & 15) != 0 ||
+                     (p.epi == 2 && (reinterpret_cast<uintptr_t>(p.epi_a) & 15) != 0)))
+      return 0;  // the wide-row epilogues move whole 16-byte groups
+#define VT_PANEL_EPI(PR_, NT_, AX_)                                                   \
+  do {                                                                                \
+    if (p.epi == 1) e = panel_go<PR_, NT_, AX_, 1>(grid, lds, hs, p, rows, Kp, nsteps); \
+    else e = panel_go<PR_, NT_, AX_, 2>(grid, lds, hs, p, rows, Kp, nsteps);            \
+  } while (0)
+    if (dz && NT == 1) e = panel_go<2, 1, 1, 2>(grid, lds, hs, p, rows, Kp, nsteps);
+    else if (dz) e = panel_go<2, 13, 1, 2>(grid, lds, hs, p, rows, Kp, nsteps);
+    else if (form == 2 && NT == 1) VT_PANEL_EPI(2, 1, 0);
+    else if (form == 2) VT_PANEL_EPI(2, 13, 0);
+    else if (NT == 1) VT_PANEL_EPI(0, 1, 0);
+    else VT_PANEL_EPI(0, 13, 0);
+#undef VT_PANEL_EPI
   } else if (ax && NT == 1) VT_PANEL(0, 1, 2);
   else if (ax) VT_PANEL(0, 13, 2);
   else if (dz && NT == 1) VT_PANEL(2, 1, 1);
   else if (dz && NT == 4) VT_PANEL(2, 4, 1);
   else if (dz) VT_PANEL(2, 13, 1);
+  else if (form == 2 && NT == 8 && lds > 80 * 1024 && wide16) e = panel_go<2, 8, 0, false, 16>(grid, lds, hs, p, rows, Kp, nsteps);
   else if (form == 2) VT_PANEL_NT(2);
   else VT_PANEL_NT(0);
 #undef VT_PANEL_NT
