@@ -521,6 +521,14 @@ int vt_gemm_sum(int form, int nterms, const vt_gemm_term *terms, int M, int N, f
  * 16-byte loadable, else VT_EUNSUPPORTED and nothing is launched. */
 int vt_gemm_bn_apply(int M, int N, int K, const float *A, int lda, const float *stat, const float *gamma, const float *beta,
                      float *A_out, const float *B, int ldb, int transB, const float *bias, float *C, int ldc, vt_stream s);
+/* The same launch when C's columns then go through Tensor::softmax over the ROW axis (the tokenizer's softmax over
+ * pixels, layers/tokenizer.hpp:36; tensor_cpu.hpp:894-944 over dim 1): besides C it leaves, per 16-row tile t and column
+ * n, the tile's share of that softmax: tile_rec[t][0][n] = max over the tile's rows of C, tile_rec[t][1][n] = sum over
+ * them of exp(C - that max); tile_rec [ceil(M / 16)][2][N] floats, 16-byte aligned.  A consumer merges the records of the
+ * rows it normalises over instead of reading C for them.  N a multiple of 4 besides the limits above, C 16-byte rows. */
+int vt_gemm_bn_apply_tile_records(int M, int N, int K, const float *A, int lda, const float *stat, const float *gamma,
+                                  const float *beta, float *A_out, const float *B, int ldb, int transB, const float *bias,
+                                  float *C, int ldc, float *tile_rec, vt_stream s);
 /* Products that read the delta behind the projector's BatchNorm (MaxPool2DLayer::backward + ReLU mask + BatchNorm
  * backward, layers/pooling_layer.hpp:68-97, relu_layer.hpp:20-33, batch_normalization_layer.hpp:172-200) as RECORDS
  * instead of a dense [rows, N] matrix.  With pooling windows a multiple of 16 wide, 16 adjacent elements of a row hold

@@ -131,6 +131,25 @@ def test_batchnorm_apply_inside_its_first_product():
     want_x = (A.astype(np.float64) - stat[:K]) * stat[K:] * gamma + beta
     assert rel_err(x.cpu().numpy(), want_x) < 2e-6
     assert rel_err(out.cpu().numpy(), want_x @ B.astype(np.float64) + bias) < 2e-6
+    # the same launch leaving per-tile records of the softmax over rows (maximum, sum of exp relative to it)
+    tiles = (M + 15) // 16
+    for Nn, dB_, dbias_, Bn, biasn in ((N, d[4], d[5], B, bias),):
+        rec = torch.full((tiles, 2, Nn), -7.0, dtype=torch.float32, device="cuda")
+        x3 = torch.zeros((M, K), dtype=torch.float32, device="cuda")
+        out3 = torch.zeros((M, Nn), dtype=torch.float32, device="cuda")
+        check(lib.vt_gemm_bn_apply_tile_records(M, Nn, K, P(d[0]), K, P(d[1]), P(d[2]), P(d[3]), P(x3), P(dB_), Nn, 0, P(dbias_),
+                                                P(out3), Nn, P(rec), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+              "vt_gemm_bn_apply_tile_records")
+        torch.cuda.synchronize()
+        assert torch.equal(out3, out) and torch.equal(x3, x)
+        S = out3.cpu().numpy().astype(np.float64)
+        pad = np.full((tiles * 16 - M, Nn), -np.inf)
+        St = np.concatenate([S, pad]).reshape(tiles, 16, Nn)
+        tm = St.max(axis=1)
+        tz = np.exp(St - tm[:, None, :]).sum(axis=1)
+        r = rec.cpu().numpy()
+        assert np.array_equal(r[:, 0, :], tm.astype(np.float32))
+        assert rel_err(r[:, 1, :], tz) < 2e-6
     # 17 ... 128 result columns: refused, nothing launched
     assert lib.vt_gemm_bn_apply(M, 32, K, P(d[0]), K, P(d[1]), P(d[2]), P(d[3]), P(x), P(d[4]), 32, 0, None, P(out), 32, None) == -2
     # 196 result columns (thirteen tiles)
@@ -143,3 +162,16 @@ def test_batchnorm_apply_inside_its_first_product():
     torch.cuda.synchronize()
     assert rel_err(x2.cpu().numpy(), want_x) < 2e-6
     assert rel_err(out2.cpu().numpy(), want_x @ B2.astype(np.float64) + bias2) < 2e-6
+    rec2 = torch.full((tiles, 2, 196), -7.0, dtype=torch.float32, device="cuda")
+    out4 = torch.zeros((M, 196), dtype=torch.float32, device="cuda")
+    check(lib.vt_gemm_bn_apply_tile_records(M, 196, K, P(d[0]), K, P(d[1]), P(d[2]), P(d[3]), P(x2), P(dB2), 196, 0, P(dbias2),
+                                            P(out4), 196, P(rec2), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+          "vt_gemm_bn_apply_tile_records")
+    torch.cuda.synchronize()
+    assert torch.equal(out4, out2)
+    S = out4.cpu().numpy().astype(np.float64)
+    St = np.concatenate([S, np.full((tiles * 16 - M, 196), -np.inf)]).reshape(tiles, 16, 196)
+    tm = St.max(axis=1)
+    r = rec2.cpu().numpy()
+    assert np.array_equal(r[:, 0, :], tm.astype(np.float32))
+    assert rel_err(r[:, 1, :], np.exp(St - tm[:, None, :]).sum(axis=1)) < 2e-6

@@ -458,6 +458,9 @@ struct GemmSumP {
   // backward r <- a * (r - sum_row a * r) with a = epi_a (laid out like C); 0 = none
   int epi;
   const float *epi_a;
+  // epi 3: C is stored as it is, and per 16-row tile and column the softmax-over-rows record of the tile goes to
+  // tile_rec [ceil(M / 16) per batch member][2][N]: the maximum of the tile's rows and the sum of exp(value - maximum)
+  float *tile_rec;
   // row-panel kernels built with DZ: term 0's A holds delta records (one pair per row and group of 16 adjacent k:
   // value, k inside the group; every other element of the group zero) and A[m][k] = dz_coef[K + k] + dz_coef[k] * delta
   const float *dz_coef;
@@ -524,6 +527,11 @@ __global__ __launch_bounds__(256) void k_gemm_sum(GemmSumP p) {
 // the matrix instructions that consume them, with no LDS staging and no workgroup barrier in the loop.
 // (The 16x16x4 fp32 instruction wants lane group g to hold k = step, not four consecutive k; a sum over k does
 // not care about the order, so instruction j of a step takes k = 4g + j from both operands.)
+// x of the lane N places further on in its row of 16 lanes (rotation within the row)
+template <int N>
+__device__ __forceinline__ float row_ror(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x120 + N, 0xf, 0xf, false));
+}
 struct PanelStep {
   const float *A;  // the term's A at this batch member
   int lda, K, k0, kofs;  // kofs: the step's first k row / column inside the LDS copy of op(B)
@@ -805,6 +813,44 @@ __global__ __launch_bounds__(64 * WV, (WV > 8 || (NT > 8 && EPI != 2)) ? 4 : 1) 
             for (int j = 0; j < NT; ++j)
 #pragma unroll
               for (int v = 0; v < 4; ++v) r[j][v] /= sum;
+          } else if constexpr (EPI == 3) {
+            // column records of this tile: the 16 rows of a column sit in the 16 lanes c of one lane group g
+            float *__restrict__ rec = p.tile_rec + ((long)b * ((p.M + 15) >> 4) + (row0 >> 4)) * 2 * p.N;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+              const int gn = j * 16 + 4 * g;
+              float mx[4], se[4];
+#pragma unroll
+              for (int v = 0; v < 4; ++v) {
+                const float x = row_on ? r[j][v] : -INFINITY;
+                // all-reduce over the 16 lanes of a row by rotations (data-parallel-primitive operands: no LDS trip)
+                float m = x;
+                m = fmaxf(m, row_ror<8>(m));
+                m = fmaxf(m, row_ror<4>(m));
+                m = fmaxf(m, row_ror<2>(m));
+                m = fmaxf(m, row_ror<1>(m));
+                float e = row_on ? __expf(x - m) : 0.f;  // row 0 of a tile inside the matrix exists: m is finite there
+                e += row_ror<8>(e);
+                e += row_ror<4>(e);
+                e += row_ror<2>(e);
+                e += row_ror<1>(e);
+                mx[v] = m;
+                se[v] = e;
+              }
+              if (c == 0 && gn < p.N && row0 < p.M) {  // (a workgroup's last tiles may lie past the matrix)
+                if (QUAD || gn + 3 < p.N) {
+                  *reinterpret_cast<float4 *>(rec + gn) = make_float4(mx[0], mx[1], mx[2], mx[3]);
+                  *reinterpret_cast<float4 *>(rec + p.N + gn) = make_float4(se[0], se[1], se[2], se[3]);
+                } else {
+#pragma unroll
+                  for (int v = 0; v < 4; ++v)
+                    if (gn + v < p.N) {
+                      rec[gn + v] = mx[v];
+                      rec[p.N + gn + v] = se[v];
+                    }
+                }
+              }
+            }
           } else {
             const float *__restrict__ arow = p.epi_a + (long)b * p.sC + gm * p.ldc;
             const bool vecE = QUAD || (vecC && (reinterpret_cast<uintptr_t>(p.epi_a) & 15) == 0);
@@ -980,7 +1026,13 @@ static int panel_launch(int form, const GemmSumP &p, int batch, hipStream_t hs, 
     else if (NT == 8) VT_PANEL(PR_, 8, 0);  \
     else VT_PANEL(PR_, 13, 0);              \
   } while (0)
-  if (p.epi != 0) {  // the row epilogues are built for one and for thirteen result tiles, without the on-load forms but records
+  if (p.epi == 3) {  // tile records of the softmax over rows: built for the normalise-on-load form
+    if ((NT != 1 && NT != 13) || !ax || dz || !p.tile_rec || p.N % 4 != 0 || p.ldc % 4 != 0 || p.sC % 4 != 0 ||
+        (reinterpret_cast<uintptr_t>(p.C) & 15) != 0 || (reinterpret_cast<uintptr_t>(p.tile_rec) & 15) != 0)
+      return 0;
+    if (NT == 1) e = panel_go<0, 1, 2, 3>(grid, lds, hs, p, rows, Kp, nsteps);
+    else e = panel_go<0, 13, 2, 3>(grid, lds, hs, p, rows, Kp, nsteps);
+  } else if (p.epi != 0) {  // the row epilogues are built for one and for thirteen result tiles, without the on-load forms but records
     if ((NT != 1 && NT != 13) || ax || (dz && p.epi != 2)) return 0;
     if (NT == 13 && (p.N % 4 != 0 || p.ldc % 4 != 0 || p.sC % 4 != 0 || (reinterpret_cast<uintptr_t>(p.C) & 15) != 0 ||
                      (p.epi == 2 && (reinterpret_cast<uintptr_t>(p.epi_a) & 15) != 0)))
@@ -1081,8 +1133,10 @@ static int gemm_launch(int form, int transA, int transB, int M, int N, int K, fl
 #undef VT_GEMM_LAUNCH
   VT_CHECK_LAUNCH();
   if (p.ksplit > 1 && !bias && !accumulate && ldc == N && (batch == 1 || strideC == (long)M * N) &&
-      (long)M * N * batch < (1L << 30)) {
+      (long)M * N * batch <= (1L << 19)) {
     // plain case (the weight gradients): the partial tiles are rows of a [slices, batch*M*N] matrix
+    // (results of more than half a million elements go to the element-wise pass below: the slab reduction is laid out
+    // for many rows of few columns and reads a few wide rows at a fifth of that pass's rate)
     return vt_reduce_rows(workspace, p.ksplit, (int)((long)M * N * batch), (int)((long)M * N * batch), C, s);
   }
   if (p.ksplit > 1) {
@@ -1157,9 +1211,9 @@ extern "C" int vt_gemm_sum(int form, int nterms, const vt_gemm_term *terms, int 
   return 0;
 }
 
-extern "C" int vt_gemm_bn_apply(int M, int N, int K, const float *A, int lda, const float *stat, const float *gamma,
-                                const float *beta, float *A_out, const float *B, int ldb, int transB, const float *bias, float *C,
-                                int ldc, vt_stream s) {
+static int bn_apply_launch(int M, int N, int K, const float *A, int lda, const float *stat, const float *gamma,
+                           const float *beta, float *A_out, const float *B, int ldb, int transB, const float *bias, float *C,
+                           int ldc, float *tile_rec, vt_stream s) {
   if (M < 1 || N < 1 || K < 1 || !A || !stat || !gamma || !beta || !A_out || !B || !C || lda < K || ldc < N ||
       ldb < (transB ? K : N))
     return VT_EINVAL;
@@ -1170,9 +1224,26 @@ extern "C" int vt_gemm_bn_apply(int M, int N, int K, const float *A, int lda, co
                     aligned(B) && ldb % 4 == 0 && (transB ? K % 4 == 0 : N % 4 == 0)};
   p.nterms = 1; p.C = C; p.bias = bias; p.M = M; p.N = N; p.ldc = ldc; p.sC = 0; p.alpha = 1.f;
   p.ax_stat = stat; p.ax_gamma = gamma; p.ax_beta = beta; p.ax_out = A_out;
+  if (tile_rec) {
+    p.epi = 3;
+    p.tile_rec = tile_rec;
+  }
   const int took = panel_launch(0, p, 1, (hipStream_t)s, false, true);
   if (took < 0) return -took;
   return took > 0 ? 0 : VT_EUNSUPPORTED;
+}
+
+extern "C" int vt_gemm_bn_apply(int M, int N, int K, const float *A, int lda, const float *stat, const float *gamma,
+                                const float *beta, float *A_out, const float *B, int ldb, int transB, const float *bias, float *C,
+                                int ldc, vt_stream s) {
+  return bn_apply_launch(M, N, K, A, lda, stat, gamma, beta, A_out, B, ldb, transB, bias, C, ldc, nullptr, s);
+}
+
+extern "C" int vt_gemm_bn_apply_tile_records(int M, int N, int K, const float *A, int lda, const float *stat, const float *gamma,
+                                             const float *beta, float *A_out, const float *B, int ldb, int transB,
+                                             const float *bias, float *C, int ldc, float *tile_rec, vt_stream s) {
+  if (!tile_rec) return VT_EINVAL;
+  return bn_apply_launch(M, N, K, A, lda, stat, gamma, beta, A_out, B, ldb, transB, bias, C, ldc, tile_rec, s);
 }
 
 // ---- transposed-A product with at most 16 result rows and B given as delta records: C[b] = A[b]^T . expand(rec[b]),

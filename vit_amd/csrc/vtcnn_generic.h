@@ -18,6 +18,7 @@ struct GenModel {
   float *col, *conv, *x, *tokA, *T0, *tok, *a, *hdn, *rl, *s2, *o, *Mq, *k, *v, *pa, *z, *pooled, *logits, *probs;
   int *pool_idx;
   float *stat_bn, *stat_n1, *stat_n2, *stat_pn, *coef, *part, *ws, *spx;
+  float *spt;  // tile records of the tokenizer's softmax over pixels ([N * P / 16][2][L]; null when P is not a multiple of 16)
   long part_floats, ws_floats;
   // backward
   float *dlogits, *dpool, *du, *dz, *pdx, *dsa, *dsa_tok, *U, *dv, *dk, *pdt, *d0, *ds2, *dh, *da, *dr, *dc;

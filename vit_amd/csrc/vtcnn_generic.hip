@@ -408,6 +408,39 @@ __global__ __launch_bounds__(GT) void k_softpix_merge(const float *__restrict__ 
   fin[(size_t)n * 2 * Lt + Lt + l] = z;
 }
 
+// records per 16-row tile (written by the score product's own launch, vt_gemm_bn_apply_tile_records; rec [tiles][2][Lt]
+// per sample) to chunk records in k_softpix_partial's format: workgroup (x, n, z) takes 64 columns of chunk z of sample
+// n's tiles, 16 tile lanes per column; maxima first, then the sums relative to them.  k_softpix_merge finishes.
+template <int CW>  // columns per workgroup (16 or 64); 1024 / CW tile lanes per column
+__global__ __launch_bounds__(1024) void k_softpix_tiles_to_chunks(const float *__restrict__ rec, int tiles, int Lt,
+                                                                  float *__restrict__ out) {
+  constexpr int TL = 1024 / CW;
+  __shared__ float sh[TL][CW];
+  const int tx = threadIdx.x % CW, ty = threadIdx.x / CW, l = blockIdx.x * CW + tx, n = blockIdx.y;
+  const int nch = gridDim.z, per = (tiles + nch - 1) / nch, t0 = blockIdx.z * per, t1 = min(tiles, t0 + per);
+  const bool on = l < Lt;
+  const float *__restrict__ r0 = rec + (size_t)n * tiles * 2 * Lt + (on ? l : 0);
+  float m = -INFINITY;
+  if (on)
+    for (int t = t0 + ty; t < t1; t += TL) m = fmaxf(m, r0[(size_t)t * 2 * Lt]);
+  sh[ty][tx] = m;
+  __syncthreads();
+  for (int k = 0; k < TL; ++k) m = fmaxf(m, sh[k][tx]);
+  __syncthreads();
+  float z = 0.f;
+  if (on)
+    for (int t = t0 + ty; t < t1; t += TL) z += r0[(size_t)t * 2 * Lt + Lt] * expf(r0[(size_t)t * 2 * Lt] - m);
+  sh[ty][tx] = z;
+  __syncthreads();
+  if (ty == 0 && on) {
+    float zz = 0.f;
+    for (int k = 0; k < TL; ++k) zz += sh[k][tx];
+    float *__restrict__ o = out + ((size_t)n * nch + blockIdx.z) * 2 * Lt;
+    o[l] = m;          // an empty chunk leaves (-inf, 0): k_softpix_merge gives it weight exp(-inf) = 0
+    o[Lt + l] = zz;
+  }
+}
+
 template <int VEC>
 __global__ __launch_bounds__(GT) void k_softpix_apply(float *__restrict__ S, int P, int Lt, ColGeo geo,
                                                       const float *__restrict__ fin) {
@@ -1087,6 +1120,24 @@ int softmax_pixels(vt::GenModel *g, float *S, int n, int P, int Lt, hipStream_t 
   return 0;
 }
 
+// the same softmax when the launch that wrote S left records per 16-row tile in g->spt: merge, normalise
+int softmax_pixels_from_tiles(vt::GenModel *g, float *S, int n, int P, int Lt, hipStream_t s) {
+  const ColGeo geo = col_geo(Lt);
+  const dim3 grid((P + SPX_CHUNK - 1) / SPX_CHUNK, n);
+  const int tiles = P / 16;
+  int nch = (int)grid.x;  // as many chunks as k_softpix_partial would leave fit the buffer; fewer when the device is full anyway
+  const int cw = Lt <= 16 ? 16 : 64;
+  while (nch > 1 && (long)nch * n * ((Lt + cw - 1) / cw) > 2048) nch >>= 1;
+  float *fin = g->spx + (size_t)n * grid.x * 2 * Lt;
+  if (cw == 16) hipLaunchKernelGGL(k_softpix_tiles_to_chunks<16>, dim3((Lt + 15) / 16, n, nch), dim3(1024), 0, s, g->spt, tiles, Lt, g->spx);
+  else hipLaunchKernelGGL(k_softpix_tiles_to_chunks<64>, dim3((Lt + 63) / 64, n, nch), dim3(1024), 0, s, g->spt, tiles, Lt, g->spx);
+  hipLaunchKernelGGL(k_softpix_merge, dim3((Lt + GT - 1) / GT, n), dim3(GT), 0, s, g->spx, nch, Lt, fin);
+  if (geo.vec == 4) hipLaunchKernelGGL(k_softpix_apply<4>, grid, dim3(GT), 0, s, S, P, Lt, geo, fin);
+  else hipLaunchKernelGGL(k_softpix_apply<1>, grid, dim3(GT), 0, s, S, P, Lt, geo, fin);
+  VT_CHECK_LAUNCH();
+  return 0;
+}
+
 int softmax_rows(float *S, long rows, int Wd, hipStream_t s) {
   if (Wd == 16) hipLaunchKernelGGL(k_softmax_rows16, dim3((unsigned)((rows * 16 + GT - 1) / GT)), dim3(GT), 0, s, S, rows);
   else if (Wd <= 64) hipLaunchKernelGGL(k_softmax_rows_reg<1>, dim3((unsigned)((rows + 3) / 4)), dim3(GT), 0, s, S, rows, Wd);
@@ -1158,6 +1209,8 @@ int gen_create(GenModel *g, const vt_dims *d, int maxN, int (*alloc)(void *, flo
   g->part_floats = 8192L * 2 * std::max(std::max(C1, C2), std::max(D, 64)) + 1024;
   A(&g->part, (size_t)g->part_floats, nullptr);
   A(&g->spx, N * ((g->P + SPX_CHUNK - 1) / SPX_CHUNK + 1) * 2 * L, nullptr);
+  g->spt = nullptr;
+  if (g->P % 16 == 0 && L % 4 == 0) A(&g->spt, N * (g->P / 16) * 2 * L, nullptr);
   g->ws_floats = 16L << 20;
   A(&g->ws, (size_t)g->ws_floats, nullptr);
   // backward
@@ -1226,9 +1279,15 @@ int gen_forward(GenModel *g, const float *arena, const vt_layout *lo, float *are
   // FilterTokenizer::forward (layers/tokenizer.hpp:22-48).  The BatchNorm apply rides in the launch of its first
   // reader, the tokenizer's score product, where the row-panel kernel takes the shape: x is written by that launch and
   // the convolution output is read once for both
+  bool tiles_done = false;  // the score launch also left the per-tile records of the softmax over pixels
   {
     int rc = VT_EUNSUPPORTED;
-    if (!g->bf16 && NP < (1L << 31))
+    if (!g->bf16 && NP < (1L << 31) && g->spt) {
+      rc = vt_gemm_bn_apply_tile_records((int)NP, L, C1, g->conv, C1, g->stat_bn, W("bn.gamma"), W("bn.beta"), g->x,
+                                         W("tok.linear1.W"), L, 0, W("tok.linear1.b"), g->tokA, L, g->spt, (vt_stream)s);
+      tiles_done = rc == 0;
+    }
+    if (rc == VT_EUNSUPPORTED && !g->bf16 && NP < (1L << 31))
       rc = vt_gemm_bn_apply((int)NP, L, C1, g->conv, C1, g->stat_bn, W("bn.gamma"), W("bn.beta"), g->x, W("tok.linear1.W"), L, 0,
                             W("tok.linear1.b"), g->tokA, L, (vt_stream)s);
     if (rc == VT_EUNSUPPORTED) {
@@ -1238,7 +1297,8 @@ int gen_forward(GenModel *g, const float *arena, const vt_layout *lo, float *are
       return rc;
     }
   }
-  VTG(softmax_pixels(g, g->tokA, n, P, L, s));
+  if (tiles_done) VTG(softmax_pixels_from_tiles(g, g->tokA, n, P, L, s));
+  else VTG(softmax_pixels(g, g->tokA, n, P, L, s));
   VTG(mm(true, false, L, C1, P, g->tokA, L, g->x, C1, g->T0, C1, nullptr, false, 1.f, n, (long)P * L, (long)P * C1,
          (long)L * C1));
   VTG(mm(false, false, (int)NL, D, C1, g->T0, C1, W("tok.linear2.W"), D, g->tok, D, W("tok.linear2.b")));
