@@ -156,7 +156,7 @@ def measured_step_traffic(shape, batch, classes):
     """HBM bytes of one whole general-shape training step from the committed PMC passes; None off the measured
     configurations."""
     try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "r02_k_step_hbm_traffic_shapes.json")))
+        t = json.load(open(os.path.join(ROOT, "profiles", "r03_e_step_hbm_traffic_shapes.json")))
         return int(t["steps"]["%s_b%d_k%d" % (shape, batch, classes)]["traffic_bytes"])
     except (OSError, KeyError, ValueError):
         return None
@@ -539,7 +539,8 @@ def main():
     # Untimed settle steps between the warm-up's per-launcher breakdown (which ends in a device synchronisation and a
     # host read-back: the GPU idles and drops its clocks) and the timed region, so that a short timed region (the
     # driver's 20 steps are 5 ms) measures the steady state and not the ramp after an idle gap.
-    settle = max(0, int(os.environ.get("VT_BENCH_SETTLE", "60")))
+    # (the general shapes run milliseconds per step: their clocks are settled by the warm-up itself)
+    settle = max(0, int(os.environ.get("VT_BENCH_SETTLE", "0" if generic else "60")))
     for i in range(settle):
         step(a.warmup + a.steps + i)
     m.profile(dominant + "/8")  # restart the event-pair count: only timed steps are counted

@@ -1,7 +1,7 @@
 """Turns the outputs of tools/profile_shapes.sh (gpurun_out/shapes/) into the committed summaries under profiles/:
 kernel traces, bench lines, per-kernel traffic tables and the whole-step traffic totals.
 
-    python tools/shape_profiles_to_repo.py <tag>      e.g. r02_k
+    python tools/shape_profiles_to_repo.py <tag> [shape ...]     e.g. r02_k, or r03_e wide
 """
 import csv
 import glob
@@ -24,10 +24,13 @@ def step_rows(d, counter):
 
 def main():
     tag = sys.argv[1]
+    only = sys.argv[2:]  # shapes to take (default: both)
     totals = {"unit": "bytes per training step (every launch of one step)",
               "formula": "sum over the step's launches of 1024 * (2 * FETCH_SIZE + WRITE_SIZE), separate rocprofv3 --pmc passes "
                          "of bench.py --steps 1 --warmup 1 (tools/profile_shapes.sh)", "steps": {}}
     for sh, b in CFG.items():
+        if only and sh not in only:
+            continue
         line = [l for l in open("%s/%s_bench.json" % (SRC, sh)) if l.startswith("{")][-1]
         d = json.loads(line)
         open("%s/profiles/%s_%s_bench_line.json" % (ROOT, tag, sh), "w").write(line)
