@@ -183,6 +183,60 @@ def test_gemm_with_softmax_epilogues(form, tol):
                                     C.c_void_p(dC.data_ptr()), 16, 1, None) != 0  # backward needs a
 
 
+def test_gemm_sum_with_batchnorm_partial_records():
+    """vt_gemm_sum_colstats: the sum of products plus, per block of rows, (sum, squared distances from the block's mean)
+    of every result column; vt_bn_stats_finalize on those records gives the statistics of the result (numpy, float64)."""
+    import torch
+    from vit_amd._lib import VtGemmTerm, check, lib
+    rng = np.random.default_rng(11)
+    for (M, N, batch, ks) in [(4096, 128, 3, (64, 16)), (5000, 100, 1, (64, 196)), (2048, 128, 16, (32,))]:
+        terms = (VtGemmTerm * len(ks))()
+        keep, want = [], np.zeros((batch, M, N))
+        for t, K in enumerate(ks):
+            A = (rng.standard_normal((batch, M, K)) + 0.3).astype(np.float32)
+            B = rng.standard_normal((batch, K, N)).astype(np.float32)
+            dA, dB = torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda()
+            keep += [dA, dB]
+            terms[t] = VtGemmTerm(dA.data_ptr(), dB.data_ptr(), M * K, K * N, K, K, N, 0)
+            want += A.astype(np.float64) @ B.astype(np.float64)
+        bias = (rng.standard_normal(N) * 3).astype(np.float32)
+        want += bias
+        pivot = (want.reshape(-1, N).mean(0) + rng.standard_normal(N) * 0.5).astype(np.float32)
+        dbias, dpiv = torch.from_numpy(bias).cuda(), torch.from_numpy(pivot).cuda()
+        dC = torch.zeros((batch, M, N), dtype=torch.float32, device="cuda")
+        dC2 = torch.zeros_like(dC)
+        part = torch.full((batch * ((M + 127) // 128) * 2 * N,), -3.0, dtype=torch.float32, device="cuda")
+        rpb = C.c_int(0)
+        s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        check(lib.vt_gemm_sum_colstats(2, len(ks), terms, M, N, 1.0, C.c_void_p(dC.data_ptr()), N, M * N,
+                                       C.c_void_p(dbias.data_ptr()), batch, C.c_void_p(dpiv.data_ptr()),
+                                       C.c_void_p(part.data_ptr()), part.numel(), C.byref(rpb), s), "vt_gemm_sum_colstats")
+        check(lib.vt_gemm_sum(2, len(ks), terms, M, N, 1.0, 0, C.c_void_p(dC2.data_ptr()), N, M * N,
+                              C.c_void_p(dbias.data_ptr()), batch, s), "vt_gemm_sum")
+        torch.cuda.synchronize()
+        assert torch.equal(dC, dC2)
+        rows = rpb.value
+        assert rows >= 128 and (batch == 1 or M % rows == 0)
+        nb = batch * ((M + rows - 1) // rows)
+        got = dC.cpu().numpy().astype(np.float64).reshape(batch * M, N)
+        rec = part.cpu().numpy()[:nb * 2 * N].reshape(nb, 2, N)
+        for b in (0, nb // 2, nb - 1):
+            blk = got[b * rows:(b + 1) * rows] if batch == 1 else got.reshape(batch, M, N)[b // (M // rows)][(b % (M // rows)) * rows:][:rows]
+            assert rel_err(rec[b, 0], blk.sum(0)) < 2e-6, (M, N, b)
+            assert rel_err(rec[b, 1], ((blk - blk.mean(0)) ** 2).sum(0)) < 2e-5, (M, N, b)
+        stat = torch.zeros(2 * N, dtype=torch.float32, device="cuda")
+        rm, rv = torch.zeros(N, device="cuda"), torch.ones(N, device="cuda")
+        check(lib.vt_bn_stats_finalize(C.c_void_p(part.data_ptr()), nb, N, rows, batch * M, C.c_void_p(rm.data_ptr()),
+                                       C.c_void_p(rv.data_ptr()), C.c_void_p(stat.data_ptr()), s), "vt_bn_stats_finalize")
+        torch.cuda.synchronize()
+        st = stat.cpu().numpy()
+        assert rel_err(st[:N], got.mean(0)) < 2e-6
+        assert rel_err(st[N:], 1.0 / np.sqrt(got.var(0) + 1e-5)) < 2e-5
+    # shapes the row-panel kernel does not take with records: refused, nothing launched
+    assert lib.vt_gemm_sum_colstats(2, 1, terms, 300, 128, 1.0, C.c_void_p(dC.data_ptr()), 128, 300 * 128, None, 1, None,
+                                    C.c_void_p(part.data_ptr()), part.numel(), C.byref(rpb), s) == -2
+
+
 def _bf16_round(a):
     u = a.astype(np.float32).view(np.uint32).astype(np.uint64)
     u = (u + 0x7FFF + ((u >> 16) & 1)) >> 16 << 16

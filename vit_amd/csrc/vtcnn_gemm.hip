@@ -461,6 +461,12 @@ struct GemmSumP {
   // epi 3: C is stored as it is, and per 16-row tile and column the softmax-over-rows record of the tile goes to
   // tile_rec [ceil(M / 16) per batch member][2][N]: the maximum of the tile's rows and the sum of exp(value - maximum)
   float *tile_rec;
+  // epi 4: C is stored as it is, and every workgroup leaves the BatchNorm partial record of its rows (k_colstats' format:
+  // sum, sum of squared distances from the workgroup's own mean) in col_part [batch][workgroups][2][N]; the second
+  // moments are accumulated around col_pivot [N] (may be null: zero)
+  float *col_part;
+  long col_part_floats;
+  const float *col_pivot;
   // row-panel kernels built with DZ: term 0's A holds delta records (one pair per row and group of 16 adjacent k:
   // value, k inside the group; every other element of the group zero) and A[m][k] = dz_coef[K + k] + dz_coef[k] * delta
   const float *dz_coef;
@@ -656,6 +662,12 @@ __global__ __launch_bounds__(64 * WV, (WV > 8 || (NT > 8 && EPI != 2)) ? 4 : 1) 
       zc[i] = k >= K0 ? 0.f : w == 0 ? p.ax_stat[k] : w == 1 ? p.ax_stat[K0 + k] : w == 2 ? p.ax_gamma[k] : p.ax_beta[k];
     }
   }
+  // EPI 4: per-wave running sums [WV][2][NP16] of (value - pivot) and its square, and the pivot [NP16], behind op(B)
+  float *__restrict__ cst = reinterpret_cast<float *>(smem + PANEL_HEAD) + (PR == 2 ? NP16 * ldk : Kp * ldn);
+  if constexpr (EPI == 4) {
+    for (int i = tid; i < WV * 2 * NP16; i += (64 * WV)) cst[i] = 0.f;
+    for (int i = tid; i < NP16; i += (64 * WV)) cst[WV * 2 * NP16 + i] = (p.col_pivot && i < p.N) ? p.col_pivot[i] : 0.f;
+  }
   __syncthreads();
 
   const int G = (nsteps + 3) >> 2;  // groups of four steps: one group is in the matrix cores, the next in flight
@@ -813,6 +825,36 @@ __global__ __launch_bounds__(64 * WV, (WV > 8 || (NT > 8 && EPI != 2)) ? 4 : 1) 
             for (int j = 0; j < NT; ++j)
 #pragma unroll
               for (int v = 0; v < 4; ++v) r[j][v] /= sum;
+          } else if constexpr (EPI == 4) {
+            // column sums of (value - pivot) and of its square over the tile's rows (the 16 lanes of a lane row), added to
+            // this wave's running sums in LDS by the row's first lane
+            float *__restrict__ ws = cst + wave * 2 * NP16;
+            const float *__restrict__ piv = cst + WV * 2 * NP16;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+              const int gn = j * 16 + 4 * g;
+              const float4 pv = *reinterpret_cast<const float4 *>(piv + gn);
+              const float pq[4] = {pv.x, pv.y, pv.z, pv.w};
+              float s1[4], s2[4];
+#pragma unroll
+              for (int v = 0; v < 4; ++v) {
+                const float d = row_on ? r[j][v] - pq[v] : 0.f;
+                float a = d, q = d * d;
+                a += row_ror<8>(a); q += row_ror<8>(q);
+                a += row_ror<4>(a); q += row_ror<4>(q);
+                a += row_ror<2>(a); q += row_ror<2>(q);
+                a += row_ror<1>(a); q += row_ror<1>(q);
+                s1[v] = a;
+                s2[v] = q;
+              }
+              if (c == 0) {
+                float4 o1 = *reinterpret_cast<float4 *>(ws + gn), o2 = *reinterpret_cast<float4 *>(ws + NP16 + gn);
+                o1.x += s1[0]; o1.y += s1[1]; o1.z += s1[2]; o1.w += s1[3];
+                o2.x += s2[0]; o2.y += s2[1]; o2.z += s2[2]; o2.w += s2[3];
+                *reinterpret_cast<float4 *>(ws + gn) = o1;
+                *reinterpret_cast<float4 *>(ws + NP16 + gn) = o2;
+              }
+            }
           } else if constexpr (EPI == 3) {
             // column records of this tile: the 16 rows of a column sit in the 16 lanes c of one lane group g
             float *__restrict__ rec = p.tile_rec + ((long)b * ((p.M + 15) >> 4) + (row0 >> 4)) * 2 * p.N;
@@ -927,6 +969,25 @@ __global__ __launch_bounds__(64 * WV, (WV > 8 || (NT > 8 && EPI != 2)) ? 4 : 1) 
       for (int e = 0; e < 4; ++e) cur[e] = nxt[e];
     }
   }
+  if constexpr (EPI == 4) {
+    // the workgroup's record: the waves' sums in wave order, brought from the pivot to (sum, squared distances from
+    // the workgroup's own mean)
+    __syncthreads();
+    if (tid < p.N) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < WV; ++w) {
+        s1 += cst[w * 2 * NP16 + tid];
+        s2 += cst[w * 2 * NP16 + NP16 + tid];
+      }
+      const long left = p.M - wg_row0;
+      const double n = (double)(left < rows_per_wg ? (left > 0 ? left : 0) : rows_per_wg);
+      const double pv = (double)cst[WV * 2 * NP16 + tid];
+      float *__restrict__ o = p.col_part + ((long)b * gridDim.x + blockIdx.x) * 2 * p.N;
+      o[tid] = (float)((double)s1 + n * pv);
+      o[p.N + tid] = n > 0.0 ? (float)((double)s2 - (double)s1 * (double)s1 / n) : 0.f;
+    }
+  }
 }
 
 // C[b][m][n] = sum over slices of part[s][b][m][n] (+ bias) (+ C), slices in ascending order.
@@ -971,7 +1032,8 @@ static hipError_t panel_go(dim3 grid, size_t lds, hipStream_t hs, const GemmSumP
 
 // Row-panel launch of a sum of products when it is tall and narrow and every A is 16-byte loadable; returns
 // 1 when it took the job, 0 when the tiled kernels should, < 0 on a launch error.
-static int panel_launch(int form, const GemmSumP &p, int batch, hipStream_t hs, bool dz = false, bool ax = false) {
+static int panel_launch(int form, const GemmSumP &p, int batch, hipStream_t hs, bool dz = false, bool ax = false,
+                        int *rows_out = nullptr) {
   static const bool off = [] {
     const char *e = getenv("VT_GEMM_PANEL");
     return e && *e == '0';
@@ -1026,7 +1088,17 @@ static int panel_launch(int form, const GemmSumP &p, int batch, hipStream_t hs, 
     else if (NT == 8) VT_PANEL(PR_, 8, 0);  \
     else VT_PANEL(PR_, 13, 0);              \
   } while (0)
-  if (p.epi == 3) {  // tile records of the softmax over rows: built for the normalise-on-load form
+  if (p.epi == 4) {  // BatchNorm partial records of the result's columns: built for the split form with eight tiles
+    if (NT != 8 || form != 2 || ax || dz || p.accumulate || !p.col_part) return 0;
+    if (batch > 1 && p.M % rows != 0) return 0;  // every workgroup but the launch's last must hold `rows` rows
+    if ((long)batch * grid.x * 2 * p.N > p.col_part_floats) return 0;
+    const bool sixteen = lds > 80 * 1024 && wide16;  // decided as for the plain launch, before the slots are added
+    lds += ((size_t)(sixteen ? 16 : 8) * 2 + 1) * NT * 16 * sizeof(float);
+    if (lds > (size_t)PANEL_LDS_MAX) return 0;
+    if (sixteen) e = panel_go<2, 8, 0, 4, 16>(grid, lds, hs, p, rows, Kp, nsteps);
+    else e = panel_go<2, 8, 0, 4>(grid, lds, hs, p, rows, Kp, nsteps);
+    if (e == hipSuccess && rows_out) *rows_out = rows;
+  } else if (p.epi == 3) {  // tile records of the softmax over rows: built for the normalise-on-load form
     if ((NT != 1 && NT != 13) || !ax || dz || !p.tile_rec || p.N % 4 != 0 || p.ldc % 4 != 0 || p.sC % 4 != 0 ||
         (reinterpret_cast<uintptr_t>(p.C) & 15) != 0 || (reinterpret_cast<uintptr_t>(p.tile_rec) & 15) != 0)
       return 0;
@@ -1170,8 +1242,10 @@ extern "C" int vt_gemm_f32x3(int transA, int transB, int M, int N, int K, float 
                      batch, workspace, workspace_floats, s);
 }
 
-extern "C" int vt_gemm_sum(int form, int nterms, const vt_gemm_term *terms, int M, int N, float alpha, int accumulate,
-                           float *C, int ldc, long strideC, const float *bias, int batch, vt_stream s) {
+// col_part != nullptr: the launch also leaves the BatchNorm partial records of C's columns (row-panel kernel only)
+static int gemm_sum_launch(int form, int nterms, const vt_gemm_term *terms, int M, int N, float alpha, int accumulate,
+                           float *C, int ldc, long strideC, const float *bias, int batch, const float *col_pivot, float *col_part,
+                           long col_part_floats, int *rows_per_block, vt_stream s) {
   if (form < 0 || form > 2 || nterms < 1 || nterms > 4 || !terms || M < 1 || N < 1 || batch < 1 || !C || ldc < N) return VT_EINVAL;
   GemmSumP p{};
   auto aligned = [](const float *q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
@@ -1187,6 +1261,14 @@ extern "C" int vt_gemm_sum(int form, int nterms, const vt_gemm_term *terms, int 
   }
   p.nterms = nterms; p.C = C; p.bias = bias; p.M = M; p.N = N; p.ldc = ldc; p.sC = strideC; p.alpha = alpha;
   p.accumulate = accumulate ? 1 : 0;
+  if (col_part) {
+    p.epi = 4;
+    p.col_part = col_part;
+    p.col_part_floats = col_part_floats;
+    p.col_pivot = col_pivot;
+    const int took = panel_launch(form, p, batch, (hipStream_t)s, false, false, rows_per_block);
+    return took > 0 ? 0 : took < 0 ? -took : VT_EUNSUPPORTED;
+  }
   if (const int took = panel_launch(form, p, batch, (hipStream_t)s)) return took > 0 ? 0 : -took;
   int BM = 64, BN = 64;
   if (N > 64) {
@@ -1209,6 +1291,19 @@ extern "C" int vt_gemm_sum(int form, int nterms, const vt_gemm_term *terms, int 
 #undef VT_SUM_LAUNCH
   VT_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int vt_gemm_sum(int form, int nterms, const vt_gemm_term *terms, int M, int N, float alpha, int accumulate,
+                           float *C, int ldc, long strideC, const float *bias, int batch, vt_stream s) {
+  return gemm_sum_launch(form, nterms, terms, M, N, alpha, accumulate, C, ldc, strideC, bias, batch, nullptr, nullptr, 0, nullptr, s);
+}
+
+extern "C" int vt_gemm_sum_colstats(int form, int nterms, const vt_gemm_term *terms, int M, int N, float alpha, float *C,
+                                    int ldc, long strideC, const float *bias, int batch, const float *col_pivot,
+                                    float *col_part, long col_part_floats, int *rows_per_block, vt_stream s) {
+  if (!col_part || !rows_per_block) return VT_EINVAL;
+  return gemm_sum_launch(form, nterms, terms, M, N, alpha, 0, C, ldc, strideC, bias, batch, col_pivot, col_part,
+                         col_part_floats, rows_per_block, s);
 }
 
 static int bn_apply_launch(int M, int N, int K, const float *A, int lda, const float *stat, const float *gamma,

@@ -1206,7 +1206,9 @@ int gen_create(GenModel *g, const vt_dims *d, int maxN, int (*alloc)(void *, flo
   A(&g->stat_n2, 2 * D, "stat.norm2");
   A(&g->stat_pn, 2 * C2, "stat.proj.norm");
   A(&g->coef, 2 * (size_t)std::max(std::max(C1, C2), D), nullptr);
-  g->part_floats = 8192L * 2 * std::max(std::max(C1, C2), std::max(D, 64)) + 1024;
+  // partial records: up to 8192 blocks of any BatchNorm, or one block per 1024 pixel rows of every image (the records the
+  // projector output's own launch leaves)
+  g->part_floats = std::max(8192L, (long)N * ((g->P + 1023) / 1024 + 1)) * 2 * std::max(std::max(C1, C2), std::max(D, 64)) + 1024;
   A(&g->part, (size_t)g->part_floats, nullptr);
   A(&g->spx, N * ((g->P + SPX_CHUNK - 1) / SPX_CHUNK + 1) * 2 * L, nullptr);
   g->spt = nullptr;
@@ -1325,9 +1327,24 @@ int gen_forward(GenModel *g, const float *arena, const vt_layout *lo, float *are
   {  // z = downsample(x) + attention . values (projector_layer.hpp:93-100), one pass, z written once
     const vt_gemm_term t[2] = {{g->x, W("proj.downsample.W"), (long)P * C1, 0, C1, C1, C2, 0},
                                {g->pa, g->v, (long)P * L, (long)L * C2, L, L, C2, 0}};
-    VTG(vt_gemm_sum(sum_form(), 2, t, P, C2, 1.f, 0, g->z, C2, (long)P * C2, W("proj.downsample.b"), n, (vt_stream)s));
+    // where the row-panel kernel takes the shape, the same launch leaves the BatchNorm's partial records (second moments
+    // around the running mean) and z is not read again for its statistics
+    int rpb = 0;
+    int rc = VT_EUNSUPPORTED;
+    if (sum_form() == 2)
+      rc = vt_gemm_sum_colstats(2, 2, t, P, C2, 1.f, g->z, C2, (long)P * C2, W("proj.downsample.b"), n,
+                                W("proj.norm.running_mean"), g->part, g->part_floats, &rpb, (vt_stream)s);
+    if (rc == 0) {
+      const int nb = n * ((P + rpb - 1) / rpb);
+      VTG(vt_bn_stats_finalize(g->part, nb, C2, rpb, NP, RW("proj.norm.running_mean"), RW("proj.norm.running_var"), g->stat_pn,
+                               (vt_stream)s));
+    } else if (rc == VT_EUNSUPPORTED) {
+      VTG(vt_gemm_sum(sum_form(), 2, t, P, C2, 1.f, 0, g->z, C2, (long)P * C2, W("proj.downsample.b"), n, (vt_stream)s));
+      VTG(bn_stats(g, g->z, NP, C2, RW("proj.norm.running_mean"), RW("proj.norm.running_var"), g->stat_pn, false, s));
+    } else {
+      return rc;
+    }
   }
-  VTG(bn_stats(g, g->z, NP, C2, RW("proj.norm.running_mean"), RW("proj.norm.running_var"), g->stat_pn, false, s));
   // reshape, max-pool, fc, softmax (vit_cnn.hpp:179-203)
   {
     const long strips = (long)n * C2 * 14;
