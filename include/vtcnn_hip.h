@@ -518,9 +518,9 @@ int vt_gemm_sum(int form, int nterms, const vt_gemm_term *terms, int M, int N, f
  * col_part [batch * blocks][2][N] = per block of *rows_per_block consecutive rows (sum, sum of squared distances from the
  * block's own mean), the input of vt_bn_stats_finalize(col_part, batch * blocks, N, *rows_per_block, batch * M, ...);
  * C is not read again for them.  The second moments are accumulated around col_pivot [N] (any value near the columns'
- * means keeps them of the order of the variance, e.g. the running mean; NULL: zero).  Row-panel kernel only (form 2,
- * 65 <= N <= 128, tall M, A operands 16-byte loadable, batch members of a whole number of blocks): VT_EUNSUPPORTED
- * otherwise, and nothing is launched. */
+ * means keeps them of the order of the variance, e.g. the running mean; NULL: zero).  Row-panel kernel only (form 2
+ * with 65 <= N <= 128 or form 0 with 33 <= N <= 64; tall M, A operands 16-byte loadable, batch members of a whole number
+ * of blocks): VT_EUNSUPPORTED otherwise, and nothing is launched. */
 int vt_gemm_sum_colstats(int form, int nterms, const vt_gemm_term *terms, int M, int N, float alpha, float *C, int ldc,
                          long strideC, const float *bias, int batch, const float *col_pivot, float *col_part,
                          long col_part_floats, int *rows_per_block, vt_stream s);

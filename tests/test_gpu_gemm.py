@@ -189,7 +189,8 @@ def test_gemm_sum_with_batchnorm_partial_records():
     import torch
     from vit_amd._lib import VtGemmTerm, check, lib
     rng = np.random.default_rng(11)
-    for (M, N, batch, ks) in [(4096, 128, 3, (64, 16)), (5000, 100, 1, (64, 196)), (2048, 128, 16, (32,))]:
+    for (form, M, N, batch, ks) in [(2, 4096, 128, 3, (64, 16)), (2, 5000, 100, 1, (64, 196)), (2, 2048, 128, 16, (32,)),
+                                    (0, 70000, 64, 1, (28,)), (0, 4096, 40, 2, (12, 8))]:
         terms = (VtGemmTerm * len(ks))()
         keep, want = [], np.zeros((batch, M, N))
         for t, K in enumerate(ks):
@@ -208,10 +209,10 @@ def test_gemm_sum_with_batchnorm_partial_records():
         part = torch.full((batch * ((M + 127) // 128) * 2 * N,), -3.0, dtype=torch.float32, device="cuda")
         rpb = C.c_int(0)
         s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        check(lib.vt_gemm_sum_colstats(2, len(ks), terms, M, N, 1.0, C.c_void_p(dC.data_ptr()), N, M * N,
+        check(lib.vt_gemm_sum_colstats(form, len(ks), terms, M, N, 1.0, C.c_void_p(dC.data_ptr()), N, M * N,
                                        C.c_void_p(dbias.data_ptr()), batch, C.c_void_p(dpiv.data_ptr()),
                                        C.c_void_p(part.data_ptr()), part.numel(), C.byref(rpb), s), "vt_gemm_sum_colstats")
-        check(lib.vt_gemm_sum(2, len(ks), terms, M, N, 1.0, 0, C.c_void_p(dC2.data_ptr()), N, M * N,
+        check(lib.vt_gemm_sum(form, len(ks), terms, M, N, 1.0, 0, C.c_void_p(dC2.data_ptr()), N, M * N,
                               C.c_void_p(dbias.data_ptr()), batch, s), "vt_gemm_sum")
         torch.cuda.synchronize()
         assert torch.equal(dC, dC2)
@@ -233,8 +234,8 @@ def test_gemm_sum_with_batchnorm_partial_records():
         assert rel_err(st[:N], got.mean(0)) < 2e-6
         assert rel_err(st[N:], 1.0 / np.sqrt(got.var(0) + 1e-5)) < 2e-5
     # shapes the row-panel kernel does not take with records: refused, nothing launched
-    assert lib.vt_gemm_sum_colstats(2, 1, terms, 300, 128, 1.0, C.c_void_p(dC.data_ptr()), 128, 300 * 128, None, 1, None,
-                                    C.c_void_p(part.data_ptr()), part.numel(), C.byref(rpb), s) == -2
+    assert lib.vt_gemm_sum_colstats(form, len(ks), terms, 300, N, 1.0, C.c_void_p(dC.data_ptr()), N, 300 * N, None, 1, None,
+                                    C.c_void_p(part.data_ptr()), part.numel(), C.byref(rpb), s) == -2  # too few rows
 
 
 def _bf16_round(a):

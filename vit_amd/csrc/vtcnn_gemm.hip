@@ -1088,14 +1088,16 @@ static int panel_launch(int form, const GemmSumP &p, int batch, hipStream_t hs, 
     else if (NT == 8) VT_PANEL(PR_, 8, 0);  \
     else VT_PANEL(PR_, 13, 0);              \
   } while (0)
-  if (p.epi == 4) {  // BatchNorm partial records of the result's columns: built for the split form with eight tiles
-    if (NT != 8 || form != 2 || ax || dz || p.accumulate || !p.col_part) return 0;
+  if (p.epi == 4) {  // BatchNorm partial records of the result's columns: built for the split form with eight tiles and
+                     // the exact form with four
+    if (!((NT == 8 && form == 2) || (NT == 4 && form == 0)) || ax || dz || p.accumulate || !p.col_part) return 0;
     if (batch > 1 && p.M % rows != 0) return 0;  // every workgroup but the launch's last must hold `rows` rows
     if ((long)batch * grid.x * 2 * p.N > p.col_part_floats) return 0;
     const bool sixteen = lds > 80 * 1024 && wide16;  // decided as for the plain launch, before the slots are added
     lds += ((size_t)(sixteen ? 16 : 8) * 2 + 1) * NT * 16 * sizeof(float);
     if (lds > (size_t)PANEL_LDS_MAX) return 0;
-    if (sixteen) e = panel_go<2, 8, 0, 4, 16>(grid, lds, hs, p, rows, Kp, nsteps);
+    if (NT == 4) e = panel_go<0, 4, 0, 4>(grid, lds, hs, p, rows, Kp, nsteps);
+    else if (sixteen) e = panel_go<2, 8, 0, 4, 16>(grid, lds, hs, p, rows, Kp, nsteps);
     else e = panel_go<2, 8, 0, 4>(grid, lds, hs, p, rows, Kp, nsteps);
     if (e == hipSuccess && rows_out) *rows_out = rows;
   } else if (p.epi == 3) {  // tile records of the softmax over rows: built for the normalise-on-load form

@@ -18,6 +18,8 @@ struct GenModel {
   float *col, *conv, *x, *tokA, *T0, *tok, *a, *hdn, *rl, *s2, *o, *Mq, *k, *v, *pa, *z, *pooled, *logits, *probs;
   int *pool_idx;
   float *stat_bn, *stat_n1, *stat_n2, *stat_pn, *coef, *part, *ws, *spx;
+  int cks;        // row stride of col: Ci * 9 rounded up to a multiple of 4 (16-byte rows; the extra columns are zero)
+  float *convWp;  // conv.W with rows of cks floats (extra columns zero): the B operand that goes with col
   float *spt;  // tile records of the tokenizer's softmax over pixels ([N * P / 16][2][L]; null when P is not a multiple of 16)
   long part_floats, ws_floats;
   // backward

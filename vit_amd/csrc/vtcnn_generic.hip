@@ -62,12 +62,17 @@ __device__ __forceinline__ void stv(float *p, const Vecf<VEC> &r) {
 // ---- im2col for the 3x3, stride 1, pad 1 convolution (layers/conv2d_layer.hpp:35-87) ----------
 // col[(n*P + p)][ci*9 + kh*3 + kw] = X[n][ci][h+kh-1][w+kw-1] (0 outside the image); one thread per
 // element of col, so that the writes are contiguous
+// (rows of ld >= Ci * 9 floats, the columns past Ci * 9 zero)
 __global__ __launch_bounds__(GT) void k_im2col(const float *__restrict__ X, float *__restrict__ col, long total, int Ci,
-                                               int H, int W) {
+                                               int H, int W, int ld) {
   const int CK = Ci * 9;
   for (long i = (long)blockIdx.x * GT + threadIdx.x; i < total; i += (long)gridDim.x * GT) {
-    const int j = (int)(i % CK);
-    const long row = i / CK;
+    const int j = (int)(i % ld);
+    const long row = i / ld;
+    if (j >= CK) {
+      col[i] = 0.f;
+      continue;
+    }
     const int p = (int)(row % ((long)H * W));
     const long n = row / ((long)H * W);
     const int ci = j / 9, kh = (j % 9) / 3, kw = j % 3;
@@ -78,10 +83,12 @@ __global__ __launch_bounds__(GT) void k_im2col(const float *__restrict__ X, floa
 
 // The same matrix, a workgroup taking 256 consecutive pixels of one image: gathered pixel by pixel into LDS (for a
 // fixed k neighbouring threads read neighbouring pixels), then written out as the contiguous block it is.
-__global__ __launch_bounds__(GT) void k_im2col_rows(const float *__restrict__ X, float *__restrict__ col, int Ci, int H) {
-  extern __shared__ float sh[];  // [256][Ci * 9]
-  const int CK = Ci * 9, P = H * H, n = blockIdx.y, p0 = blockIdx.x * GT, p = p0 + threadIdx.x;
+__global__ __launch_bounds__(GT) void k_im2col_rows(const float *__restrict__ X, float *__restrict__ col, int Ci, int H,
+                                                    int ld) {
+  extern __shared__ float sh[];  // [256][ld]
+  const int CK = ld, P = H * H, n = blockIdx.y, p0 = blockIdx.x * GT, p = p0 + threadIdx.x;
   if (p < P) {
+    for (int j = Ci * 9; j < ld; ++j) sh[threadIdx.x * CK + j] = 0.f;
     const int h = p / H, w = p - h * H;
     const float *__restrict__ img = X + (size_t)n * Ci * P;
     for (int ci = 0; ci < Ci; ++ci)
@@ -141,6 +148,14 @@ __global__ __launch_bounds__(GT) void k_im2col_colsum(const float *__restrict__ 
 
 // G[c][k] = G[c][k] * coef[c] + coef[C + c] * csum[k]: the gradient of the convolution weights from the product with
 // the delta BEFORE the BatchNorm backward's affine map din = delta * coef[c] + coef[C + c]
+// out [rows][ld] = in [rows][cols], the columns past cols zero
+__global__ __launch_bounds__(GT) void k_pad_rows(const float *__restrict__ in, float *__restrict__ out, int rows, int cols,
+                                                 int ld) {
+  const int i = blockIdx.x * GT + threadIdx.x;
+  if (i >= rows * ld) return;
+  const int r = i / ld, c = i - r * ld;
+  out[i] = c < cols ? in[r * cols + c] : 0.f;
+}
 __global__ __launch_bounds__(GT) void k_affine_rank1(float *__restrict__ G, const float *__restrict__ coef,
                                                      const float *__restrict__ csum, int C, int K) {
   const int i = blockIdx.x * GT + threadIdx.x;
@@ -945,13 +960,13 @@ int sum_form() {
 
 // the im2col matrix of X [n, Ci, H, H] into g->col
 int im2col(vt::GenModel *g, const float *X, int n, hipStream_t s) {
-  const int CK = g->Ci * 9;
+  const int CK = g->cks;
   const long NP = (long)n * g->P;
   const size_t lds = (size_t)GT * CK * sizeof(float);
   if (lds <= 64 * 1024 && n <= 65535)
-    hipLaunchKernelGGL(k_im2col_rows, dim3((g->P + GT - 1) / GT, n), dim3(GT), lds, s, X, g->col, g->Ci, g->H);
+    hipLaunchKernelGGL(k_im2col_rows, dim3((g->P + GT - 1) / GT, n), dim3(GT), lds, s, X, g->col, g->Ci, g->H, CK);
   else
-    hipLaunchKernelGGL(k_im2col, dim3(nblk(NP * CK)), dim3(GT), 0, s, X, g->col, NP * CK, g->Ci, g->H, g->H);
+    hipLaunchKernelGGL(k_im2col, dim3(nblk(NP * CK)), dim3(GT), 0, s, X, g->col, NP * CK, g->Ci, g->H, g->H, CK);
   VT_CHECK_LAUNCH();
   return 0;
 }
@@ -1179,7 +1194,9 @@ int gen_create(GenModel *g, const vt_dims *d, int maxN, int (*alloc)(void *, flo
   const int C1 = g->C1, C2 = g->C2, L = g->L, D = g->D, hd = g->hd, K = g->K, Q = g->Q;
   int rc = 0;
   auto A = [&](float **p, size_t n, const char *name) { rc |= alloc(ctx, p, n, name); };
-  A(&g->col, NP * g->Ci * 9, nullptr);
+  g->cks = (g->Ci * 9 + 3) & ~3;
+  A(&g->col, NP * g->cks, nullptr);
+  A(&g->convWp, (size_t)C1 * g->cks, nullptr);
   A(&g->conv, NP * C1, "fwd.conv_out");
   A(&g->x, NP * C1, "fwd.x");
   A(&g->tokA, NP * L, "fwd.tok_A");
@@ -1274,10 +1291,30 @@ int gen_forward(GenModel *g, const float *arena, const vt_layout *lo, float *are
   const Gemm mm{g, s, false}, mm_exact{g, s, false, true};
   const Gemm mm_ffn{g, s, (bfm & 1) != 0}, mm_k{g, s, (bfm & 2) != 0, true}, mm_v{g, s, (bfm & 4) != 0}, mm_fc{g, s, (bfm & 8) != 0};
   // Conv2DLayer::forward as im2col x W^T (conv2d_layer.hpp:35-87); output pixel-major [N*P, C1]
+  // (col and the copy of conv.W that goes with it have rows of cks floats, the columns past CK zero: 16-byte rows, so the
+  // product is a row-panel launch, which in training mode also leaves the BatchNorm's partial records)
+  const int CKs = g->cks;
   VTG(im2col(g, X, n, s));
-  VTG(mm(false, true, (int)NP, C1, CK, g->col, CK, W("conv.W"), CK, g->conv, C1, W("conv.b")));
+  hipLaunchKernelGGL(k_pad_rows, dim3((C1 * CKs + GT - 1) / GT), dim3(GT), 0, s, W("conv.W"), g->convWp, C1, CK, CKs);
+  VT_CHECK_LAUNCH();
   // BatchNorm2DLayer::forward (batch_normalization_layer.hpp:262-298): the only norm that honours eval
-  VTG(bn_stats(g, g->conv, NP, C1, RW("bn.running_mean"), RW("bn.running_var"), g->stat_bn, !training, s));
+  {
+    int rc = VT_EUNSUPPORTED, rpb = 0;
+    if (training && NP < (1L << 31)) {
+      const vt_gemm_term t = {g->col, g->convWp, 0, 0, CKs, CKs, CKs, 1};
+      rc = vt_gemm_sum_colstats(0, 1, &t, (int)NP, C1, 1.f, g->conv, C1, 0, W("conv.b"), 1, W("bn.running_mean"), g->part,
+                                g->part_floats, &rpb, (vt_stream)s);
+      if (rc == 0)
+        VTG(vt_bn_stats_finalize(g->part, (int)((NP + rpb - 1) / rpb), C1, rpb, NP, RW("bn.running_mean"), RW("bn.running_var"),
+                                 g->stat_bn, (vt_stream)s));
+    }
+    if (rc == VT_EUNSUPPORTED) {
+      VTG(mm(false, true, (int)NP, C1, CKs, g->col, CKs, g->convWp, CKs, g->conv, C1, W("conv.b")));
+      VTG(bn_stats(g, g->conv, NP, C1, RW("bn.running_mean"), RW("bn.running_var"), g->stat_bn, !training, s));
+    } else if (rc != 0) {
+      return rc;
+    }
+  }
   // FilterTokenizer::forward (layers/tokenizer.hpp:22-48).  The BatchNorm apply rides in the launch of its first
   // reader, the tokenizer's score product, where the row-panel kernel takes the shape: x is written by that launch and
   // the convolution output is read once for both
@@ -1485,7 +1522,7 @@ int gen_backward(GenModel *g, const float *arena, const vt_layout *lo, float *gr
                              (vt_stream)s));
       VTG(bn_din_colsum(W("bn.gamma"), g->stat_bn, g->conv, G("bn.gamma"), C1, G("conv.b"), s));
       g->tdx_valid = 0;
-      VTG(mm(true, false, C1, CK, (int)NP, g->pdx, C1, g->col, CK, G("conv.W"), CK));
+      VTG(mm(true, false, C1, CK, (int)NP, g->pdx, C1, g->col, g->cks, G("conv.W"), CK));
       int bands = 8;
       while (bands > 1 && ((long)n * bands * CK > g->part_floats || (long)n * bands > 65535)) bands >>= 1;
       const int blocks = n * bands;
