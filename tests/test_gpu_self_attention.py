@@ -39,7 +39,7 @@ def test_self_attention_matches_reference(case):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("rows,width", [(1, 1), (7, 16), (129, 16), (33, 77), (5, 1000)])
+@pytest.mark.parametrize("rows,width", [(1, 1), (7, 16), (129, 16), (33, 77), (9, 200), (5, 1000), (6, 1024), (4, 1500)])
 def test_softmax_rows_and_backward(rows, width):
     import torch
     from vit_amd._lib import check, lib

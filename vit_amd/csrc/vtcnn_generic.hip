@@ -1158,6 +1158,7 @@ int softmax_rows(float *S, long rows, int Wd, hipStream_t s) {
   else if (Wd <= 64) hipLaunchKernelGGL(k_softmax_rows_reg<1>, dim3((unsigned)((rows + 3) / 4)), dim3(GT), 0, s, S, rows, Wd);
   else if (Wd <= 128) hipLaunchKernelGGL(k_softmax_rows_reg<2>, dim3((unsigned)((rows + 3) / 4)), dim3(GT), 0, s, S, rows, Wd);
   else if (Wd <= 256) hipLaunchKernelGGL(k_softmax_rows_reg<4>, dim3((unsigned)((rows + 3) / 4)), dim3(GT), 0, s, S, rows, Wd);
+  else if (Wd <= 1024) hipLaunchKernelGGL(k_softmax_rows_reg<16>, dim3((unsigned)((rows + 3) / 4)), dim3(GT), 0, s, S, rows, Wd);
   else hipLaunchKernelGGL(k_softmax_rows, dim3((unsigned)((rows + 3) / 4)), dim3(GT), 0, s, S, rows, Wd);
   VT_CHECK_LAUNCH();
   return 0;
@@ -1168,6 +1169,7 @@ int softmax_bwd_rows(const float *a, float *da, long rows, int Wd, hipStream_t s
   else if (Wd <= 64) hipLaunchKernelGGL(k_softmax_bwd_rows_reg<1>, dim3((unsigned)((rows + 3) / 4)), dim3(GT), 0, s, a, da, rows, Wd);
   else if (Wd <= 128) hipLaunchKernelGGL(k_softmax_bwd_rows_reg<2>, dim3((unsigned)((rows + 3) / 4)), dim3(GT), 0, s, a, da, rows, Wd);
   else if (Wd <= 256) hipLaunchKernelGGL(k_softmax_bwd_rows_reg<4>, dim3((unsigned)((rows + 3) / 4)), dim3(GT), 0, s, a, da, rows, Wd);
+  else if (Wd <= 1024) hipLaunchKernelGGL(k_softmax_bwd_rows_reg<16>, dim3((unsigned)((rows + 3) / 4)), dim3(GT), 0, s, a, da, rows, Wd);
   else hipLaunchKernelGGL(k_softmax_bwd_rows, dim3((unsigned)((rows + 3) / 4)), dim3(GT), 0, s, a, da, rows, Wd);
   VT_CHECK_LAUNCH();
   return 0;
