@@ -137,6 +137,12 @@ def test_irregular_shape_against_oracle(dims, n):
     m.backward_attention()
     # (running statistics moved between the two forwards; the weights did not, so gradients agree)
     assert np.array_equal(m.get_grads(), gg)
+    # ... and so does the one-stream order (by default the transformer / attention half runs on a side stream)
+    m.set_concurrency(False)
+    m.forward(torch.from_numpy(x).cuda())
+    m.zero_grad()
+    m.backward(torch.from_numpy(y).cuda())
+    assert np.array_equal(m.get_grads(), gg)
 
 
 def test_wide_shape_bf16_mode_within_1e_2():

@@ -22,6 +22,7 @@ struct GenModel {
   float *convWp;  // conv.W with rows of cks floats (extra columns zero): the B operand that goes with col
   float *spt;  // tile records of the tokenizer's softmax over pixels ([N * P / 16][2][L]; null when P is not a multiple of 16)
   long part_floats, ws_floats;
+  float *ws2, *part2, *coef2;  // scratch of the backward pass's side chain (same sizes as ws, part, coef)
   // backward
   float *dlogits, *dpool, *du, *dz, *pdx, *dsa, *dsa_tok, *U, *dv, *dk, *pdt, *d0, *ds2, *dh, *da, *dr, *dc;
   float *Qm, *Km, *Vm, *dQ, *dK, *dV, *attn, *dat, *dT0, *tdx, *csum, *dzr, *coef_pn;
@@ -37,8 +38,10 @@ int gen_create(GenModel *g, const vt_dims *d, int maxN, int (*alloc)(void *, flo
 int gen_forward(GenModel *g, const float *arena, const vt_layout *lo, float *arena_rw, const float *X, int n, int training,
                 float *probs_out, hipStream_t s);
 // phase bit 0: everything but the attention block; bit 1: the attention block (mha.q*/k*/v* gradients)
+// side, ev_fork, ev_join (all or none): the transformer half (and, with both bits, the attention block) runs on `side`
+// between the two events, beside the tokenizer / convolution half on s; s has waited for it when the call returns
 int gen_backward(GenModel *g, const float *arena, const vt_layout *lo, float *grads, const float *X, const int *labels, int n,
-                 int phase, hipStream_t s);
+                 int phase, hipStream_t s, hipStream_t side = nullptr, hipEvent_t ev_fork = nullptr, hipEvent_t ev_join = nullptr);
 // fills g->du (the dense delta behind the pooling layer) from the last backward's window records
 int gen_expand_du(GenModel *g, const float *arena, const vt_layout *lo, int n, hipStream_t s);
 // fills g->dz (the dense delta behind the projector's BatchNorm) from the last backward's window records

@@ -1225,15 +1225,18 @@ int gen_create(GenModel *g, const vt_dims *d, int maxN, int (*alloc)(void *, flo
   A(&g->stat_n2, 2 * D, "stat.norm2");
   A(&g->stat_pn, 2 * C2, "stat.proj.norm");
   A(&g->coef, 2 * (size_t)std::max(std::max(C1, C2), D), nullptr);
+  A(&g->coef2, 2 * (size_t)std::max(std::max(C1, C2), D), nullptr);
   // partial records: up to 8192 blocks of any BatchNorm, or one block per 1024 pixel rows of every image (the records the
   // projector output's own launch leaves)
   g->part_floats = std::max(8192L, (long)N * ((g->P + 1023) / 1024 + 1)) * 2 * std::max(std::max(C1, C2), std::max(D, 64)) + 1024;
   A(&g->part, (size_t)g->part_floats, nullptr);
+  A(&g->part2, (size_t)g->part_floats, nullptr);
   A(&g->spx, N * ((g->P + SPX_CHUNK - 1) / SPX_CHUNK + 1) * 2 * L, nullptr);
   g->spt = nullptr;
   if (g->P % 16 == 0 && L % 4 == 0) A(&g->spt, N * (g->P / 16) * 2 * L, nullptr);
   g->ws_floats = 16L << 20;
   A(&g->ws, (size_t)g->ws_floats, nullptr);
+  A(&g->ws2, (size_t)g->ws_floats, nullptr);
   // backward
   A(&g->dlogits, N * K, "bwd.d_logits");
   A(&g->dpool, N * Q, "bwd.d_pooled");
@@ -1402,13 +1405,97 @@ int gen_forward(GenModel *g, const float *arena, const vt_layout *lo, float *are
 
 // VTCNN::backward (model/vit_cnn.hpp:215-242); gradients are written (not accumulated) into grads
 int gen_backward(GenModel *g, const float *arena, const vt_layout *lo, float *grads, const float *X, const int *labels, int n,
-                 int phase, hipStream_t s) {
+                 int phase, hipStream_t s, hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join) {
   const int P = g->P, C1 = g->C1, C2 = g->C2, L = g->L, D = g->D, K = g->K, Q = g->Q, CK = g->Ci * 9, hd = g->hd;
   const long NP = (long)n * P, NL = (long)n * L;
   auto W = [&](const char *name) { return arena + lo->t[vt_find(lo, name)].offset; };
   auto G = [&](const char *name) { return grads + lo->t[vt_find(lo, name)].offset; };
   const bool bf_qkv = (bf16_products() & 16) != 0;
-  const Gemm mm{g, s, false}, mm_fwd{g, s, bf_qkv}, mm_exact{g, s, false, true}, mm_fwd_exact{g, s, bf_qkv, true};
+  const Gemm mm{g, s, false};
+  // The feed-forward half of the transformer layer's backward and the attention block read the projector's token delta
+  // and write deltas and gradients of their own; the tokenizer / BatchNorm2D / convolution backward (the launches that
+  // stream the pixel rows) reads the same delta and nothing of theirs.  With a side stream the two run side by side:
+  // the row chain (dozens of small launches) on the side stream with scratch buffers of its own, the pixel chain on s.
+  auto transformer_bwd = [&](GenModel *g, hipStream_t s) -> int {
+    const Gemm mm{g, s, false};
+    // TransformerLayer::backward with targets = projector token delta: seed = out - delta
+    // (visual_transformer.hpp:153-157, transformer_layer.hpp:133-207); no ReLU derivative (:174-181)
+    VTG(ewise(g->o, g->pdt, g->d0, NL * D, 1, s));
+    VTG(bn_backward(g, g->d0, g->s2, g->stat_n2, W("norm2.gamma"), NL, D, G("norm2.gamma"), G("norm2.beta"), g->coef, g->ds2,
+                    s, G("ffn.linear2.b")));
+    VTG(mm(true, false, D, D, (int)NL, g->rl, D, g->ds2, D, G("ffn.linear2.W"), D));
+    VTG(mm(false, true, (int)NL, D, D, g->ds2, D, W("ffn.linear2.W"), D, g->dh, D));
+    VTG(mm(true, false, D, D, (int)NL, g->a, D, g->dh, D, G("ffn.linear1.W"), D));
+    VTG(col_sums(g, g->dh, NL, D, G("ffn.linear1.b"), s));
+    VTG(mm(false, true, (int)NL, D, D, g->dh, D, W("ffn.linear1.W"), D, g->da, D));
+    VTG(ewise(g->da, g->ds2, g->da, NL * D, 0, s));
+    VTG(bn_backward(g, g->da, g->tok, g->stat_n1, W("norm1.gamma"), NL, D, G("norm1.gamma"), G("norm1.beta"), g->coef, g->dr,
+                    s));
+    return 0;
+  };
+  auto attention_bwd = [&](GenModel *g, hipStream_t s) -> int {
+    const Gemm mm{g, s, false}, mm_fwd{g, s, bf_qkv}, mm_exact{g, s, false, true}, mm_fwd_exact{g, s, bf_qkv, true};
+    // MultiHeadAttention::backward (multi_head_attention.hpp:109-193): L groups of n consecutive token
+    // rows; scores = key . query^T * scale; only the q / k / v weight gradients leave this block
+    VTG(mm(false, true, (int)NL, D, D, g->dr, D, W("mha.o.W"), D, g->dc, D));
+    const float scale = 1.0f / sqrtf((float)hd);
+    const long sG = (long)n * hd, sS = (long)n * n;
+    // The heads' weights lie q0 k0 v0 q1 k1 v1 ... at one stride in the arena; with it the per-head operations are
+    // batch members of one launch each: heads x L groups of n rows (head h, token l = member h * L + l).
+    const int H = g->heads;
+    long wstride = 0;
+    bool batched = g->heads_batched != 0;
+    if (batched) {
+      const long q0 = lo->t[vt_find(lo, "mha.q0.W")].offset, q1 = lo->t[vt_find(lo, "mha.q1.W")].offset;
+      wstride = q1 - q0;
+      for (int h = 0; h < H && batched; ++h) {
+        const std::string hs = std::to_string(h);
+        batched = lo->t[vt_find(lo, ("mha.q" + hs + ".W").c_str())].offset == q0 + h * wstride &&
+                  lo->t[vt_find(lo, ("mha.k" + hs + ".W").c_str())].offset == lo->t[vt_find(lo, "mha.k0.W")].offset + h * wstride &&
+                  lo->t[vt_find(lo, ("mha.v" + hs + ".W").c_str())].offset == lo->t[vt_find(lo, "mha.v0.W")].offset + h * wstride;
+      }
+    }
+    if (batched) {
+      const long sH = NL * hd;  // one head's [n*L, hd] matrix
+      const int HL = H * L;
+      // queries, keys and their scores feed the softmax's exponential: exact fp32
+      VTG(mm_fwd_exact(false, false, (int)NL, hd, D, g->tok, D, W("mha.q0.W"), hd, g->Qm, hd, nullptr, false, 1.f, H, 0, wstride, sH));
+      VTG(mm_fwd_exact(false, false, (int)NL, hd, D, g->tok, D, W("mha.k0.W"), hd, g->Km, hd, nullptr, false, 1.f, H, 0, wstride, sH));
+      VTG(mm_fwd(false, false, (int)NL, hd, D, g->tok, D, W("mha.v0.W"), hd, g->Vm, hd, nullptr, false, 1.f, H, 0, wstride, sH));
+      VTG(mm_exact(false, true, n, n, hd, g->Km, hd, g->Qm, hd, g->attn, n, nullptr, false, scale, HL, sG, sG, sS));
+      VTG(softmax_rows(g->attn, NL * H, n, s));
+      hipLaunchKernelGGL(k_head_major, dim3(nblk(NL * D)), dim3(GT), 0, s, g->dc, g->dch, NL, H, hd);
+      VT_CHECK_LAUNCH();
+      VTG(mm(false, true, n, n, hd, g->dch, hd, g->Vm, hd, g->dat, n, nullptr, false, 1.f, HL, sG, sG, sS));
+      VTG(mm(true, false, n, hd, n, g->attn, n, g->dch, hd, g->dV, hd, nullptr, false, 1.f, HL, sS, sG, sG));
+      VTG(softmax_bwd_rows(g->attn, g->dat, NL * H, n, s));
+      VTG(mm(false, false, n, hd, n, g->dat, n, g->Qm, hd, g->dK, hd, nullptr, false, 1.f, HL, sS, sG, sG));
+      VTG(mm(true, false, n, hd, n, g->dat, n, g->Km, hd, g->dQ, hd, nullptr, false, 1.f, HL, sS, sG, sG));
+      VTG(mm(true, false, D, hd, (int)NL, g->tok, D, g->dK, hd, G("mha.k0.W"), hd, nullptr, false, 1.f, H, 0, sH, wstride));
+      VTG(mm(true, false, D, hd, (int)NL, g->tok, D, g->dQ, hd, G("mha.q0.W"), hd, nullptr, false, 1.f, H, 0, sH, wstride));
+      VTG(mm(true, false, D, hd, (int)NL, g->tok, D, g->dV, hd, G("mha.v0.W"), hd, nullptr, false, 1.f, H, 0, sH, wstride));
+    }
+    for (int h = 0; h < (batched ? 0 : g->heads); ++h) {
+      const std::string hs = std::to_string(h);
+      const std::string nq = "mha.q" + hs + ".W", nk = "mha.k" + hs + ".W", nv = "mha.v" + hs + ".W";
+      // queries, keys and their scores feed the softmax's exponential: exact fp32
+      VTG(mm_fwd_exact(false, false, (int)NL, hd, D, g->tok, D, W(nq.c_str()), hd, g->Qm, hd));
+      VTG(mm_fwd_exact(false, false, (int)NL, hd, D, g->tok, D, W(nk.c_str()), hd, g->Km, hd));
+      VTG(mm_fwd(false, false, (int)NL, hd, D, g->tok, D, W(nv.c_str()), hd, g->Vm, hd));
+      VTG(mm_exact(false, true, n, n, hd, g->Km, hd, g->Qm, hd, g->attn, n, nullptr, false, scale, L, sG, sG, sS));
+      VTG(softmax_rows(g->attn, NL, n, s));
+      const float *dhd = g->dc + h * hd;  // this head's columns of the concat delta, row stride D
+      VTG(mm(false, true, n, n, hd, dhd, D, g->Vm, hd, g->dat, n, nullptr, false, 1.f, L, (long)n * D, sG, sS));
+      VTG(mm(true, false, n, hd, n, g->attn, n, dhd, D, g->dV, hd, nullptr, false, 1.f, L, sS, (long)n * D, sG));
+      VTG(softmax_bwd_rows(g->attn, g->dat, NL, n, s));
+      VTG(mm(false, false, n, hd, n, g->dat, n, g->Qm, hd, g->dK, hd, nullptr, false, 1.f, L, sS, sG, sG));
+      VTG(mm(true, false, n, hd, n, g->dat, n, g->Km, hd, g->dQ, hd, nullptr, false, 1.f, L, sS, sG, sG));
+      VTG(mm(true, false, D, hd, (int)NL, g->tok, D, g->dK, hd, G(nk.c_str()), hd));
+      VTG(mm(true, false, D, hd, (int)NL, g->tok, D, g->dQ, hd, G(nq.c_str()), hd));
+      VTG(mm(true, false, D, hd, (int)NL, g->tok, D, g->dV, hd, G(nv.c_str()), hd));
+    }
+    return 0;
+  };
   if (phase & 1) {
     // softmax - onehot, fc (softmax_layer.hpp:29, dense_layer.hpp:92-99)
     hipLaunchKernelGGL(k_dlogits, dim3((n * K + GT - 1) / GT), dim3(GT), 0, s, g->probs, labels, g->dlogits, n * K, K);
@@ -1471,19 +1558,17 @@ int gen_backward(GenModel *g, const float *arena, const vt_layout *lo, float *gr
     VTG(mm(true, false, D, D, (int)NL, g->o, D, g->dk, D, G("proj.linear2.W"), D));
     VTG(mm(false, true, (int)NL, D, D, g->dk, D, W("proj.linear2.W"), D, g->pdt, D, nullptr, true));
     VTG(mm(true, false, C1, D, (int)NL, g->U, C1, g->k, D, G("proj.linear1.W"), D));
-    // TransformerLayer::backward with targets = projector token delta: seed = out - delta
-    // (visual_transformer.hpp:153-157, transformer_layer.hpp:133-207); no ReLU derivative (:174-181)
-    VTG(ewise(g->o, g->pdt, g->d0, NL * D, 1, s));
-    VTG(bn_backward(g, g->d0, g->s2, g->stat_n2, W("norm2.gamma"), NL, D, G("norm2.gamma"), G("norm2.beta"), g->coef, g->ds2,
-                    s, G("ffn.linear2.b")));
-    VTG(mm(true, false, D, D, (int)NL, g->rl, D, g->ds2, D, G("ffn.linear2.W"), D));
-    VTG(mm(false, true, (int)NL, D, D, g->ds2, D, W("ffn.linear2.W"), D, g->dh, D));
-    VTG(mm(true, false, D, D, (int)NL, g->a, D, g->dh, D, G("ffn.linear1.W"), D));
-    VTG(col_sums(g, g->dh, NL, D, G("ffn.linear1.b"), s));
-    VTG(mm(false, true, (int)NL, D, D, g->dh, D, W("ffn.linear1.W"), D, g->da, D));
-    VTG(ewise(g->da, g->ds2, g->da, NL * D, 0, s));
-    VTG(bn_backward(g, g->da, g->tok, g->stat_n1, W("norm1.gamma"), NL, D, G("norm1.gamma"), G("norm1.beta"), g->coef, g->dr,
-                    s));
+    const bool fork = side != nullptr && ev_fork != nullptr && ev_join != nullptr && g->ws2 != nullptr;
+    GenModel gb = *g;  // the side chain's view: the same buffers, scratch of its own
+    gb.ws = g->ws2; gb.part = g->part2; gb.coef = g->coef2;
+    // (the pixel chain's few long launches are issued first: the host then enqueues the side chain's dozens of short
+    // ones while those run)
+    if (fork) {
+      HIPCHK_G(hipEventRecord(ev_fork, s));
+      HIPCHK_G(hipStreamWaitEvent(side, ev_fork, 0));
+    } else {
+      VTG(transformer_bwd(g, s));
+    }
     // the output projection's cached input is the zero concat: its gradient is zero
     VTG(ewise(nullptr, nullptr, G("mha.o.W"), (long)D * D, 3, s));
     // FilterTokenizer::backward2 (tokenizer.hpp:50-107): the softmax over pixels is differentiated over
@@ -1535,67 +1620,16 @@ int gen_backward(GenModel *g, const float *arena, const vt_layout *lo, float *gr
       hipLaunchKernelGGL(k_affine_rank1, dim3((C1 * CK + GT - 1) / GT), dim3(GT), 0, s, G("conv.W"), g->coef, g->csum, C1, CK);
       VT_CHECK_LAUNCH();
     }
-  }
-  if (phase & 2) {
-    // MultiHeadAttention::backward (multi_head_attention.hpp:109-193): L groups of n consecutive token
-    // rows; scores = key . query^T * scale; only the q / k / v weight gradients leave this block
-    VTG(mm(false, true, (int)NL, D, D, g->dr, D, W("mha.o.W"), D, g->dc, D));
-    const float scale = 1.0f / sqrtf((float)hd);
-    const long sG = (long)n * hd, sS = (long)n * n;
-    // The heads' weights lie q0 k0 v0 q1 k1 v1 ... at one stride in the arena; with it the per-head operations are
-    // batch members of one launch each: heads x L groups of n rows (head h, token l = member h * L + l).
-    const int H = g->heads;
-    long wstride = 0;
-    bool batched = g->heads_batched != 0;
-    if (batched) {
-      const long q0 = lo->t[vt_find(lo, "mha.q0.W")].offset, q1 = lo->t[vt_find(lo, "mha.q1.W")].offset;
-      wstride = q1 - q0;
-      for (int h = 0; h < H && batched; ++h) {
-        const std::string hs = std::to_string(h);
-        batched = lo->t[vt_find(lo, ("mha.q" + hs + ".W").c_str())].offset == q0 + h * wstride &&
-                  lo->t[vt_find(lo, ("mha.k" + hs + ".W").c_str())].offset == lo->t[vt_find(lo, "mha.k0.W")].offset + h * wstride &&
-                  lo->t[vt_find(lo, ("mha.v" + hs + ".W").c_str())].offset == lo->t[vt_find(lo, "mha.v0.W")].offset + h * wstride;
-      }
+    if (fork) {
+      VTG(transformer_bwd(&gb, side));
+      if (phase & 2) VTG(attention_bwd(&gb, side));
+      HIPCHK_G(hipEventRecord(ev_join, side));
+      HIPCHK_G(hipStreamWaitEvent(s, ev_join, 0));
+    } else if (phase & 2) {
+      VTG(attention_bwd(g, s));
     }
-    if (batched) {
-      const long sH = NL * hd;  // one head's [n*L, hd] matrix
-      const int HL = H * L;
-      // queries, keys and their scores feed the softmax's exponential: exact fp32
-      VTG(mm_fwd_exact(false, false, (int)NL, hd, D, g->tok, D, W("mha.q0.W"), hd, g->Qm, hd, nullptr, false, 1.f, H, 0, wstride, sH));
-      VTG(mm_fwd_exact(false, false, (int)NL, hd, D, g->tok, D, W("mha.k0.W"), hd, g->Km, hd, nullptr, false, 1.f, H, 0, wstride, sH));
-      VTG(mm_fwd(false, false, (int)NL, hd, D, g->tok, D, W("mha.v0.W"), hd, g->Vm, hd, nullptr, false, 1.f, H, 0, wstride, sH));
-      VTG(mm_exact(false, true, n, n, hd, g->Km, hd, g->Qm, hd, g->attn, n, nullptr, false, scale, HL, sG, sG, sS));
-      VTG(softmax_rows(g->attn, NL * H, n, s));
-      hipLaunchKernelGGL(k_head_major, dim3(nblk(NL * D)), dim3(GT), 0, s, g->dc, g->dch, NL, H, hd);
-      VT_CHECK_LAUNCH();
-      VTG(mm(false, true, n, n, hd, g->dch, hd, g->Vm, hd, g->dat, n, nullptr, false, 1.f, HL, sG, sG, sS));
-      VTG(mm(true, false, n, hd, n, g->attn, n, g->dch, hd, g->dV, hd, nullptr, false, 1.f, HL, sS, sG, sG));
-      VTG(softmax_bwd_rows(g->attn, g->dat, NL * H, n, s));
-      VTG(mm(false, false, n, hd, n, g->dat, n, g->Qm, hd, g->dK, hd, nullptr, false, 1.f, HL, sS, sG, sG));
-      VTG(mm(true, false, n, hd, n, g->dat, n, g->Km, hd, g->dQ, hd, nullptr, false, 1.f, HL, sS, sG, sG));
-      VTG(mm(true, false, D, hd, (int)NL, g->tok, D, g->dK, hd, G("mha.k0.W"), hd, nullptr, false, 1.f, H, 0, sH, wstride));
-      VTG(mm(true, false, D, hd, (int)NL, g->tok, D, g->dQ, hd, G("mha.q0.W"), hd, nullptr, false, 1.f, H, 0, sH, wstride));
-      VTG(mm(true, false, D, hd, (int)NL, g->tok, D, g->dV, hd, G("mha.v0.W"), hd, nullptr, false, 1.f, H, 0, sH, wstride));
-    }
-    for (int h = 0; h < (batched ? 0 : g->heads); ++h) {
-      const std::string hs = std::to_string(h);
-      const std::string nq = "mha.q" + hs + ".W", nk = "mha.k" + hs + ".W", nv = "mha.v" + hs + ".W";
-      // queries, keys and their scores feed the softmax's exponential: exact fp32
-      VTG(mm_fwd_exact(false, false, (int)NL, hd, D, g->tok, D, W(nq.c_str()), hd, g->Qm, hd));
-      VTG(mm_fwd_exact(false, false, (int)NL, hd, D, g->tok, D, W(nk.c_str()), hd, g->Km, hd));
-      VTG(mm_fwd(false, false, (int)NL, hd, D, g->tok, D, W(nv.c_str()), hd, g->Vm, hd));
-      VTG(mm_exact(false, true, n, n, hd, g->Km, hd, g->Qm, hd, g->attn, n, nullptr, false, scale, L, sG, sG, sS));
-      VTG(softmax_rows(g->attn, NL, n, s));
-      const float *dhd = g->dc + h * hd;  // this head's columns of the concat delta, row stride D
-      VTG(mm(false, true, n, n, hd, dhd, D, g->Vm, hd, g->dat, n, nullptr, false, 1.f, L, (long)n * D, sG, sS));
-      VTG(mm(true, false, n, hd, n, g->attn, n, dhd, D, g->dV, hd, nullptr, false, 1.f, L, sS, (long)n * D, sG));
-      VTG(softmax_bwd_rows(g->attn, g->dat, NL, n, s));
-      VTG(mm(false, false, n, hd, n, g->dat, n, g->Qm, hd, g->dK, hd, nullptr, false, 1.f, L, sS, sG, sG));
-      VTG(mm(true, false, n, hd, n, g->dat, n, g->Km, hd, g->dQ, hd, nullptr, false, 1.f, L, sS, sG, sG));
-      VTG(mm(true, false, D, hd, (int)NL, g->tok, D, g->dK, hd, G(nk.c_str()), hd));
-      VTG(mm(true, false, D, hd, (int)NL, g->tok, D, g->dQ, hd, G(nq.c_str()), hd));
-      VTG(mm(true, false, D, hd, (int)NL, g->tok, D, g->dV, hd, G(nv.c_str()), hd));
-    }
+  } else if (phase & 2) {
+    VTG(attention_bwd(g, s));
   }
   return 0;
 }

@@ -44,6 +44,7 @@ struct vt_model {
   hipStream_t side = nullptr;
   hipEvent_t ev_rows = nullptr, ev_join = nullptr;
   bool concurrent = true, side_open = false;
+  bool gen_attention_done = false;  // general shapes: the last backward_main also ran the attention block
   bool join_signalled = false;  // the side chain's last kernel signals ev_join itself (no record needed)
   bool signal_launches = [] { const char *e = getenv("VT_SIGNAL_LAUNCHES"); return !(e && *e == '0'); }();  // VT_SIGNAL_LAUNCHES=0: event-record packets
   // Deferred attention backward (vt_model_set_deferred_attention): the attention block's backward and the
@@ -177,6 +178,11 @@ extern "C" int vt_model_create(const vt_dims *dims, int max_batch, int device, f
     }
     m->probs = m->gen->probs;
     rc |= dalloc(m, &m->loss_buf, 4);
+    // the side chain of the general backward (gen_backward): stream and fork / join events
+    if (rc == 0 && (hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking) != hipSuccess ||
+                    hipEventCreateWithFlags(&m->ev_rows, hipEventDisableTiming) != hipSuccess ||
+                    hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming) != hipSuccess))
+      rc = VT_ENOMEM;
     if (rc != 0) {
       vt_model_destroy(m);
       return VT_ENOMEM;
@@ -992,9 +998,14 @@ struct BatchScope {
 // transformer layer, tokenizer, BatchNorm2D and the convolution.  The tokenizer only needs the
 // transformer's input delta (transformer_bwd_a) and the projector's input delta, so it runs here
 // and the attention block, which nothing else waits for, closes the step.
-static int backward_main(vt_model *m, const int *d_labels, vt_stream s) {
+// whole (general shapes only): the attention block too, on the side chain; backward_attention then has nothing left to do
+static int backward_main(vt_model *m, const int *d_labels, vt_stream s, bool whole = false) {
   if (m->gen) {
-    STEP("generic_backward", gen_backward(m->gen, m->arena, &m->lo, m->grads, m->last_images, d_labels, m->lastN, 1, (hipStream_t)s));
+    const bool fork = m->concurrent && m->side != nullptr;
+    m->gen_attention_done = whole && fork;
+    STEP("generic_backward", gen_backward(m->gen, m->arena, &m->lo, m->grads, m->last_images, d_labels, m->lastN,
+                                          m->gen_attention_done ? 3 : 1, (hipStream_t)s, fork ? m->side : nullptr,
+                                          fork ? m->ev_rows : nullptr, fork ? m->ev_join : nullptr));
     return 0;
   }
   const int n = m->lastN, H = m->d.input_dim, P = m->P, Ci = m->d.image_channels, K = m->K, Q = m->Q;
@@ -1126,6 +1137,10 @@ static int backward_main(vt_model *m, const int *d_labels, vt_stream s) {
 static int backward_attention(vt_model *m, float *g_out, vt_stream s) {
   if (m->gen) {
     if (g_out) return VT_EUNSUPPORTED;
+    if (m->gen_attention_done) {  // ran beside the tokenizer / convolution half (backward_main, whole)
+      m->gen_attention_done = false;
+      return 0;
+    }
     STEP("generic_backward_attention", gen_backward(m->gen, m->arena, &m->lo, m->grads, m->last_images, nullptr, m->lastN, 2, (hipStream_t)s));
     return 0;
   }
@@ -1159,7 +1174,7 @@ extern "C" int vt_model_backward(vt_model *m, const int *d_labels, vt_stream s) 
   VTCHK(attention_join(m, (hipStream_t)s));
   const bool defer = m->defer_attn && !m->gen && !m->capturing && m->attn_stream != nullptr;
   BatchScope batch(m);
-  VTCHK(backward_main(m, d_labels, s));
+  VTCHK(backward_main(m, d_labels, s, m->gen != nullptr));
   if (defer) HIPCHK(hipEventRecord(m->ev_attn_go, (hipStream_t)s));  // everything the attention block reads exists
   else VTCHK(backward_attention(m, nullptr, s));
   VTCHK(join_side(m, s));
