@@ -521,9 +521,23 @@ int vt_gemm_sum(int form, int nterms, const vt_gemm_term *terms, int M, int N, f
  * means keeps them of the order of the variance, e.g. the running mean; NULL: zero).  Row-panel kernel only (form 2
  * with 65 <= N <= 128 or form 0 with 33 <= N <= 64; tall M, A operands 16-byte loadable, batch members of a whole number
  * of blocks): VT_EUNSUPPORTED otherwise, and nothing is launched. */
+/* ldc == 0: the statistics without the matrix: of C only row 0 of batch member 0 is stored (N floats; the row the
+ * BatchNorm backward's variance term reads, layers/batch_normalization_layer.hpp:172-200), for callers that form C again
+ * where they need it (vt_gemm_sum_bn_relu_pool). */
 int vt_gemm_sum_colstats(int form, int nterms, const vt_gemm_term *terms, int M, int N, float alpha, float *C, int ldc,
                          long strideC, const float *bias, int batch, const float *col_pivot, float *col_part,
                          long col_part_floats, int *rows_per_block, vt_stream s);
+/* The sum of products of vt_gemm_sum (alpha 1, one H*H x N matrix per batch member) taken straight through the
+ * BatchNorm apply, the ReLU, the reference's reshape [P, N] -> [N, H, H] (no data movement, model/vit_cnn.hpp:179) and
+ * MaxPool2DLayer::forward with pk x pk windows to 14 x 14 (layers/pooling_layer.hpp:18-66; the first maximum of a window
+ * in row-major order wins), without storing the matrix:
+ *   pooled [batch][N][14][14], pool_idx (position of the maximum inside its H x H plane), cmax (the matrix's own value
+ *   there, what the BatchNorm backward needs of it); stat = mean [N] | 1/sqrt(var + eps) [N].
+ * Row-panel kernel only: form 2, 65 <= N <= 128 and a multiple of 16, pk = 16 (H = 224), H*H a multiple of 112 rows,
+ * A operands 16-byte loadable; VT_EUNSUPPORTED otherwise, and nothing is launched. */
+int vt_gemm_sum_bn_relu_pool(int form, int nterms, const vt_gemm_term *terms, int H, int N, const float *bias, int batch,
+                             const float *stat, const float *gamma, const float *beta, int pk, float *pooled, int *pool_idx,
+                             float *cmax, vt_stream s);
 /* BatchNorm2DLayer::forward's apply (layers/batch_normalization_layer.hpp:292-297) inside the first product that reads
  * its result (the tokenizer's scores, layers/tokenizer.hpp:30-34):
  *   A_out[m][k] = (A[m][k] - stat[k]) * stat[K + k] * gamma[k] + beta[k],   C = A_out . op(B) (+ bias[n])

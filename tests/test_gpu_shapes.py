@@ -193,3 +193,28 @@ def test_wide_shape_bf16_mode_within_1e_2():
     _check_against_exact_math(m, dims, n16, x16, y16, arena0, p16, m.get_grads(), tol=1e-2, gap_tol=5e-2, frac_tol=5e-2)
     with pytest.raises(RuntimeError):
         VTCNN(Dims(num_classes=8), max_batch=2, seed=42).set_matmul_precision(True)  # headline kernels: fp32 only
+
+
+def test_scaled_shape_pooling_without_the_stored_matrix_is_bit_identical():
+    """VT_GEN_STORE_Z=0: the scaled shape forms the projector's pre-norm output twice (statistics, then normalise + ReLU +
+    pool) instead of storing it (the default).  Same probabilities, pooled values, arg-max positions,
+    gradients and, read on request, the same matrix, bit for bit."""
+    import os
+    import torch
+    from vit_amd import VTCNN, Dims
+    g = load_golden("shape_scaled_n2.npz")
+    dims, n, k, seed, x, y = shape_case(g)
+    xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    out = {}
+    for mode in ("0", "1"):
+        os.environ["VT_GEN_STORE_Z"] = mode
+        try:
+            m = VTCNN(Dims(**dims), max_batch=n, seed=42)
+            p = m.forward(xd).cpu().numpy().copy()
+            pooled = m.read("fwd.pooled").copy()
+            m.backward(yd)
+            out[mode] = (p, pooled, m.get_grads().copy(), m.read("fwd.proj_z").copy(), m.get_arena().copy())
+        finally:
+            os.environ.pop("VT_GEN_STORE_Z", None)
+    for a, b in zip(out["0"], out["1"]):
+        assert np.array_equal(a, b)

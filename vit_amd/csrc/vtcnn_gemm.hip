@@ -467,6 +467,16 @@ struct GemmSumP {
   float *col_part;
   long col_part_floats;
   const float *col_pivot;
+  int c_first_row_only;  // epi 4: of C only row 0 of batch member 0 is stored (C is recomputed where it is needed)
+  // epi 5: C is not stored; it is normalised (BatchNorm apply with pl_stat = mean | 1/sigma, pl_gamma, pl_beta), passed
+  // through the ReLU and max-pooled in the layout the reference's reshape gives it: batch member b's M x N values, flat,
+  // are N planes of pl_H x pl_H positions, pooled by pl_pk x pl_pk windows to 14 x 14 (vit_cnn.hpp:179,
+  // layers/pooling_layer.hpp:18-66; the first maximum of a window in row-major order wins).  Per window: the pooled value,
+  // the position of its maximum inside the plane, and the value of C there.
+  const float *pl_stat, *pl_gamma, *pl_beta;
+  float *pl_pooled, *pl_cmax;
+  int *pl_idx;
+  int pl_H, pl_pk;
   // row-panel kernels built with DZ: term 0's A holds delta records (one pair per row and group of 16 adjacent k:
   // value, k inside the group; every other element of the group zero) and A[m][k] = dz_coef[K + k] + dz_coef[k] * delta
   const float *dz_coef;
@@ -551,7 +561,9 @@ constexpr int PANEL_NMAX = 208, PANEL_LDS_MAX = 160 * 1024;  // result columns (
 // load and written back (GemmSumP::ax_*)
 // EPI: built with the row epilogue GemmSumP::epi (1 or 2); WV: waves per workgroup (sixteen where a copy of op(B) leaves
 // room for one workgroup per compute unit and the kernel fits four waves on a SIMD)
-template <int PR, int NT, int AX = 0, int EPI = 0, int WV = PANEL_W>
+// GS: 16-deep steps per group (one group is in the matrix cores while the next group's rows of A are in flight; with
+// nsteps <= GS the whole next tile is in flight during a tile)
+template <int PR, int NT, int AX = 0, int EPI = 0, int WV = PANEL_W, int GS = 4>
 __global__ __launch_bounds__(64 * WV, (WV > 8 || (NT > 8 && EPI != 2)) ? 4 : 1) void k_gemm_panel(GemmSumP p, int rows_per_wg, int Kp, int nsteps) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   PanelStep *steps = reinterpret_cast<PanelStep *>(smem);
@@ -664,21 +676,35 @@ __global__ __launch_bounds__(64 * WV, (WV > 8 || (NT > 8 && EPI != 2)) ? 4 : 1) 
   }
   // EPI 4: per-wave running sums [WV][2][NP16] of (value - pivot) and its square, and the pivot [NP16], behind op(B)
   float *__restrict__ cst = reinterpret_cast<float *>(smem + PANEL_HEAD) + (PR == 2 ? NP16 * ldk : Kp * ldn);
+  // EPI 5: mean, 1/sigma * gamma, beta [NP16 each], then the segment records of one chunk of 16 * WV rows:
+  // best value, its column inside the segment, the value of C there [16 * WV][NT] each
+  float *__restrict__ pl_c = cst;
+  float *__restrict__ seg_y = cst + 3 * NP16;
+  int *__restrict__ seg_k = reinterpret_cast<int *>(seg_y + 16 * WV * NT);
+  float *__restrict__ seg_z = seg_y + 2 * 16 * WV * NT;
+  if constexpr (EPI == 5) {
+    for (int i = tid; i < NP16; i += (64 * WV)) {
+      const bool on = i < p.N;
+      pl_c[i] = on ? p.pl_stat[i] : 0.f;
+      pl_c[NP16 + i] = on ? p.pl_stat[p.N + i] * p.pl_gamma[i] : 0.f;
+      pl_c[2 * NP16 + i] = on ? p.pl_beta[i] : 0.f;
+    }
+  }
   if constexpr (EPI == 4) {
     for (int i = tid; i < WV * 2 * NP16; i += (64 * WV)) cst[i] = 0.f;
     for (int i = tid; i < NP16; i += (64 * WV)) cst[WV * 2 * NP16 + i] = (p.col_pivot && i < p.N) ? p.col_pivot[i] : 0.f;
   }
   __syncthreads();
 
-  const int G = (nsteps + 3) >> 2;  // groups of four steps: one group is in the matrix cores, the next in flight
+  const int G = (nsteps + GS - 1) / GS;  // groups of GS steps: one group is in the matrix cores, the next in flight
   const long wg_row0 = (long)blockIdx.x * rows_per_wg;
   const int ntiles = rows_per_wg / (16 * WV);  // 16-row tiles per wave: tile i of this wave is tile wave + WV i of the workgroup
   auto tile_row0 = [&](int i) { return wg_row0 + (long)(wave + WV * i) * 16; };
-  auto fetch = [&](long row0, int gi, float4 (&dst)[4]) {
+  auto fetch = [&](long row0, int gi, float4 (&dst)[GS]) {
     const long row = row0 + c;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int si = gi * 4 + e;
+    for (int e = 0; e < GS; ++e) {
+      const int si = gi * GS + e;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (si < nsteps) {
         const PanelStep st = steps[si];
@@ -698,7 +724,7 @@ __global__ __launch_bounds__(64 * WV, (WV > 8 || (NT > 8 && EPI != 2)) ? 4 : 1) 
   f32x4 acc[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float4 cur[4], nxt[4];
+  float4 cur[GS], nxt[GS];
   fetch(tile_row0(0), 0, cur);
   float *__restrict__ C = p.C + (long)b * p.sC;
   // kernels of more than eight tiles with an epilogue are only launched on 16-byte rows (C, epi_a) with N % 4 == 0:
@@ -712,8 +738,8 @@ __global__ __launch_bounds__(64 * WV, (WV > 8 || (NT > 8 && EPI != 2)) ? 4 : 1) 
       if (!last) fetch(row0, gi + 1, nxt);
       else if (i + 1 < ntiles) fetch(tile_row0(i + 1), 0, nxt);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int si = gi * 4 + e;
+      for (int e = 0; e < GS; ++e) {
+        const int si = gi * GS + e;
         if (si < nsteps) {
           const int kb = steps[si].kofs + 4 * g;
           float av[4] = {cur[e].x, cur[e].y, cur[e].z, cur[e].w};
@@ -755,7 +781,7 @@ __global__ __launch_bounds__(64 * WV, (WV > 8 || (NT > 8 && EPI != 2)) ? 4 : 1) 
             // one row of C (one 16-byte store).  All of op(B)'s fragments first, then the three partial products
             // tile by tile: consecutive matrix instructions write different accumulators, none waits for the one
             // before it
-            constexpr int JG = NT <= 8 ? NT : (EPI == 1 ? 4 : 7);  // tiles whose fragments are held at once
+            constexpr int JG = GS > 4 ? 4 : NT <= 8 ? NT : (EPI == 1 ? 4 : 7);  // tiles whose fragments are held at once
 #pragma unroll
             for (int j0 = 0; j0 < NT; j0 += JG) {
               s16x4 bh[JG], bl[JG];
@@ -825,6 +851,44 @@ __global__ __launch_bounds__(64 * WV, (WV > 8 || (NT > 8 && EPI != 2)) ? 4 : 1) 
             for (int j = 0; j < NT; ++j)
 #pragma unroll
               for (int v = 0; v < 4; ++v) r[j][v] /= sum;
+          } else if constexpr (EPI == 5) {
+            // y = relu((value - mean) * scale + beta); per row and 16-column segment the first maximum of y: the lane's
+            // four columns first, then the four lanes of the row (columns ascend with the lane group)
+            const int rl = (wave) * 16 + c;  // row inside the chunk
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+              const int gn = j * 16 + 4 * g;
+              const float4 mu = *reinterpret_cast<const float4 *>(pl_c + gn);
+              const float4 sc = *reinterpret_cast<const float4 *>(pl_c + NP16 + gn);
+              const float4 be = *reinterpret_cast<const float4 *>(pl_c + 2 * NP16 + gn);
+              const float mq[4] = {mu.x, mu.y, mu.z, mu.w}, sq[4] = {sc.x, sc.y, sc.z, sc.w}, bq[4] = {be.x, be.y, be.z, be.w};
+              float best = -INFINITY, bz = 0.f;
+              int bk = 0;
+#pragma unroll
+              for (int v = 0; v < 4; ++v) {
+                const float y = fmaxf(fmaf(r[j][v] - mq[v], sq[v], bq[v]), 0.f);
+                if (y > best) {
+                  best = y;
+                  bk = 4 * g + v;
+                  bz = r[j][v];
+                }
+              }
+#pragma unroll
+              for (int o = 16; o < 64; o <<= 1) {
+                const float oy = __shfl_xor(best, o), oz = __shfl_xor(bz, o);
+                const int ok = __shfl_xor(bk, o);
+                if (oy > best || (oy == best && ok < bk)) {
+                  best = oy;
+                  bk = ok;
+                  bz = oz;
+                }
+              }
+              if (g == 0) {
+                seg_y[rl * NT + j] = best;
+                seg_k[rl * NT + j] = bk;
+                seg_z[rl * NT + j] = bz;
+              }
+            }
           } else if constexpr (EPI == 4) {
             // column sums of (value - pivot) and of its square over the tile's rows (the 16 lanes of a lane row), added to
             // this wave's running sums in LDS by the row's first lane
@@ -923,10 +987,11 @@ __global__ __launch_bounds__(64 * WV, (WV > 8 || (NT > 8 && EPI != 2)) ? 4 : 1) 
 #pragma unroll
               for (int v = 0; v < 4; ++v) r[j][v] = a[j][v] * (r[j][v] - dot);
           }
+          const bool store_row = EPI == 5 ? false : (EPI == 4 && p.c_first_row_only) ? (row_on && b == 0 && gm == 0) : row_on;
 #pragma unroll
           for (int j = 0; j < NT; ++j) {
             const int gn = j * 16 + 4 * g;
-            if (row_on && gn < p.N) {
+            if (store_row && gn < p.N) {
               float *__restrict__ dst = C + gm * p.ldc + gn;
               if (QUAD || (vecC && gn + 3 < p.N)) {
                 *reinterpret_cast<float4 *>(dst) = make_float4(r[j][0], r[j][1], r[j][2], r[j][3]);
@@ -966,7 +1031,38 @@ __global__ __launch_bounds__(64 * WV, (WV > 8 || (NT > 8 && EPI != 2)) ? 4 : 1) 
         }
       }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) cur[e] = nxt[e];
+      for (int e = 0; e < GS; ++e) cur[e] = nxt[e];
+    }
+    if constexpr (EPI == 5) {
+      // the chunk's 16 * WV rows are a whole number of bands (pk image rows of one plane): one thread per window walks
+      // the window's pk rows, one segment record each, in row order
+      __syncthreads();
+      const int W = p.pl_H, pk = p.pl_pk, band = pk * W, P = W * W, wpb = W / pk;  // wpb = 14 windows per band
+      const long F0 = (wg_row0 + (long)i * 16 * WV) * p.N;                            // the chunk's flat start inside the image
+      const int nwin = (16 * WV * p.N / band) * wpb;
+      for (int t = tid; t < nwin; t += 64 * WV) {
+        const int bnd = t / wpb, wi = t - bnd * wpb;
+        const long Fb = F0 + (long)bnd * band;
+        const int plane = (int)(Fb / P), ii = (int)((Fb - (long)plane * P) / band);
+        float best = -INFINITY, bz = 0.f;
+        int bki = 0, bkj = 0;
+        for (int ki = 0; ki < pk; ++ki) {
+          const int f = bnd * band + ki * W + wi * pk;  // flat offset inside the chunk: a multiple of 16
+          const int rl = f / p.N, sj = (f - rl * p.N) >> 4;
+          const float y = seg_y[rl * NT + sj];
+          if (y > best) {
+            best = y;
+            bki = ki;
+            bkj = seg_k[rl * NT + sj];
+            bz = seg_z[rl * NT + sj];
+          }
+        }
+        const long win = ((long)b * p.N + plane) * (wpb * wpb) + ii * wpb + wi;
+        p.pl_pooled[win] = best;
+        p.pl_idx[win] = (ii * pk + bki) * W + wi * pk + bkj;
+        p.pl_cmax[win] = bz;
+      }
+      __syncthreads();
     }
   }
   if constexpr (EPI == 4) {
@@ -1012,7 +1108,7 @@ using namespace vt;
 
 // One instantiation of the row-panel kernel.  More than 64 KB of LDS per workgroup (a single workgroup may hold all of a
 // compute unit's 160 KB) is asked for once per device and instantiation.
-template <int PR, int NT, int AX, int EPI = 0, int WV = PANEL_W>
+template <int PR, int NT, int AX, int EPI = 0, int WV = PANEL_W, int GS = 4>
 static hipError_t panel_go(dim3 grid, size_t lds, hipStream_t hs, const GemmSumP &p, int rows, int Kp, int nsteps) {
   if (lds > 64 * 1024) {
     static std::atomic<unsigned long long> asked{0};
@@ -1020,13 +1116,13 @@ static hipError_t panel_go(dim3 grid, size_t lds, hipStream_t hs, const GemmSumP
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev >= 64 || !((asked.load(std::memory_order_relaxed) >> dev) & 1)) {
-      e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_panel<PR, NT, AX, EPI, WV>),
+      e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_panel<PR, NT, AX, EPI, WV, GS>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, PANEL_LDS_MAX);
       if (e != hipSuccess) return e;
       if (dev < 64) asked.fetch_or(1ull << dev, std::memory_order_relaxed);
     }
   }
-  hipLaunchKernelGGL((k_gemm_panel<PR, NT, AX, EPI, WV>), grid, dim3(64 * WV), lds, hs, p, rows, Kp, nsteps);
+  hipLaunchKernelGGL((k_gemm_panel<PR, NT, AX, EPI, WV, GS>), grid, dim3(64 * WV), lds, hs, p, rows, Kp, nsteps);
   return hipGetLastError();
 }
 
@@ -1088,7 +1184,22 @@ static int panel_launch(int form, const GemmSumP &p, int batch, hipStream_t hs, 
     else if (NT == 8) VT_PANEL(PR_, 8, 0);  \
     else VT_PANEL(PR_, 13, 0);              \
   } while (0)
-  if (p.epi == 4) {  // BatchNorm partial records of the result's columns: built for the split form with eight tiles and
+  if (p.epi == 5) {  // normalise, ReLU, max-pool instead of storing: seven-wave workgroups, chunks of 112 rows
+    const int H = p.pl_H, pk = p.pl_pk;
+    if (NT != 8 || form != 2 || ax || dz || p.accumulate || !p.pl_stat || !p.pl_gamma || !p.pl_beta || !p.pl_pooled ||
+        !p.pl_idx || !p.pl_cmax)
+      return 0;
+    if (pk != 16 || H % 16 != 0 || H / pk != 14 || (long)H * H != p.M || p.N % 16 != 0 || p.M % 112 != 0 ||
+        (112 * p.N) % (pk * H) != 0)
+      return 0;
+    const int chunks = p.M / 112;
+    int k = 16;  // chunks per workgroup: op(B) is copied once per workgroup
+    while (k > 1 && (chunks % k != 0 || (long)(chunks / k) * batch < 1024)) --k;
+    lds += (size_t)(3 * NT * 16 + 3 * 16 * 7 * NT) * sizeof(float);
+    if (lds > (size_t)PANEL_LDS_MAX) return 0;
+    if (nsteps == 5) e = panel_go<2, 8, 0, 5, 7, 5>(dim3((unsigned)(chunks / k), (unsigned)batch), lds, hs, p, 112 * k, Kp, nsteps);
+    else e = panel_go<2, 8, 0, 5, 7>(dim3((unsigned)(chunks / k), (unsigned)batch), lds, hs, p, 112 * k, Kp, nsteps);
+  } else if (p.epi == 4) {  // BatchNorm partial records of the result's columns: built for the split form with eight tiles and
                      // the exact form with four
     if (!((NT == 8 && form == 2) || (NT == 4 && form == 0)) || ax || dz || p.accumulate || !p.col_part) return 0;
     if (batch > 1 && p.M % rows != 0) return 0;  // every workgroup but the launch's last must hold `rows` rows
@@ -1245,10 +1356,19 @@ extern "C" int vt_gemm_f32x3(int transA, int transB, int M, int N, int K, float 
 }
 
 // col_part != nullptr: the launch also leaves the BatchNorm partial records of C's columns (row-panel kernel only)
+struct PoolArgs {
+  const float *stat, *gamma, *beta;
+  float *pooled, *cmax;
+  int *idx;
+  int H, pk;
+};
 static int gemm_sum_launch(int form, int nterms, const vt_gemm_term *terms, int M, int N, float alpha, int accumulate,
                            float *C, int ldc, long strideC, const float *bias, int batch, const float *col_pivot, float *col_part,
-                           long col_part_floats, int *rows_per_block, vt_stream s) {
-  if (form < 0 || form > 2 || nterms < 1 || nterms > 4 || !terms || M < 1 || N < 1 || batch < 1 || !C || ldc < N) return VT_EINVAL;
+                           long col_part_floats, int *rows_per_block, vt_stream s, const PoolArgs *pool = nullptr) {
+  const bool first_row_only = col_part && ldc == 0;  // statistics without the matrix: only row 0 of member 0 is stored
+  if (form < 0 || form > 2 || nterms < 1 || nterms > 4 || !terms || M < 1 || N < 1 || batch < 1 || (!C && !pool) ||
+      (ldc < N && !first_row_only && !pool))
+    return VT_EINVAL;
   GemmSumP p{};
   auto aligned = [](const float *q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
   long ktot = 0;
@@ -1263,8 +1383,17 @@ static int gemm_sum_launch(int form, int nterms, const vt_gemm_term *terms, int 
   }
   p.nterms = nterms; p.C = C; p.bias = bias; p.M = M; p.N = N; p.ldc = ldc; p.sC = strideC; p.alpha = alpha;
   p.accumulate = accumulate ? 1 : 0;
+  if (pool) {
+    p.epi = 5;
+    p.pl_stat = pool->stat; p.pl_gamma = pool->gamma; p.pl_beta = pool->beta;
+    p.pl_pooled = pool->pooled; p.pl_cmax = pool->cmax; p.pl_idx = pool->idx; p.pl_H = pool->H; p.pl_pk = pool->pk;
+    const int took = panel_launch(form, p, batch, (hipStream_t)s);
+    return took > 0 ? 0 : took < 0 ? -took : VT_EUNSUPPORTED;
+  }
   if (col_part) {
     p.epi = 4;
+    p.c_first_row_only = first_row_only ? 1 : 0;
+    if (first_row_only) p.ldc = N;
     p.col_part = col_part;
     p.col_part_floats = col_part_floats;
     p.col_pivot = col_pivot;
@@ -1306,6 +1435,14 @@ extern "C" int vt_gemm_sum_colstats(int form, int nterms, const vt_gemm_term *te
   if (!col_part || !rows_per_block) return VT_EINVAL;
   return gemm_sum_launch(form, nterms, terms, M, N, alpha, 0, C, ldc, strideC, bias, batch, col_pivot, col_part,
                          col_part_floats, rows_per_block, s);
+}
+
+extern "C" int vt_gemm_sum_bn_relu_pool(int form, int nterms, const vt_gemm_term *terms, int H, int N, const float *bias,
+                                       int batch, const float *stat, const float *gamma, const float *beta, int pk,
+                                       float *pooled, int *pool_idx, float *cmax, vt_stream s) {
+  if (H < 1 || (long)H * H > (1L << 30) || !stat || !gamma || !beta || !pooled || !pool_idx || !cmax) return VT_EINVAL;
+  const PoolArgs pa{stat, gamma, beta, pooled, cmax, pool_idx, H, pk};
+  return gemm_sum_launch(form, nterms, terms, H * H, N, 1.f, 0, nullptr, N, 0, bias, batch, nullptr, nullptr, 0, nullptr, s, &pa);
 }
 
 static int bn_apply_launch(int M, int N, int K, const float *A, int lda, const float *stat, const float *gamma,

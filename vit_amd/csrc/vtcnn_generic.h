@@ -18,6 +18,8 @@ struct GenModel {
   float *col, *conv, *x, *tokA, *T0, *tok, *a, *hdn, *rl, *s2, *o, *Mq, *k, *v, *pa, *z, *pooled, *logits, *probs;
   int *pool_idx;
   float *stat_bn, *stat_n1, *stat_n2, *stat_pn, *coef, *part, *ws, *spx;
+  float *zmax;    // z at every pooling window's arg-max [N * Q] (what the backward needs of z when z itself is not stored)
+  int z_valid;    // 1: `z` holds the projector's pre-norm output of the last forward (0: only its row 0, statistics, pooling)
   int cks;        // row stride of col: Ci * 9 rounded up to a multiple of 4 (16-byte rows; the extra columns are zero)
   float *convWp;  // conv.W with rows of cks floats (extra columns zero): the B operand that goes with col
   float *spt;  // tile records of the tokenizer's softmax over pixels ([N * P / 16][2][L]; null when P is not a multiple of 16)
@@ -46,6 +48,8 @@ int gen_backward(GenModel *g, const float *arena, const vt_layout *lo, float *gr
 int gen_expand_du(GenModel *g, const float *arena, const vt_layout *lo, int n, hipStream_t s);
 // fills g->dz (the dense delta behind the projector's BatchNorm) from the last backward's window records
 int gen_expand_dz(GenModel *g, int n, hipStream_t s);
+// fills g->z (the projector's pre-norm output) when the last forward pooled it without storing it
+int gen_expand_z(GenModel *g, const float *arena, const vt_layout *lo, int n, hipStream_t s);
 // fills g->tdx (the BatchNorm2D input delta) from the last backward's coefficients
 int gen_expand_tdx(GenModel *g, int n, hipStream_t s);
 

@@ -805,8 +805,10 @@ __global__ __launch_bounds__(GT) void k_pool_delta_records(const float *__restri
 // that own a channel add up the records of that channel in window order (every thread reads the same record at the
 // same time: one broadcast read), so the sums do not depend on scheduling.  Channel c is owned by 256 / C2 threads,
 // each with a slice of the 256 records (NK = 1); one thread owns up to four channels when C2 > 256 (NK = 4).
+// (zmax != nullptr: z at the windows' arg-max positions, one value per window, instead of z itself)
 template <int NK>
-__global__ __launch_bounds__(GT) void k_pool_delta_windows(const float *__restrict__ z, const float *__restrict__ stat,
+__global__ __launch_bounds__(GT) void k_pool_delta_windows(const float *__restrict__ z, const float *__restrict__ zmax,
+                                                           const float *__restrict__ stat,
                                                            const float *__restrict__ dpool, const float *__restrict__ pooled,
                                                            const int *__restrict__ pool_idx, long windows, int wpb, int C2,
                                                            int P, float *__restrict__ out) {
@@ -831,7 +833,7 @@ __global__ __launch_bounds__(GT) void k_pool_delta_windows(const float *__restri
         const long nc = wi / 196;
         const int idx = pool_idx[wi];
         const int c = (int)(((nc % C2) * PmodC + idx) % C2);  // (nc * P + idx) % C2 without 64-bit products
-        const float xh = (z[nc * P + idx] - stat[c]) * stat[C2 + c];
+        const float xh = ((zmax ? zmax[wi] : z[nc * P + idx]) - stat[c]) * stat[C2 + c];
         r = make_float4(__int_as_float(c), d, d * xh, 0.f);
       }
     }
@@ -1085,16 +1087,17 @@ int pool_bn_backward(vt::GenModel *g, const float *gamma, float *ggamma, float *
   const long R = (long)n * g->P;
   // the two column sums from a walk over the window records (one non-zero per pk x pk positions)
   const long windows = (long)n * g->Q;
+  const float *zmax = g->z_valid ? nullptr : g->zmax;  // (row 0 of z, which the finalize below reads, is always stored)
   const long most = g->part_floats / (2L * C2);  // partial records the buffer holds
   long wpb = 4096;
   while ((windows + wpb - 1) / wpb > most) wpb *= 2;
   const int nb = (int)((windows + wpb - 1) / wpb);
   if (C2 > 4 * GT || wpb > (1L << 30)) return VT_EUNSUPPORTED;
   if (C2 <= GT)
-    hipLaunchKernelGGL(k_pool_delta_windows<1>, dim3(nb), dim3(GT), 0, s, g->z, g->stat_pn, g->dpool, g->pooled, g->pool_idx,
+    hipLaunchKernelGGL(k_pool_delta_windows<1>, dim3(nb), dim3(GT), 0, s, g->z, zmax, g->stat_pn, g->dpool, g->pooled, g->pool_idx,
                        windows, (int)wpb, C2, g->P, g->part);
   else
-    hipLaunchKernelGGL(k_pool_delta_windows<4>, dim3(nb), dim3(GT), 0, s, g->z, g->stat_pn, g->dpool, g->pooled, g->pool_idx,
+    hipLaunchKernelGGL(k_pool_delta_windows<4>, dim3(nb), dim3(GT), 0, s, g->z, zmax, g->stat_pn, g->dpool, g->pooled, g->pool_idx,
                        windows, (int)wpb, C2, g->P, g->part);
   VT_CHECK_LAUNCH();
   VTG(vt_bn_bwd_finalize(g->part, nb, C2, R, gamma, g->stat_pn, g->z, ggamma, gbeta, g->coef_pn, (vt_stream)s));
@@ -1214,6 +1217,8 @@ int gen_create(GenModel *g, const vt_dims *d, int maxN, int (*alloc)(void *, flo
   A(&g->v, NL * C2, nullptr);
   A(&g->pa, NP * L, "fwd.proj_a");
   A(&g->z, NP * C2, "fwd.proj_z");
+  A(&g->zmax, N * (size_t)g->Q, nullptr);
+  g->z_valid = 1;
   A(&g->pooled, N * Q, "fwd.pooled");
   A(&g->logits, N * K, "fwd.logits");
   A(&g->probs, N * K, "fwd.preds");
@@ -1366,16 +1371,34 @@ int gen_forward(GenModel *g, const float *arena, const vt_layout *lo, float *are
   VTG(mm_exact(false, true, C1, L, D, W("proj.linear1.W"), D, g->k, D, g->Mq, L, nullptr, false, 1.f, n, 0, (long)L * D,
                (long)C1 * L));
   VTG(mm_softmax(g, 0, 1, nullptr, false, P, L, C1, g->x, C1, (long)P * C1, g->Mq, L, (long)C1 * L, g->pa, n, s));
+  bool z_pooled = false;  // the pooling ran inside the launch that formed z
   {  // z = downsample(x) + attention . values (projector_layer.hpp:93-100), one pass, z written once
     const vt_gemm_term t[2] = {{g->x, W("proj.downsample.W"), (long)P * C1, 0, C1, C1, C2, 0},
                                {g->pa, g->v, (long)P * L, (long)L * C2, L, L, C2, 0}};
     // where the row-panel kernel takes the shape, the same launch leaves the BatchNorm's partial records (second moments
     // around the running mean) and z is not read again for its statistics
+    // VT_GEN_STORE_Z=0: z is not stored at all where it is much wider than what it is made from (2 * C2 > C1 + L: the scaled
+    // shape, 128 columns from 80): a first launch forms it for its statistics only (row 0, which the BatchNorm backward
+    // reads, is kept), a second forms it again, normalises, applies the ReLU and pools; the backward gets z at the
+    // windows' arg-max positions (g->zmax).  Bit-identical, 62 GB less traffic at batch 1024, and slower: the launches
+    // that form z take 11-13 ms with or without the store (matrix instructions, their LDS operand reads, the
+    // statistics' vector work and the loads add up rather than overlap), so forming it twice costs more than writing
+    // and re-reading it.  Kept as a switch for memory-bound parts.
+    const char *sz = getenv("VT_GEN_STORE_Z");  // read per call: a test switches it inside one process
+    const bool store_z = !(sz && *sz == '0');
+    const bool pooled_launch = !store_z && sum_form() == 2 && g->pk == 16 && 2 * C2 > C1 + L && P % 112 == 0;
     int rpb = 0;
     int rc = VT_EUNSUPPORTED;
+    g->z_valid = 1;
+    z_pooled = false;
     if (sum_form() == 2)
+      rc = vt_gemm_sum_colstats(2, 2, t, P, C2, 1.f, g->z, pooled_launch ? 0 : C2, (long)P * C2, W("proj.downsample.b"), n,
+                                W("proj.norm.running_mean"), g->part, g->part_floats, &rpb, (vt_stream)s);
+    if (rc == VT_EUNSUPPORTED && pooled_launch && sum_form() == 2)  // (shapes the statistics launch does not take at all)
       rc = vt_gemm_sum_colstats(2, 2, t, P, C2, 1.f, g->z, C2, (long)P * C2, W("proj.downsample.b"), n,
                                 W("proj.norm.running_mean"), g->part, g->part_floats, &rpb, (vt_stream)s);
+    else if (rc == 0 && pooled_launch)
+      g->z_valid = 0;
     if (rc == 0) {
       const int nb = n * ((P + rpb - 1) / rpb);
       VTG(vt_bn_stats_finalize(g->part, nb, C2, rpb, NP, RW("proj.norm.running_mean"), RW("proj.norm.running_var"), g->stat_pn,
@@ -1386,9 +1409,21 @@ int gen_forward(GenModel *g, const float *arena, const vt_layout *lo, float *are
     } else {
       return rc;
     }
+    if (!g->z_valid) {
+      const int prc = vt_gemm_sum_bn_relu_pool(2, 2, t, g->H, C2, W("proj.downsample.b"), n, g->stat_pn, W("proj.norm.gamma"),
+                                               W("proj.norm.beta"), g->pk, g->pooled, g->pool_idx, g->zmax, (vt_stream)s);
+      if (prc == 0) {
+        z_pooled = true;
+      } else if (prc == VT_EUNSUPPORTED) {  // the matrix after all, for the pooling pass below
+        VTG(vt_gemm_sum(2, 2, t, P, C2, 1.f, 0, g->z, C2, (long)P * C2, W("proj.downsample.b"), n, (vt_stream)s));
+        g->z_valid = 1;
+      } else {
+        return prc;
+      }
+    }
   }
   // reshape, max-pool, fc, softmax (vit_cnn.hpp:179-203)
-  {
+  if (!z_pooled) {
     const long strips = (long)n * C2 * 14;
     hipLaunchKernelGGL(k_pool_fwd, dim3((unsigned)((strips + 3) / 4)), dim3(GT), ((size_t)2 * (GT / 64) * g->H + 3 * (size_t)C2) * sizeof(float), s,
                        g->z, g->stat_pn, W("proj.norm.gamma"), W("proj.norm.beta"), g->pooled, g->pool_idx, strips, C2, g->H,
@@ -1631,6 +1666,19 @@ int gen_backward(GenModel *g, const float *arena, const vt_layout *lo, float *gr
   } else if (phase & 2) {
     VTG(attention_bwd(g, s));
   }
+  return 0;
+}
+
+// The projector's pre-norm output as the dense array [n*P, C2] (the forward may have pooled it without storing it): the
+// same sum of products, stored; x, the attention map and the values are those of the last forward
+int gen_expand_z(GenModel *g, const float *arena, const vt_layout *lo, int n, hipStream_t s) {
+  if (g->z_valid) return 0;
+  const int P = g->P, C1 = g->C1, C2 = g->C2, L = g->L;
+  auto W = [&](const char *name) { return arena + lo->t[vt_find(lo, name)].offset; };
+  const vt_gemm_term t[2] = {{g->x, W("proj.downsample.W"), (long)P * C1, 0, C1, C1, C2, 0},
+                             {g->pa, g->v, (long)P * L, (long)L * C2, L, L, C2, 0}};
+  VTG(vt_gemm_sum(2, 2, t, P, C2, 1.f, 0, g->z, C2, (long)P * C2, W("proj.downsample.b"), n, (vt_stream)s));
+  g->z_valid = 1;
   return 0;
 }
 

@@ -1366,6 +1366,9 @@ extern "C" long vt_model_read(vt_model *m, const char *name, float *host, long c
   if (m->gen && src == m->gen->du && m->lastN > 0) {  // likewise for the general-shape step
     if (gen_expand_du(m->gen, m->arena, &m->lo, m->lastN, nullptr) != 0 || hipDeviceSynchronize() != hipSuccess) return VT_EINVAL;
   }
+  if (m->gen && src == m->gen->z && m->lastN > 0) {  // the projector's pre-norm output may have been pooled without being stored
+    if (gen_expand_z(m->gen, m->arena, &m->lo, m->lastN, nullptr) != 0 || hipDeviceSynchronize() != hipSuccess) return VT_EINVAL;
+  }
   if (m->gen && src == m->gen->dz && m->lastN > 0) {  // the delta behind the projector's BatchNorm may exist as records only
     if (gen_expand_dz(m->gen, m->lastN, nullptr) != 0 || hipDeviceSynchronize() != hipSuccess) return VT_EINVAL;
   }
