@@ -558,13 +558,16 @@ constexpr int PANEL_T = 512, PANEL_W = PANEL_T / 64;  // eight waves share one L
 constexpr int PANEL_NMAX = 208, PANEL_LDS_MAX = 160 * 1024;  // result columns (thirteen 16-column tiles), LDS per workgroup
 
 // AX: what term 0's A is: 0 a plain matrix, 1 delta records (GemmSumP::dz_coef), 2 a BatchNorm input normalised on
-// load and written back (GemmSumP::ax_*)
+// load and written back (GemmSumP::ax_*), 3 delta records whose product never enters the matrix cores: a row's
+// expansion is shift[k] everywhere plus one value per group of 16, so its product with op(B) is a constant row
+// (shift . op(B), formed once per workgroup) plus one scaled row of op(B) per record, added to the tile in fp32 before
+// the epilogue (K0 / 16 rows of op(B) per result row instead of K0)
 // EPI: built with the row epilogue GemmSumP::epi (1 or 2); WV: waves per workgroup (sixteen where a copy of op(B) leaves
 // room for one workgroup per compute unit and the kernel fits four waves on a SIMD)
 // GS: 16-deep steps per group (one group is in the matrix cores while the next group's rows of A are in flight; with
 // nsteps <= GS the whole next tile is in flight during a tile)
 template <int PR, int NT, int AX = 0, int EPI = 0, int WV = PANEL_W, int GS = 4>
-__global__ __launch_bounds__(64 * WV, (WV > 8 || (NT > 8 && EPI != 2)) ? 4 : 1) void k_gemm_panel(GemmSumP p, int rows_per_wg, int Kp, int nsteps) {
+__global__ __launch_bounds__(64 * WV, (AX == 3 || EPI == 4 || WV > 8 || (NT > 8 && EPI != 2)) ? 4 : 1) void k_gemm_panel(GemmSumP p, int rows_per_wg, int Kp, int nsteps) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   PanelStep *steps = reinterpret_cast<PanelStep *>(smem);
   constexpr int NP16 = NT * 16;
@@ -580,7 +583,7 @@ __global__ __launch_bounds__(64 * WV, (WV > 8 || (NT > 8 && EPI != 2)) ? 4 : 1) 
   int kofs = 0, sbase = 0;
 #pragma unroll
   for (int ti = 0; ti < 4; ++ti) {
-    if (ti < p.nterms) {
+    if (ti < p.nterms && !(AX == 3 && ti == 0)) {
       const GemmTerm t = p.t[ti];
       const int ns = (t.K + 15) >> 4, K16 = ns * 16;
       if (tid >= sbase && tid < sbase + ns) {
@@ -667,6 +670,26 @@ __global__ __launch_bounds__(64 * WV, (WV > 8 || (NT > 8 && EPI != 2)) ? 4 : 1) 
     const int K0 = p.t[0].K;
     for (int i = tid; i < 2 * K0; i += (64 * WV)) zc[i] = p.dz_coef[i];
   }
+  if constexpr (AX == 3) {  // scale [K0], shift . op(B) [NP16], op(B) of term 0 in fp32 [K0][NP16 + 4]
+    const GemmTerm t = p.t[0];
+    if (p.nterms == 1) {  // no other term: one step of zeros keeps the tile loop's shape (Kp = 16)
+      if (tid == 0) steps[0] = PanelStep{t.A, 0, 0, 0, 0, 0};
+      for (int i = tid; i < 2 * NP16 * ldk; i += (64 * WV)) Bh[i] = 0;
+    }
+    const float *__restrict__ B = t.B + (long)b * t.sB;
+    float *__restrict__ sB = zc + t.K + NP16;
+    for (int i = tid; i < t.K; i += (64 * WV)) zc[i] = p.dz_coef[i];
+    for (int e = tid; e < t.K * NP16; e += (64 * WV)) {
+      const int k = t.tb ? e % t.K : e / NP16, n = t.tb ? e / t.K : e % NP16;
+      sB[k * (NP16 + 4) + n] = n < p.N ? B[t.tb ? (long)n * t.ldb + k : (long)k * t.ldb + n] : 0.f;
+    }
+    __syncthreads();
+    if (tid < NP16) {
+      float a = 0.f;
+      for (int k = 0; k < t.K; ++k) a = fmaf(p.dz_coef[t.K + k], sB[k * (NP16 + 4) + tid], a);
+      zc[t.K + tid] = a;
+    }
+  }
   if constexpr (AX == 2) {  // mean [K0p], 1/sigma [K0p], gamma [K0p], beta [K0p] (K0p = K padded to 16: zeros)
     const int K0 = p.t[0].K, K0p = ((K0 + 15) >> 4) * 16;
     for (int i = tid; i < 4 * K0p; i += (64 * WV)) {
@@ -674,7 +697,7 @@ __global__ __launch_bounds__(64 * WV, (WV > 8 || (NT > 8 && EPI != 2)) ? 4 : 1) 
       zc[i] = k >= K0 ? 0.f : w == 0 ? p.ax_stat[k] : w == 1 ? p.ax_stat[K0 + k] : w == 2 ? p.ax_gamma[k] : p.ax_beta[k];
     }
   }
-  // EPI 4: per-wave running sums [WV][2][NP16] of (value - pivot) and its square, and the pivot [NP16], behind op(B)
+  // EPI 4: the pivot and the bias [NP16 each] behind op(B)
   float *__restrict__ cst = reinterpret_cast<float *>(smem + PANEL_HEAD) + (PR == 2 ? NP16 * ldk : Kp * ldn);
   // EPI 5: mean, 1/sigma * gamma, beta [NP16 each], then the segment records of one chunk of 16 * WV rows:
   // best value, its column inside the segment, the value of C there [16 * WV][NT] each
@@ -690,9 +713,11 @@ __global__ __launch_bounds__(64 * WV, (WV > 8 || (NT > 8 && EPI != 2)) ? 4 : 1) 
       pl_c[2 * NP16 + i] = on ? p.pl_beta[i] : 0.f;
     }
   }
-  if constexpr (EPI == 4) {
-    for (int i = tid; i < WV * 2 * NP16; i += (64 * WV)) cst[i] = 0.f;
-    for (int i = tid; i < NP16; i += (64 * WV)) cst[WV * 2 * NP16 + i] = (p.col_pivot && i < p.N) ? p.col_pivot[i] : 0.f;
+  if constexpr (EPI == 4) {  // pivot [NP16], bias [NP16]; the waves' sums take op(B)'s place once the rows are done
+    for (int i = tid; i < NP16; i += (64 * WV)) {
+      cst[i] = (p.col_pivot && i < p.N) ? p.col_pivot[i] : 0.f;
+      cst[NP16 + i] = (p.bias && i < p.N) ? p.bias[i] : 0.f;
+    }
   }
   __syncthreads();
 
@@ -724,6 +749,24 @@ __global__ __launch_bounds__(64 * WV, (WV > 8 || (NT > 8 && EPI != 2)) ? 4 : 1) 
   f32x4 acc[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // EPI 6: the lane's running sums of (value - pivot) and of its square, one column per tile
+  float cs1[EPI == 4 ? NT : 1], cs2[EPI == 4 ? NT : 1];
+#pragma unroll
+  for (int j = 0; j < (EPI == 4 ? NT : 1); ++j) cs1[j] = cs2[j] = 0.f;
+  // AX 3: the records of the lane's row (pairs of value and position, two to a 16-byte load; at most eight)
+  float4 rq[AX == 3 ? 4 : 1], rq_n[AX == 3 ? 4 : 1];
+  auto fetch_records = [&](long row0, float4 (&dst)[AX == 3 ? 4 : 1]) {
+    if constexpr (AX == 3) {
+      const long row = row0 + c;
+      const float *__restrict__ R = p.t[0].A + (long)b * p.t[0].sA + row * p.t[0].lda;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        dst[u] = make_float4(0.f, __int_as_float(-1), 0.f, __int_as_float(-1));
+        if (row < p.M && 32 * u < p.t[0].K) dst[u] = *reinterpret_cast<const float4 *>(R + 4 * u);
+      }
+    }
+  };
+  fetch_records(tile_row0(0), rq);
   float4 cur[GS], nxt[GS];
   fetch(tile_row0(0), 0, cur);
   float *__restrict__ C = p.C + (long)b * p.sC;
@@ -736,7 +779,10 @@ __global__ __launch_bounds__(64 * WV, (WV > 8 || (NT > 8 && EPI != 2)) ? 4 : 1) 
     for (int gi = 0; gi < G; ++gi) {
       const bool last = gi + 1 == G;
       if (!last) fetch(row0, gi + 1, nxt);
-      else if (i + 1 < ntiles) fetch(tile_row0(i + 1), 0, nxt);
+      else if (i + 1 < ntiles) {
+        fetch_records(tile_row0(i + 1), rq_n);
+        fetch(tile_row0(i + 1), 0, nxt);
+      }
 #pragma unroll
       for (int e = 0; e < GS; ++e) {
         const int si = gi * GS + e;
@@ -781,7 +827,7 @@ __global__ __launch_bounds__(64 * WV, (WV > 8 || (NT > 8 && EPI != 2)) ? 4 : 1) 
             // one row of C (one 16-byte store).  All of op(B)'s fragments first, then the three partial products
             // tile by tile: consecutive matrix instructions write different accumulators, none waits for the one
             // before it
-            constexpr int JG = GS > 4 ? 4 : NT <= 8 ? NT : (EPI == 1 ? 4 : 7);  // tiles whose fragments are held at once
+            constexpr int JG = (GS > 4 || (EPI == 4 && NT == 8)) ? 4 : NT <= 8 ? NT : (EPI == 1 ? 4 : 7);  // tiles whose fragments are held at once
 #pragma unroll
             for (int j0 = 0; j0 < NT; j0 += JG) {
               s16x4 bh[JG], bl[JG];
@@ -793,27 +839,84 @@ __global__ __launch_bounds__(64 * WV, (WV > 8 || (NT > 8 && EPI != 2)) ? 4 : 1) 
                 }
 #pragma unroll
               for (int j = 0; j < JG; ++j)
-                if (j0 + j < NT) acc[j0 + j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bh[j], al, acc[j0 + j], 0, 0, 0);
+                if (j0 + j < NT)
+                  acc[j0 + j] = EPI == 4 ? __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al, bh[j], acc[j0 + j], 0, 0, 0)
+                                         : __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bh[j], al, acc[j0 + j], 0, 0, 0);
 #pragma unroll
               for (int j = 0; j < JG; ++j)
-                if (j0 + j < NT) acc[j0 + j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bl[j], ah, acc[j0 + j], 0, 0, 0);
+                if (j0 + j < NT)
+                  acc[j0 + j] = EPI == 4 ? __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, bl[j], acc[j0 + j], 0, 0, 0)
+                                         : __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bl[j], ah, acc[j0 + j], 0, 0, 0);
 #pragma unroll
               for (int j = 0; j < JG; ++j)
-                if (j0 + j < NT) acc[j0 + j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bh[j], ah, acc[j0 + j], 0, 0, 0);
+                if (j0 + j < NT)
+                  acc[j0 + j] = EPI == 4 ? __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, bh[j], acc[j0 + j], 0, 0, 0)
+                                         : __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bh[j], ah, acc[j0 + j], 0, 0, 0);
             }
           } else {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
               for (int j = 0; j < NT; ++j)
-                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(Bs[(kb + q) * ldn + j * 16 + c], av[q], acc[j], 0, 0, 0);
+                acc[j] = EPI == 4 ? __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], Bs[(kb + q) * ldn + j * 16 + c], acc[j], 0, 0, 0)
+                                  : __builtin_amdgcn_mfma_f32_16x16x4f32(Bs[(kb + q) * ldn + j * 16 + c], av[q], acc[j], 0, 0, 0);
           }
         }
       }
       if (last) {
         const long gm = row0 + c;  // lane (c, g) holds C[row c][16 j + 4 g .. + 3]
         const bool row_on = gm < p.M;
-        if constexpr (EPI != 0) {
+        if constexpr (AX == 3) {
+          const int K0 = p.t[0].K;
+          const float *__restrict__ sB = zc + K0 + NP16;
+          f32x4 sp[NT];
+#pragma unroll
+          for (int j = 0; j < NT; ++j) sp[j] = *reinterpret_cast<const f32x4 *>(zc + K0 + j * 16 + 4 * g);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const float rv[4] = {rq[u].x, rq[u].y, rq[u].z, rq[u].w};
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              if (16 * (2 * u + h) < K0) {
+                const int pos = __float_as_int(rv[2 * h + 1]);
+                const bool on = (unsigned)pos < 16u;
+                const int k = 16 * (2 * u + h) + (on ? pos : 0);
+                const float w = on ? rv[2 * h] * zc[k] : 0.f;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                  const f32x4 bq = *reinterpret_cast<const f32x4 *>(sB + k * (NP16 + 4) + j * 16 + 4 * g);
+#pragma unroll
+                  for (int v = 0; v < 4; ++v) sp[j][v] = fmaf(w, bq[v], sp[j][v]);
+                }
+              }
+            }
+            __builtin_amdgcn_sched_barrier(0);  // two records' rows of op(B) in registers at a time, not all eight's
+          }
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[j] += sp[j];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) rq[u] = rq_n[u];
+        }
+        if constexpr (EPI == 4) {
+          // operands the other way round: lane (c, g) holds C[rows 4 g .. + 3][column 16 j + c], so a column's sums over
+          // the rows of all of the wave's tiles gather in registers and cross lanes once, after the last tile
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            const int gn = j * 16 + c;
+            const float pv = cst[gn], bj = cst[NP16 + gn];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+              const long gr = row0 + 4 * g + v;
+              const float x = acc[j][v] * p.alpha + bj;
+              const float d = gr < p.M ? x - pv : 0.f;
+              cs1[j] += d;
+              cs2[j] += d * d;
+              const bool st = p.c_first_row_only ? (b == 0 && gr == 0) : gr < p.M;
+              if (st && gn < p.N) C[gr * p.ldc + gn] = x;
+            }
+            acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          }
+        } else if constexpr (EPI != 0) {
           // row epilogues: a row's values sit in the four lanes c, c+16, c+32, c+48, NT * 4 in each
           float r[NT][4];
 #pragma unroll
@@ -889,36 +992,6 @@ __global__ __launch_bounds__(64 * WV, (WV > 8 || (NT > 8 && EPI != 2)) ? 4 : 1) 
                 seg_z[rl * NT + j] = bz;
               }
             }
-          } else if constexpr (EPI == 4) {
-            // column sums of (value - pivot) and of its square over the tile's rows (the 16 lanes of a lane row), added to
-            // this wave's running sums in LDS by the row's first lane
-            float *__restrict__ ws = cst + wave * 2 * NP16;
-            const float *__restrict__ piv = cst + WV * 2 * NP16;
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-              const int gn = j * 16 + 4 * g;
-              const float4 pv = *reinterpret_cast<const float4 *>(piv + gn);
-              const float pq[4] = {pv.x, pv.y, pv.z, pv.w};
-              float s1[4], s2[4];
-#pragma unroll
-              for (int v = 0; v < 4; ++v) {
-                const float d = row_on ? r[j][v] - pq[v] : 0.f;
-                float a = d, q = d * d;
-                a += row_ror<8>(a); q += row_ror<8>(q);
-                a += row_ror<4>(a); q += row_ror<4>(q);
-                a += row_ror<2>(a); q += row_ror<2>(q);
-                a += row_ror<1>(a); q += row_ror<1>(q);
-                s1[v] = a;
-                s2[v] = q;
-              }
-              if (c == 0) {
-                float4 o1 = *reinterpret_cast<float4 *>(ws + gn), o2 = *reinterpret_cast<float4 *>(ws + NP16 + gn);
-                o1.x += s1[0]; o1.y += s1[1]; o1.z += s1[2]; o1.w += s1[3];
-                o2.x += s2[0]; o2.y += s2[1]; o2.z += s2[2]; o2.w += s2[3];
-                *reinterpret_cast<float4 *>(ws + gn) = o1;
-                *reinterpret_cast<float4 *>(ws + NP16 + gn) = o2;
-              }
-            }
           } else if constexpr (EPI == 3) {
             // column records of this tile: the 16 rows of a column sit in the 16 lanes c of one lane group g
             float *__restrict__ rec = p.tile_rec + ((long)b * ((p.M + 15) >> 4) + (row0 >> 4)) * 2 * p.N;
@@ -987,7 +1060,7 @@ __global__ __launch_bounds__(64 * WV, (WV > 8 || (NT > 8 && EPI != 2)) ? 4 : 1) 
 #pragma unroll
               for (int v = 0; v < 4; ++v) r[j][v] = a[j][v] * (r[j][v] - dot);
           }
-          const bool store_row = EPI == 5 ? false : (EPI == 4 && p.c_first_row_only) ? (row_on && b == 0 && gm == 0) : row_on;
+          const bool store_row = EPI == 5 ? false : row_on;
 #pragma unroll
           for (int j = 0; j < NT; ++j) {
             const int gn = j * 16 + 4 * g;
@@ -1066,19 +1139,32 @@ __global__ __launch_bounds__(64 * WV, (WV > 8 || (NT > 8 && EPI != 2)) ? 4 : 1) 
     }
   }
   if constexpr (EPI == 4) {
-    // the workgroup's record: the waves' sums in wave order, brought from the pivot to (sum, squared distances from
-    // the workgroup's own mean)
+    // the lane groups' sums of a column, then the waves' in wave order (their slots take op(B)'s place), brought from
+    // the pivot to (sum, squared distances from the workgroup's own mean)
+    __syncthreads();
+    float *__restrict__ slot = reinterpret_cast<float *>(smem + PANEL_HEAD);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      float a = cs1[j], q = cs2[j];
+      a += __shfl_xor(a, 16); q += __shfl_xor(q, 16);
+      a += __shfl_xor(a, 32); q += __shfl_xor(q, 32);
+      if (g == 0) {
+        slot[wave * 2 * NP16 + j * 16 + c] = a;
+        slot[wave * 2 * NP16 + NP16 + j * 16 + c] = q;
+      }
+    }
+    const float pvt = tid < NP16 ? cst[tid] : 0.f;
     __syncthreads();
     if (tid < p.N) {
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int w = 0; w < WV; ++w) {
-        s1 += cst[w * 2 * NP16 + tid];
-        s2 += cst[w * 2 * NP16 + NP16 + tid];
+        s1 += slot[w * 2 * NP16 + tid];
+        s2 += slot[w * 2 * NP16 + NP16 + tid];
       }
       const long left = p.M - wg_row0;
       const double n = (double)(left < rows_per_wg ? (left > 0 ? left : 0) : rows_per_wg);
-      const double pv = (double)cst[WV * 2 * NP16 + tid];
+      const double pv = (double)pvt;
       float *__restrict__ o = p.col_part + ((long)b * gridDim.x + blockIdx.x) * 2 * p.N;
       o[tid] = (float)((double)s1 + n * pv);
       o[p.N + tid] = n > 0.0 ? (float)((double)s2 - (double)s1 * (double)s1 / n) : 0.f;
@@ -1145,19 +1231,28 @@ static int panel_launch(int form, const GemmSumP &p, int batch, hipStream_t hs, 
   }();
   if (off || (form != 0 && form != 2) || p.N > PANEL_NMAX || p.M < 2048 || batch > 65535) return 0;
   if (p.epi != 0 && p.accumulate) return 0;
+  const int NT = p.N <= 16 ? 1 : p.N <= 32 ? 2 : p.N <= 64 ? 4 : p.N <= 128 ? 8 : 13;
+  static const bool sparse_on = [] {
+    const char *e = getenv("VT_PANEL_RECORD_ROWS");
+    return !(e && *e == '0');
+  }();
+  // records applied row by row (16-byte loads of a row's records: at most eight, in pairs)
+  const bool sparse = dz && sparse_on && form == 2 && (NT == 1 || NT == 4) && p.t[0].K % 32 == 0 && p.t[0].K <= 128 &&
+                      (reinterpret_cast<uintptr_t>(p.t[0].A) & 15) == 0 && p.t[0].sA % 4 == 0 && p.t[0].lda % 4 == 0;
   int Kp = 0, nsteps = 0;
-  for (int i = 0; i < p.nterms; ++i) {
+  if (sparse && p.nterms == 1) Kp = 16, nsteps = 1;  // a step of zeros
+  for (int i = sparse ? 1 : 0; i < p.nterms; ++i) {
     if (!p.t[i].vecA) return 0;
     const int ns = (p.t[i].K + 15) / 16;
     nsteps += ns;
     Kp += ns * 16;
   }
   if (nsteps > PANEL_STEPS) return 0;
-  const int NT = p.N <= 16 ? 1 : p.N <= 32 ? 2 : p.N <= 64 ? 4 : p.N <= 128 ? 8 : 13;
   size_t lds = PANEL_HEAD + (form == 2 ? (size_t)2 * NT * 16 * (Kp + 8) * 2 : (size_t)Kp * (NT * 16 + 4) * 4);
   if (dz) {
     if (form != 2 || p.t[0].K % 16 != 0 || !p.dz_coef || (NT != 1 && NT != 4 && NT != 13)) return 0;
-    lds += (size_t)2 * p.t[0].K * sizeof(float);
+    if (sparse) lds += ((size_t)p.t[0].K + NT * 16 + (size_t)p.t[0].K * (NT * 16 + 4)) * sizeof(float);
+    else lds += (size_t)2 * p.t[0].K * sizeof(float);
   }
   if (ax) {  // built for the exact form with one or thirteen result tiles (the tokenizer's scores)
     if (form != 0 || (NT != 1 && NT != 13) || !p.ax_stat || !p.ax_gamma || !p.ax_beta || !p.ax_out || p.t[0].K % 4 != 0) return 0;
@@ -1204,8 +1299,8 @@ static int panel_launch(int form, const GemmSumP &p, int batch, hipStream_t hs, 
     if (!((NT == 8 && form == 2) || (NT == 4 && form == 0)) || ax || dz || p.accumulate || !p.col_part) return 0;
     if (batch > 1 && p.M % rows != 0) return 0;  // every workgroup but the launch's last must hold `rows` rows
     if ((long)batch * grid.x * 2 * p.N > p.col_part_floats) return 0;
-    const bool sixteen = lds > 80 * 1024 && wide16;  // decided as for the plain launch, before the slots are added
-    lds += ((size_t)(sixteen ? 16 : 8) * 2 + 1) * NT * 16 * sizeof(float);
+    const bool sixteen = lds > 80 * 1024 && wide16;  // decided as for the plain launch
+    lds += (size_t)2 * NT * 16 * sizeof(float);  // pivot and bias; the waves' sums reuse op(B)'s space
     if (lds > (size_t)PANEL_LDS_MAX) return 0;
     if (NT == 4) e = panel_go<0, 4, 0, 4>(grid, lds, hs, p, rows, Kp, nsteps);
     else if (sixteen) e = panel_go<2, 8, 0, 4, 16>(grid, lds, hs, p, rows, Kp, nsteps);
@@ -1227,7 +1322,8 @@ static int panel_launch(int form, const GemmSumP &p, int batch, hipStream_t hs, 
     if (p.epi == 1) e = panel_go<PR_, NT_, AX_, 1>(grid, lds, hs, p, rows, Kp, nsteps); \
     else e = panel_go<PR_, NT_, AX_, 2>(grid, lds, hs, p, rows, Kp, nsteps);            \
   } while (0)
-    if (dz && NT == 1) e = panel_go<2, 1, 1, 2>(grid, lds, hs, p, rows, Kp, nsteps);
+    if (sparse && NT == 1) e = panel_go<2, 1, 3, 2>(grid, lds, hs, p, rows, Kp, nsteps);
+    else if (dz && NT == 1) e = panel_go<2, 1, 1, 2>(grid, lds, hs, p, rows, Kp, nsteps);
     else if (dz) e = panel_go<2, 13, 1, 2>(grid, lds, hs, p, rows, Kp, nsteps);
     else if (form == 2 && NT == 1) VT_PANEL_EPI(2, 1, 0);
     else if (form == 2) VT_PANEL_EPI(2, 13, 0);
@@ -1236,6 +1332,8 @@ static int panel_launch(int form, const GemmSumP &p, int batch, hipStream_t hs, 
 #undef VT_PANEL_EPI
   } else if (ax && NT == 1) VT_PANEL(0, 1, 2);
   else if (ax) VT_PANEL(0, 13, 2);
+  else if (sparse && NT == 1) VT_PANEL(2, 1, 3);
+  else if (sparse) VT_PANEL(2, 4, 3);
   else if (dz && NT == 1) VT_PANEL(2, 1, 1);
   else if (dz && NT == 4) VT_PANEL(2, 4, 1);
   else if (dz) VT_PANEL(2, 13, 1);
