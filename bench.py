@@ -156,7 +156,7 @@ def measured_step_traffic(shape, batch, classes):
     """HBM bytes of one whole general-shape training step from the committed PMC passes; None off the measured
     configurations."""
     try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "r03_e_step_hbm_traffic_shapes.json")))
+        t = json.load(open(os.path.join(ROOT, "profiles", "r03_f_step_hbm_traffic_shapes.json")))
         return int(t["steps"]["%s_b%d_k%d" % (shape, batch, classes)]["traffic_bytes"])
     except (OSError, KeyError, ValueError):
         return None
@@ -300,6 +300,42 @@ def time_extra_config(shape, batch, bf16, classes, steps=3, warmup=1):
     return {"ms_per_step": round(dt * 1e3, 3), "images_per_sec": round(batch / dt, 1), "batch": batch, "steps": steps,
             "warmup": warmup, "dtype": "bf16" if bf16 else "f32", "emulation": emulation_note(True, bf16),
             "weights_finite_after_run": finite, "roofline": roof}
+
+
+def time_blood_general_path(batch, classes, exact, steps=30, warmup=5):
+    """The headline shape on the general-shape launchers (VT_GENERAL_PATH=1 at create), with the deep contractions as
+    bf16 hi/lo split products (exact False: the arithmetic of the tuned step) or with every product on exact fp32 matrix
+    instructions (exact True): what exactness costs on this shape, measured on the one set of kernels that has both."""
+    from vit_amd import VTCNN, Dims
+    from vit_amd._lib import lib as L
+    dims = Dims(num_classes=classes, **SHAPES["blood"])
+    os.environ["VT_GENERAL_PATH"] = "1"
+    before = L.vt_set_exact_products(1 if exact else 0)
+    try:
+        m = VTCNN(dims, max_batch=batch, seed=42)
+    finally:
+        os.environ.pop("VT_GENERAL_PATH", None)
+    try:
+        g = torch.Generator(device="cuda")
+        g.manual_seed(321)
+        x = (torch.randint(0, 256, (batch, 1, 28, 28), device="cuda", generator=g).to(torch.float32) / 255.0).contiguous()
+        y = torch.randint(0, classes, (batch,), device="cuda", generator=g).to(torch.int32)
+        for _ in range(warmup):
+            m.train_step(x, y, float(batch))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            m.train_step(x, y, float(batch))
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        finite = bool(torch.isfinite(m.arena).all().item())
+    finally:
+        L.vt_set_exact_products(before)
+    del m, x, y
+    torch.cuda.empty_cache()
+    return {"ms_per_step": round(dt * 1e3, 4), "images_per_sec": round(batch / dt, 1), "batch": batch, "steps": steps,
+            "warmup": warmup, "dtype": "f32", "kernels": "general-shape launchers (not the tuned step)",
+            "emulation": None if exact else GENERIC_EMULATION, "weights_finite_after_run": finite}
 
 
 def time_blood_config(batch, group, classes, steps=100, warmup=20):
@@ -699,7 +735,18 @@ def main():
                 except Exception as e:
                     extra[name] = {"error": "%s: %s" % (type(e).__name__, e)}
                     torch.cuda.empty_cache()
+            # what exact fp32 products cost on the headline shape: the general-shape launchers with and without them
+            for name, ex in (("blood_b1024_general_launchers_split_f32", False), ("blood_b1024_general_launchers_exact_f32", True)):
+                try:
+                    extra[name] = time_blood_general_path(1024, a.classes, ex)
+                except Exception as e:
+                    extra[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+                    torch.cuda.empty_cache()
             res["configs"] = extra
+            gs, ge = extra["blood_b1024_general_launchers_split_f32"], extra["blood_b1024_general_launchers_exact_f32"]
+            if "ms_per_step" in gs and "ms_per_step" in ge:
+                res["emulation"] += ("; the same step on the general-shape launchers: %.3f ms with split products, %.3f ms with "
+                                     "every product on exact fp32 MFMA (vt_set_exact_products)" % (gs["ms_per_step"], ge["ms_per_step"]))
         if world == 1 and not a.no_cpu_baseline and a.mode == "train" and not generic:
             res["cpu_baseline"] = cpu_baseline(B, a.classes)
         print(json.dumps(res), flush=True)

@@ -565,7 +565,9 @@ int vt_gemm_bn_apply_tile_records(int M, int N, int K, const float *A, int lda, 
  *   as in vt_gemm_f32.
  * vt_gemm_sum_records:  vt_gemm_sum (epi 0) or vt_gemm_softmax_rows' softmax backward (epi 2, epi_a laid out like C)
  *   with terms[0].A = rec (terms[0].K = N of the delta, a multiple of 16; terms[0].lda = K / 8 floats per row of
- *   records; terms[0].strideA in floats).  Row-panel kernel only: results up to 16, 33..64 or 129..208 columns wide
+ *   records; terms[0].strideA in floats).  Results up to 64 columns wide with at most eight groups (K <= 128, rec
+ *   16-byte aligned) apply the records row by row in fp32 (per result row: shift . op(B) plus one scaled row of op(B)
+ *   per record) instead of expanding them into the matrix steps.  Row-panel kernel only: results up to 16, 33..64 or 129..208 columns wide
  *   without the epilogue, up to 16 or 129..208 with it, and op(B) of all terms within 160 KB of LDS: VT_EUNSUPPORTED
  *   otherwise, and nothing is launched. */
 int vt_gemm_tn_records(int M, int N, int K, const float *A, int lda, long strideA, const float *rec, long strideRec,
@@ -593,6 +595,13 @@ int vt_softmax_bwd_rows(const float *a, float *da, long rows, int width, vt_stre
  * buffers.  stat [2C] receives (mean, 1/sqrt(var + 1e-5)) and is what the backward pass takes.  backward:
  * ggamma = sum delta*xhat, gbeta = sum delta, din = the reference's input delta including its row-0
  * variance term (:197-199).  scratch: vt_batchnorm_scratch_floats(C) floats. */
+/* Process-wide arithmetic of the general-shape step's products (no counterpart in the reference, whose products are
+ * plain fp32 loops: Tensor::matmul, tensor_cpu.hpp:754-814): on != 0 runs every product on exact fp32 matrix instructions
+ * (v_mfma_f32_16x16x4_f32), no bf16 hi/lo split products and no delta records; 0 (the default unless the environment
+ * variable VT_GEMM_EXACT is set) leaves the deep feature contractions on split products.  Returns the previous
+ * setting.  Together with VT_GENERAL_PATH=1 in the environment of vt_model_create (the general launchers also for
+ * the shape the tuned kernels are built for) it measures what exact products cost on the headline shape. */
+int vt_set_exact_products(int on);
 long vt_batchnorm_scratch_floats(int C);
 int vt_batchnorm_fwd(const float *in, long R, int C, const float *gamma, const float *beta, float *running_mean,
                      float *running_var, int training, float *stat, float *out, float *scratch, long scratch_floats,

@@ -218,3 +218,41 @@ def test_scaled_shape_pooling_without_the_stored_matrix_is_bit_identical():
             os.environ.pop("VT_GEN_STORE_Z", None)
     for a, b in zip(out["0"], out["1"]):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("exact", [False, True])
+def test_headline_shape_on_the_general_launchers_matches_the_tuned_step(exact, monkeypatch):
+    """VT_GENERAL_PATH=1 at create runs the headline shape on the general-shape launchers; with vt_set_exact_products
+    every product of that step is an exact fp32 matrix instruction.  Same weights, same batch: predictions and every
+    gradient against the tuned step's (whose deep contractions are hi/lo split products), pooling decisions checked
+    through exact arithmetic as for the other shapes when a near-tie flips one."""
+    import torch
+    from vit_amd import VTCNN, Dims
+    from vit_amd._lib import lib
+    dims = dict(num_classes=8, image_channels=1, input_dim=28, tokens=16, token_channels=32, vt_channels=16, heads=2)
+    n = 64
+    rng = np.random.default_rng(11)
+    x = (rng.integers(0, 256, size=(n, 1, 28, 28)).astype(np.float32) / np.float32(255.0))
+    y = rng.integers(0, 8, size=n).astype(np.int32)
+    tuned = VTCNN(Dims(**dims), max_batch=n, seed=42)
+    monkeypatch.setenv("VT_GENERAL_PATH", "1")
+    before = lib.vt_set_exact_products(1 if exact else 0)
+    try:
+        gen = VTCNN(Dims(**dims), max_batch=n, seed=42)
+        monkeypatch.delenv("VT_GENERAL_PATH")
+        arena = gen.get_arena().copy()
+        assert np.array_equal(arena, tuned.get_arena())
+        xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+        pt = tuned.forward(xd).cpu().numpy().copy()
+        pg = gen.forward(xd).cpu().numpy().copy()
+        assert rel_err(pg, pt) < TOL
+        tuned.backward(yd)
+        gen.backward(yd)
+        gt, gg = tuned.get_grads(), gen.get_grads()
+        lo = gen.layout
+        bad = [nm for nm, (off, size, shape, kind) in lo.tensors.items()
+               if kind == 0 and rel_err(gg[off:off + size], gt[off:off + size]) > 5e-4]
+        if bad:  # a pooling window decided the other way: both against exact arithmetic under their own decisions
+            _check_against_exact_math(gen, dims, n, x, y, arena, pg, gg)
+    finally:
+        lib.vt_set_exact_products(before)

@@ -9,6 +9,7 @@
 #include "vtcnn_generic.h"
 
 #include <algorithm>
+#include <atomic>
 #include <string>
 
 namespace vt {
@@ -924,6 +925,16 @@ int bf16_products() {
   return mask;
 }
 
+// Process-wide: every product of the general step on exact fp32 matrix instructions (no hi/lo split products, no
+// delta records).  Starts from the environment variable VT_GEMM_EXACT; vt_set_exact_products changes it.
+std::atomic<int> &exact_products() {
+  static std::atomic<int> v{[] {
+    const char *e = getenv("VT_GEMM_EXACT");
+    return (e && *e && *e != '0') ? 1 : 0;
+  }()};
+  return v;
+}
+
 struct Gemm {
   vt::GenModel *g;
   hipStream_t s;
@@ -941,24 +952,15 @@ struct Gemm {
     // fp32 mode: products at least 32 deep that contract over features (not over the batch's rows) and do not feed
     // an exponential run as bf16 hi/lo split products (fp32 accuracy to about 2^-17 per product, a third of the
     // matrix-pipe time); everything else on exact fp32 matrix instructions
-    static const bool all_exact = [] {
-      const char *e = getenv("VT_GEMM_EXACT");
-      return e && *e && *e != '0';
-    }();
+    const bool all_exact = exact_products().load(std::memory_order_relaxed) != 0;
     auto fn = (g->bf16 && reduced_ok && !ta) ? vt_gemm_bf16_mfma
               : (!exact && !all_exact && K >= 32) ? vt_gemm_f32x3 : vt_gemm_f32;
     return fn(ta, tb, M, N, K, alpha, A, lda, sA, B, ldb, sB, acc, C, ldc, sC, bias, batch, g->ws, g->ws_floats, (vt_stream)s);
   }
 };
 
-// arithmetic form of the sums of products (vt_gemm_sum): hi/lo split unless VT_GEMM_EXACT asks for fp32 instructions
-int sum_form() {
-  static const int form = [] {
-    const char *e = getenv("VT_GEMM_EXACT");
-    return (e && *e && *e != '0') ? 0 : 2;
-  }();
-  return form;
-}
+// arithmetic form of the sums of products (vt_gemm_sum): hi/lo split unless exact products are asked for
+int sum_form() { return exact_products().load(std::memory_order_relaxed) != 0 ? 0 : 2; }
 
 // the im2col matrix of X [n, Ci, H, H] into g->col
 int im2col(vt::GenModel *g, const float *X, int n, hipStream_t s) {
@@ -1714,6 +1716,8 @@ int gen_expand_du(GenModel *g, const float *arena, const vt_layout *lo, int n, h
 // for hosts that keep their own layer objects (layers/batch_normalization_layer.hpp:142-200, 262-327).
 // scratch holds the per-block partial sums (4096 blocks at most) and the 2C backward coefficients.
 // ---------------------------------------------------------------------------------------------
+extern "C" int vt_set_exact_products(int on) { return exact_products().exchange(on ? 1 : 0, std::memory_order_relaxed); }
+
 extern "C" long vt_batchnorm_scratch_floats(int C) { return C < 1 ? 0 : 4096L * 2 * C + 2L * C; }
 
 extern "C" int vt_batchnorm_fwd(const float *in, long R, int C, const float *gamma, const float *beta, float *running_mean,

@@ -151,9 +151,13 @@ extern "C" int vt_model_create(const vt_dims *dims, int max_batch, int device, f
   if (!dims || !out || max_batch < 1) return VT_EINVAL;
   vt_layout lo;
   if (vt_make_layout(dims, &lo) != 0) return VT_EINVAL;
+  // VT_GENERAL_PATH=1 (read at every create): the general-shape launchers also for the shape the tuned kernels are built
+  // for (measurement aid: the same step on another set of kernels, and with vt_set_exact_products on exact fp32
+  // matrix instructions throughout)
+  const char *gp = getenv("VT_GENERAL_PATH");
   const bool headline = dims->vt_channels == C2 && dims->tokens == L && dims->token_channels == D && dims->heads == HEADS &&
                         dims->input_dim * dims->input_dim <= PPT * TPB && dims->num_classes <= KMAX &&
-                        dims->image_channels <= 4;
+                        dims->image_channels <= 4 && !(gp && *gp && *gp != '0');
   DeviceGuard dg(device);
   if (!dg.ok) return VT_EINVAL;
   vt_model *m = new vt_model();
