@@ -527,6 +527,17 @@ int vt_gemm_sum(int form, int nterms, const vt_gemm_term *terms, int M, int N, f
 int vt_gemm_sum_colstats(int form, int nterms, const vt_gemm_term *terms, int M, int N, float alpha, float *C, int ldc,
                          long strideC, const float *bias, int batch, const float *col_pivot, float *col_part,
                          long col_part_floats, int *rows_per_block, vt_stream s);
+/* Conv2DLayer::forward, 3x3 / stride 1 / pad 1 (layers/conv2d_layer.hpp:35-87), as ONE row-panel launch in training
+ * mode: the im2col rows (row = image * H * H + h * H + w, column = (ci * 3 + kh) * 3 + kw, columns 9 Ci .. ld - 1 zero)
+ * are gathered from X [images][Ci][H][H] on load, written to col [images * H * H][ld] for the weight gradient
+ * (conv2d_layer.hpp:115-147) and multiplied by Wp^T (Wp [Co][ld]: conv.W with rows padded to ld floats) in exact fp32:
+ * C [images * H * H][Co] = col . Wp^T + bias, plus the BatchNorm partial records of C's columns as in
+ * vt_gemm_sum_colstats (BatchNorm2DLayer::forward, layers/batch_normalization_layer.hpp:262-298).  H a multiple of 16,
+ * 9 Ci <= ld <= 32, ld a multiple of 4, 33 <= Co <= 64, 16-byte aligned col and Wp: VT_EUNSUPPORTED otherwise, and
+ * nothing is launched (callers then form col themselves and use vt_gemm_sum_colstats). */
+int vt_conv3x3_rows_colstats(const float *X, int images, int Ci, int H, const float *Wp, int ld, int Co, const float *bias,
+                             float *col, float *C, const float *col_pivot, float *col_part, long col_part_floats,
+                             int *rows_per_block, vt_stream s);
 /* The sum of products of vt_gemm_sum (alpha 1, one H*H x N matrix per batch member) taken straight through the
  * BatchNorm apply, the ReLU, the reference's reshape [P, N] -> [N, H, H] (no data movement, model/vit_cnn.hpp:179) and
  * MaxPool2DLayer::forward with pk x pk windows to 14 x 14 (layers/pooling_layer.hpp:18-66; the first maximum of a window

@@ -273,3 +273,60 @@ def test_gemm_bf16_operands(ta, tb):
             return 0.5 * np.matmul(a, b) + bias
         assert rel_err(got, prod(_bf16_round(A), _bf16_round(B))) < 2e-6, (M, N, K)
         assert rel_err(got, prod(A, B)) < 1e-2, (M, N, K)
+
+
+def test_conv3x3_rows_gathered_from_the_images():
+    """vt_conv3x3_rows_colstats: the im2col matrix it writes, the product and the partial records against numpy, and
+    the product bit for bit against vt_gemm_sum_colstats on that matrix (same operands, same instruction order)."""
+    import torch
+    from vit_amd._lib import VtGemmTerm, check, lib
+    rng = np.random.default_rng(23)
+    for (n, Ci, H, Co, ld) in [(3, 3, 48, 64, 28), (2, 1, 32, 40, 12), (9, 2, 16, 64, 20)]:
+        X = rng.standard_normal((n, Ci, H, H)).astype(np.float32)
+        Wc = rng.standard_normal((Co, Ci * 9)).astype(np.float32)
+        Wp = np.zeros((Co, ld), np.float32)
+        Wp[:, :Ci * 9] = Wc
+        bias = rng.standard_normal(Co).astype(np.float32)
+        M = n * H * H
+        Xp = np.pad(X, ((0, 0), (0, 0), (1, 1), (1, 1)))
+        col = np.zeros((n, H, H, ld), np.float32)
+        for ci in range(Ci):
+            for kh in range(3):
+                for kw in range(3):
+                    col[..., (ci * 3 + kh) * 3 + kw] = Xp[:, ci, kh:kh + H, kw:kw + H]
+        col = col.reshape(M, ld)
+        want = col.astype(np.float64) @ Wp.T.astype(np.float64) + bias
+        pivot = (want.mean(0) + 0.1).astype(np.float32)
+        dX, dW, db, dp = (torch.from_numpy(a).cuda() for a in (X, Wp, bias, pivot))
+        dcol = torch.full((M, ld), 7.0, dtype=torch.float32, device="cuda")
+        dC = torch.zeros((M, Co), dtype=torch.float32, device="cuda")
+        dC2 = torch.zeros_like(dC)
+        part = torch.zeros(((M + 127) // 128) * 2 * Co, dtype=torch.float32, device="cuda")
+        part2 = torch.zeros_like(part)
+        rpb, rpb2 = C.c_int(0), C.c_int(0)
+        s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        check(lib.vt_conv3x3_rows_colstats(C.c_void_p(dX.data_ptr()), n, Ci, H, C.c_void_p(dW.data_ptr()), ld, Co,
+                                           C.c_void_p(db.data_ptr()), C.c_void_p(dcol.data_ptr()), C.c_void_p(dC.data_ptr()),
+                                           C.c_void_p(dp.data_ptr()), C.c_void_p(part.data_ptr()), part.numel(), C.byref(rpb), s),
+              "vt_conv3x3_rows_colstats")
+        torch.cuda.synchronize()
+        assert np.array_equal(dcol.cpu().numpy(), col), (n, Ci, H)
+        got = dC.cpu().numpy()
+        assert rel_err(got, want) < 1e-5
+        term = (VtGemmTerm * 1)()
+        term[0] = VtGemmTerm(dcol.data_ptr(), dW.data_ptr(), 0, 0, ld, ld, ld, 1)
+        check(lib.vt_gemm_sum_colstats(0, 1, term, M, Co, 1.0, C.c_void_p(dC2.data_ptr()), Co, 0, C.c_void_p(db.data_ptr()), 1,
+                                       C.c_void_p(dp.data_ptr()), C.c_void_p(part2.data_ptr()), part2.numel(), C.byref(rpb2), s),
+              "vt_gemm_sum_colstats")
+        torch.cuda.synchronize()
+        assert rpb.value == rpb2.value and torch.equal(dC, dC2) and torch.equal(part, part2)
+        rows = rpb.value
+        nb = (M + rows - 1) // rows
+        rec = part.cpu().numpy()[:nb * 2 * Co].reshape(nb, 2, Co)
+        blk = got[(nb - 1) * rows:].astype(np.float64)
+        assert rel_err(rec[nb - 1, 0], blk.sum(0)) < 2e-6
+        assert rel_err(rec[nb - 1, 1], ((blk - blk.mean(0)) ** 2).sum(0)) < 2e-5
+    # image sides that are not a multiple of 16: refused, nothing launched
+    assert lib.vt_conv3x3_rows_colstats(C.c_void_p(dX.data_ptr()), 1, 1, 28, C.c_void_p(dW.data_ptr()), 12, Co,
+                                        None, C.c_void_p(dcol.data_ptr()), C.c_void_p(dC.data_ptr()), None,
+                                        C.c_void_p(part.data_ptr()), part.numel(), C.byref(rpb), s) == -2

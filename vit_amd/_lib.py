@@ -136,6 +136,7 @@ SIGNATURES = {
     "vt_gemm_f32x3": (i, [i, i, i, i, i, f, p, i, C.c_long, p, i, C.c_long, i, p, i, C.c_long, p, i, p, C.c_long, p]),
     "vt_gemm_sum": (i, [i, i, C.POINTER(VtGemmTerm), i, i, f, i, p, i, C.c_long, p, i, p]),
     "vt_set_exact_products": (i, [i]),
+    "vt_conv3x3_rows_colstats": (i, [p, i, i, i, p, i, i, p, p, p, p, p, C.c_long, C.POINTER(C.c_int), p]),
     "vt_gemm_sum_bn_relu_pool": (i, [i, i, C.POINTER(VtGemmTerm), i, i, p, i, p, p, p, i, p, p, p, p]),
     "vt_gemm_sum_colstats": (i, [i, i, C.POINTER(VtGemmTerm), i, i, f, p, i, C.c_long, p, i, p, p, C.c_long, C.POINTER(C.c_int), p]),
     "vt_gemm_bn_apply": (i, [i, i, i, p, i, p, p, p, p, p, i, i, p, p, i, p]),

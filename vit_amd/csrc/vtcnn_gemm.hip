@@ -480,6 +480,10 @@ struct GemmSumP {
   // row-panel kernels built with DZ: term 0's A holds delta records (one pair per row and group of 16 adjacent k:
   // value, k inside the group; every other element of the group zero) and A[m][k] = dz_coef[K + k] + dz_coef[k] * delta
   const float *dz_coef;
+  // AX 4: term 0's A rows are the im2col rows of a 3x3 / stride 1 / pad 1 convolution over im_X [images][im_Ci][im_H][im_H]
+  // (row = image * H * H + h * H + w, column = (ci * 3 + kh) * 3 + kw), gathered on load and written to ax_out
+  const float *im_X;
+  int im_Ci, im_H;
   // row-panel kernels built with AX == 2: term 0's A is a BatchNorm's input, normalised on load,
   //   A'[m][k] = (A[m][k] - ax_stat[k]) * ax_stat[K + k] * ax_gamma[k] + ax_beta[k]
   // (BatchNorm2DLayer::forward's apply, layers/batch_normalization_layer.hpp:292-297), and A' is also written to
@@ -561,7 +565,9 @@ constexpr int PANEL_NMAX = 208, PANEL_LDS_MAX = 160 * 1024;  // result columns (
 // load and written back (GemmSumP::ax_*), 3 delta records whose product never enters the matrix cores: a row's
 // expansion is shift[k] everywhere plus one value per group of 16, so its product with op(B) is a constant row
 // (shift . op(B), formed once per workgroup) plus one scaled row of op(B) per record, added to the tile in fp32 before
-// the epilogue (K0 / 16 rows of op(B) per result row instead of K0)
+// the epilogue (K0 / 16 rows of op(B) per result row instead of K0), 4 the im2col rows of a 3x3 convolution gathered from
+// the images on load and written out for later readers (GemmSumP::im_*; H a multiple of 16, so a 16-row tile is 16
+// neighbouring pixels of one image row; at most two 16-deep steps)
 // EPI: built with the row epilogue GemmSumP::epi (1 or 2); WV: waves per workgroup (sixteen where a copy of op(B) leaves
 // room for one workgroup per compute unit and the kernel fits four waves on a SIMD)
 // GS: 16-deep steps per group (one group is in the matrix cores while the next group's rows of A are in flight; with
@@ -725,8 +731,57 @@ __global__ __launch_bounds__(64 * WV, (AX == 3 || EPI == 4 || WV > 8 || (NT > 8 
   const long wg_row0 = (long)blockIdx.x * rows_per_wg;
   const int ntiles = rows_per_wg / (16 * WV);  // 16-row tiles per wave: tile i of this wave is tile wave + WV i of the workgroup
   auto tile_row0 = [&](int i) { return wg_row0 + (long)(wave + WV * i) * 16; };
+  // AX 4: the lane's eight taps (two steps x four consecutive k): offset from the pixel inside its image, and the
+  // tap's bit in the pixel's mask of the nine window positions that lie inside the image (bit 9, never set, for the
+  // zero columns past 9 Ci); the workgroup's first row as (image, pixel inside it)
+  int tap_off[AX == 4 ? 2 : 1][4], tap_bit[AX == 4 ? 2 : 1][4];
+  int im_img0 = 0, im_rem0 = 0;
+  unsigned im_hmagic = 0;
+  if constexpr (AX == 4) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int k = 16 * e + 4 * g + q, ci = k / 9, r9 = k - 9 * ci, kh = r9 / 3, kw = r9 - 3 * kh;
+        tap_off[e][q] = ci * p.im_H * p.im_H + (kh - 1) * p.im_H + (kw - 1);
+        tap_bit[e][q] = k < 9 * p.im_Ci ? r9 : 9;
+      }
+    const long w0 = (long)blockIdx.x * rows_per_wg;
+    im_img0 = (int)(w0 / (p.im_H * p.im_H));
+    im_rem0 = (int)(w0 - (long)im_img0 * p.im_H * p.im_H);
+    im_hmagic = (unsigned)((1ull << 32) / (unsigned)p.im_H) + 1u;  // n / H = umulhi(n, magic) for n < H * H, H <= 1024
+  }
   auto fetch = [&](long row0, int gi, float4 (&dst)[GS]) {
     const long row = row0 + c;
+    if constexpr (AX == 4) {
+      // the tile's 16 rows are 16 neighbouring pixels of one image row (H % 16 == 0): image and image row are the
+      // wave's, computed once per tile from the workgroup's first row without a division
+      const int H = p.im_H, P = H * H;
+      int rem = __builtin_amdgcn_readfirstlane(im_rem0 + (int)(row0 - wg_row0)), img = im_img0;
+      while (rem >= P) {
+        rem -= P;
+        ++img;
+      }
+      const int h = (int)__umulhi((unsigned)rem, im_hmagic), w = rem - h * H + c;
+      const float *__restrict__ ximg = p.im_X + (long)img * p.im_Ci * P;
+      const int pix = h * H + w;
+      // bit 3 kh + kw: the window position lies inside the image (rows past M: none)
+      const unsigned wm = (w >= 1 ? 1u : 0u) | 2u | (w + 1 < H ? 4u : 0u);
+      const unsigned m9 = row < p.M ? ((h >= 1 ? wm : 0u) | (wm << 3) | (h + 1 < H ? wm << 6 : 0u)) : 0u;
+#pragma unroll
+      for (int e = 0; e < GS; ++e) {
+        float x[4] = {0.f, 0.f, 0.f, 0.f};
+        if (e < 2 && e < nsteps) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const bool ok = (m9 >> tap_bit[e < 2 ? e : 0][q]) & 1u;
+            x[q] = ok ? ximg[pix + tap_off[e < 2 ? e : 0][q]] : 0.f;
+          }
+        }
+        dst[e] = make_float4(x[0], x[1], x[2], x[3]);
+      }
+      return;
+    }
 #pragma unroll
     for (int e = 0; e < GS; ++e) {
       const int si = gi * GS + e;
@@ -805,6 +860,12 @@ __global__ __launch_bounds__(64 * WV, (AX == 3 || EPI == 4 || WV > 8 || (NT > 8 
               if (row < p.M && k < st.K)  // K % 4 == 0 (the operand is 16-byte loadable)
                 *reinterpret_cast<float4 *>(p.ax_out + (st.A - p.t[0].A) + row * st.lda + k) = make_float4(av[0], av[1], av[2], av[3]);
             }
+          }
+          if constexpr (AX == 4) {  // the im2col rows for later readers (the convolution's weight gradient)
+            const long row = row0 + c;
+            const int k = steps[si].k0 + 4 * g;
+            if (row < p.M && k < steps[si].K)
+              *reinterpret_cast<float4 *>(p.ax_out + row * steps[si].lda + k) = make_float4(av[0], av[1], av[2], av[3]);
           }
           if constexpr (AX == 1) {
             if (steps[si].comp) {
@@ -1302,7 +1363,13 @@ static int panel_launch(int form, const GemmSumP &p, int batch, hipStream_t hs, 
     const bool sixteen = lds > 80 * 1024 && wide16;  // decided as for the plain launch
     lds += (size_t)2 * NT * 16 * sizeof(float);  // pivot and bias; the waves' sums reuse op(B)'s space
     if (lds > (size_t)PANEL_LDS_MAX) return 0;
-    if (NT == 4) e = panel_go<0, 4, 0, 4>(grid, lds, hs, p, rows, Kp, nsteps);
+    if (p.im_X) {  // im2col rows gathered from the images
+      if (NT != 4 || form != 0 || p.nterms != 1 || nsteps > 2 || batch != 1 || p.im_H < 16 || p.im_H % 16 != 0 || p.im_H > 1024 ||
+          p.M % (p.im_H * p.im_H) != 0 || p.im_Ci * 9 > p.t[0].K || !p.ax_out || p.t[0].lda % 4 != 0 ||
+          (reinterpret_cast<uintptr_t>(p.ax_out) & 15) != 0)
+        return 0;
+      e = panel_go<0, 4, 4, 4>(grid, lds, hs, p, rows, Kp, nsteps);
+    } else if (NT == 4) e = panel_go<0, 4, 0, 4>(grid, lds, hs, p, rows, Kp, nsteps);
     else if (sixteen) e = panel_go<2, 8, 0, 4, 16>(grid, lds, hs, p, rows, Kp, nsteps);
     else e = panel_go<2, 8, 0, 4>(grid, lds, hs, p, rows, Kp, nsteps);
     if (e == hipSuccess && rows_out) *rows_out = rows;
@@ -1533,6 +1600,23 @@ extern "C" int vt_gemm_sum_colstats(int form, int nterms, const vt_gemm_term *te
   if (!col_part || !rows_per_block) return VT_EINVAL;
   return gemm_sum_launch(form, nterms, terms, M, N, alpha, 0, C, ldc, strideC, bias, batch, col_pivot, col_part,
                          col_part_floats, rows_per_block, s);
+}
+
+extern "C" int vt_conv3x3_rows_colstats(const float *X, int images, int Ci, int H, const float *Wp, int ld, int Co,
+                                       const float *bias, float *col, float *C, const float *col_pivot, float *col_part,
+                                       long col_part_floats, int *rows_per_block, vt_stream s) {
+  if (!X || !Wp || !col || !C || !col_part || !rows_per_block || images < 1 || Ci < 1 || H < 1 || Co < 1 || ld < 9 * Ci)
+    return VT_EINVAL;
+  const long M = (long)images * H * H;
+  if (M >= (1L << 31) || ld % 4 != 0 || (reinterpret_cast<uintptr_t>(Wp) & 15) != 0) return VT_EUNSUPPORTED;
+  GemmSumP p{};
+  GemmTerm &d = p.t[0];
+  d.A = col; d.B = Wp; d.sA = 0; d.sB = 0; d.K = ld; d.lda = ld; d.ldb = ld; d.tb = 1; d.vecA = 1; d.vecB = 1;
+  p.nterms = 1; p.C = C; p.bias = bias; p.M = (int)M; p.N = Co; p.ldc = Co; p.sC = 0; p.alpha = 1.f;
+  p.epi = 4; p.col_part = col_part; p.col_part_floats = col_part_floats; p.col_pivot = col_pivot;
+  p.im_X = X; p.im_Ci = Ci; p.im_H = H; p.ax_out = col;
+  const int took = panel_launch(0, p, 1, (hipStream_t)s, false, false, rows_per_block);
+  return took > 0 ? 0 : took < 0 ? -took : VT_EUNSUPPORTED;
 }
 
 extern "C" int vt_gemm_sum_bn_relu_pool(int form, int nterms, const vt_gemm_term *terms, int H, int N, const float *bias,

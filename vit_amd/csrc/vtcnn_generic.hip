@@ -1306,20 +1306,30 @@ int gen_forward(GenModel *g, const float *arena, const vt_layout *lo, float *are
   // (col and the copy of conv.W that goes with it have rows of cks floats, the columns past CK zero: 16-byte rows, so the
   // product is a row-panel launch, which in training mode also leaves the BatchNorm's partial records)
   const int CKs = g->cks;
-  VTG(im2col(g, X, n, s));
   hipLaunchKernelGGL(k_pad_rows, dim3((C1 * CKs + GT - 1) / GT), dim3(GT), 0, s, W("conv.W"), g->convWp, C1, CK, CKs);
   VT_CHECK_LAUNCH();
   // BatchNorm2DLayer::forward (batch_normalization_layer.hpp:262-298): the only norm that honours eval
   {
     int rc = VT_EUNSUPPORTED, rpb = 0;
-    if (training && NP < (1L << 31)) {
+    // in training mode the product's launch gathers the im2col rows from the images itself where it takes the shape
+    // (and writes them out for the weight gradient), and leaves the BatchNorm's partial records
+    static const bool gather = [] {
+      const char *e = getenv("VT_CONV_GATHER");
+      return !(e && *e == '0');
+    }();
+    if (training && gather)
+      rc = vt_conv3x3_rows_colstats(X, n, g->Ci, g->H, g->convWp, CKs, C1, W("conv.b"), g->col, g->conv, W("bn.running_mean"),
+                                    g->part, g->part_floats, &rpb, (vt_stream)s);
+    if (rc != 0 && rc != VT_EUNSUPPORTED) return rc;
+    if (rc == VT_EUNSUPPORTED) VTG(im2col(g, X, n, s));
+    if (rc == VT_EUNSUPPORTED && training && NP < (1L << 31)) {
       const vt_gemm_term t = {g->col, g->convWp, 0, 0, CKs, CKs, CKs, 1};
       rc = vt_gemm_sum_colstats(0, 1, &t, (int)NP, C1, 1.f, g->conv, C1, 0, W("conv.b"), 1, W("bn.running_mean"), g->part,
                                 g->part_floats, &rpb, (vt_stream)s);
-      if (rc == 0)
-        VTG(vt_bn_stats_finalize(g->part, (int)((NP + rpb - 1) / rpb), C1, rpb, NP, RW("bn.running_mean"), RW("bn.running_var"),
-                                 g->stat_bn, (vt_stream)s));
     }
+    if (rc == 0)
+      VTG(vt_bn_stats_finalize(g->part, (int)((NP + rpb - 1) / rpb), C1, rpb, NP, RW("bn.running_mean"), RW("bn.running_var"),
+                               g->stat_bn, (vt_stream)s));
     if (rc == VT_EUNSUPPORTED) {
       VTG(mm(false, true, (int)NP, C1, CKs, g->col, CKs, g->convWp, CKs, g->conv, C1, W("conv.b")));
       VTG(bn_stats(g, g->conv, NP, C1, RW("bn.running_mean"), RW("bn.running_var"), g->stat_bn, !training, s));
