@@ -156,7 +156,7 @@ def measured_step_traffic(shape, batch, classes):
     """HBM bytes of one whole general-shape training step from the committed PMC passes; None off the measured
     configurations."""
     try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "r03_f_step_hbm_traffic_shapes.json")))
+        t = json.load(open(os.path.join(ROOT, "profiles", "r03_h_step_hbm_traffic_shapes.json")))
         return int(t["steps"]["%s_b%d_k%d" % (shape, batch, classes)]["traffic_bytes"])
     except (OSError, KeyError, ValueError):
         return None

@@ -1759,10 +1759,10 @@ extern "C" int vt_gemm_tn_records(int M, int N, int K, const float *A, int lda, 
     return e && *e == '0';
   }();
   if (!skinny_off && M <= 16 && N == 128 && workspace && K >= 1024 && aligned(rec) && strideRec % 4 == 0) {
-    // at most 16 result rows: the streaming kernel, K cut into slices that leave a few thousand workgroups and fit the
+    // at most 16 result rows: the streaming kernel, K cut into slices that leave several thousand workgroups and fit the
     // workspace
     const long tiles = (K + 15) / 16, per = (long)M * N * batch;
-    long slices = (2048 + batch - 1) / batch;
+    long slices = (8192 + batch - 1) / batch;  // (a workgroup is one wave per SIMD: several rounds of resident workgroups, so that the last round's share is small)
     if (slices > tiles / 8) slices = tiles / 8 > 0 ? tiles / 8 : 1;
     if (slices > workspace_floats / per) slices = workspace_floats / per;
     if (slices >= 1 && slices <= 65535 && batch <= 65535) {

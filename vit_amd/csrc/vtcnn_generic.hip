@@ -783,20 +783,50 @@ __global__ __launch_bounds__(GT) void k_pool_delta(const float *__restrict__ coe
 // positions lie in one row of one window, so at most one of them is not zero: rec[r][q] = (delta, its index inside
 // the group) for row r and channel group q of the row matrix [R, C2], 1/8 of the dense array's bytes.  The
 // products that read the delta expand it on load (vt_gemm_tn_records, vt_gemm_sum_records).  grid (blocks, images).
+// (five divisions by launch constants per record: with the compiler's general sequence they were most of the kernel's
+// instructions; n / d from m = floor(2^32 / d) is at most 2 short, mended by two compares)
+__device__ __forceinline__ unsigned udiv_magic(unsigned n, unsigned d, unsigned m) {
+  unsigned q = __umulhi(n, m), r = n - q * d;
+  if (r >= d) {
+    ++q;
+    r -= d;
+  }
+  return r >= d ? q + 1 : q;
+}
+struct RecordMagic {
+  unsigned ng, P, W, pk;  // floor(2^32 / d) of the four divisors (2^32 - 1 for d = 1)
+};
 __global__ __launch_bounds__(GT) void k_pool_delta_records(const float *__restrict__ dpool, const float *__restrict__ pooled,
                                                            const int *__restrict__ pool_idx, int C2, int P, int W, int pk,
-                                                           float2 *__restrict__ out) {
+                                                           RecordMagic mg, float2 *__restrict__ out) {
   const unsigned ng = C2 / 16, per_image = (unsigned)P * ng;  // records per image; an image is C2 planes of P positions
   const unsigned img = blockIdx.y;
-  for (unsigned i = blockIdx.x * GT + threadIdx.x; i < per_image; i += gridDim.x * GT) {
-    const unsigned r = i / ng, q = i - r * ng;
-    const unsigned F = r * C2 + 16 * q;  // flat position inside the image
-    const unsigned plane = F / P, pos = F - plane * P;
-    const unsigned h = pos / W, w = pos - h * W;
-    const long win = ((long)img * C2 + plane) * 196 + (h / pk) * 14 + w / pk;
-    const unsigned off = (unsigned)(pool_idx[win] - (int)pos);
-    const bool hit = off < 16u && pooled[win] > 0.f;
-    out[(size_t)img * per_image + i] = make_float2(hit ? dpool[win] : 0.f, __int_as_float(hit ? (int)off : 0));
+  // four records per thread, all of their loads in flight before the first store (the launch gives every thread four)
+  for (unsigned i0 = blockIdx.x * GT + threadIdx.x; i0 < per_image; i0 += gridDim.x * GT * 4) {
+    float dp[4], pl[4];
+    int off[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const unsigned i = i0 + u * gridDim.x * GT;
+      dp[u] = pl[u] = 0.f;
+      off[u] = -1;
+      if (i < per_image) {
+        const unsigned r = udiv_magic(i, ng, mg.ng), q = i - r * ng;
+        const unsigned F = r * C2 + 16 * q;  // flat position inside the image
+        const unsigned plane = udiv_magic(F, (unsigned)P, mg.P), pos = F - plane * P;
+        const unsigned h = udiv_magic(pos, (unsigned)W, mg.W), w = pos - h * W;
+        const long win = ((long)img * C2 + plane) * 196 + udiv_magic(h, (unsigned)pk, mg.pk) * 14 + udiv_magic(w, (unsigned)pk, mg.pk);
+        off[u] = pool_idx[win] - (int)pos;
+        pl[u] = pooled[win];
+        dp[u] = dpool[win];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const unsigned i = i0 + u * gridDim.x * GT;
+      const bool hit = (unsigned)off[u] < 16u && pl[u] > 0.f;
+      if (i < per_image) out[(size_t)img * per_image + i] = make_float2(hit ? dp[u] : 0.f, __int_as_float(hit ? off[u] : 0));
+    }
   }
 }
 
@@ -1106,8 +1136,10 @@ int pool_bn_backward(vt::GenModel *g, const float *gamma, float *ggamma, float *
   VTG(bn_din_colsum(gamma, g->stat_pn, g->z, ggamma, C2, din_colsum, s));
   if (delta_records(g) && n <= 65535) {
     const unsigned per_image = (unsigned)g->P * (C2 / 16);
+    auto magic = [](unsigned d) { return d <= 1 ? 0xFFFFFFFFu : (unsigned)((1ull << 32) / d); };
+    const RecordMagic mg{magic((unsigned)C2 / 16), magic((unsigned)g->P), magic((unsigned)g->H), magic((unsigned)g->pk)};
     hipLaunchKernelGGL(k_pool_delta_records, dim3((per_image + 4 * GT - 1) / (4 * GT), n), dim3(GT), 0, s, g->dpool, g->pooled,
-                       g->pool_idx, C2, g->P, g->H, g->pk, reinterpret_cast<float2 *>(g->dzr));
+                       g->pool_idx, C2, g->P, g->H, g->pk, mg, reinterpret_cast<float2 *>(g->dzr));
     VT_CHECK_LAUNCH();
     g->dz_valid = 0;
     return 0;
