@@ -142,6 +142,10 @@ def test_gemm_sum_of_products(form, tol):
         (2300, 128, 2, (64, 196), (0, 0), (1, 0), True, False),  # the wide projector output: more than 64 KB of LDS
         (2300, 200, 1, (128, 36), (1, 0), (0, 1), False, True),
     ])
+    _sum_cases(form, tol, [
+        # deep, narrow, many rows, op(B) beyond a compute unit's LDS: the tiled kernel with 128-row tiles
+        (2100, 64, 128, (208, 208, 208), (1, 0, 1), (1, 1, 0), True, False),
+    ])
     # argument checks
     bad = (VtGemmTerm * 1)()
     import torch

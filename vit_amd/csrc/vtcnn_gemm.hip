@@ -568,8 +568,10 @@ constexpr int PANEL_NMAX = 208, PANEL_LDS_MAX = 160 * 1024;  // result columns (
 // the epilogue (K0 / 16 rows of op(B) per result row instead of K0), 4 the im2col rows of a 3x3 convolution gathered from
 // the images on load and written out for later readers (GemmSumP::im_*; H a multiple of 16, so a 16-row tile is 16
 // neighbouring pixels of one image row; at most two 16-deep steps)
-// EPI: built with the row epilogue GemmSumP::epi (1 or 2); WV: waves per workgroup (sixteen where a copy of op(B) leaves
-// room for one workgroup per compute unit and the kernel fits four waves on a SIMD)
+// EPI: built with the epilogue GemmSumP::epi: 1 row softmax, 2 row softmax backward, 3 per-tile records of a softmax
+// over the ROW axis, 4 BatchNorm partial records of the result's columns (operands swapped: a lane owns a column),
+// 5 BatchNorm apply + ReLU + 16 x 16 max-pool instead of storing; WV: waves per workgroup (sixteen where a copy of op(B)
+// leaves room for one workgroup per compute unit and the kernel fits four waves on a SIMD)
 // GS: 16-deep steps per group (one group is in the matrix cores while the next group's rows of A are in flight; with
 // nsteps <= GS the whole next tile is in flight during a tile)
 template <int PR, int NT, int AX = 0, int EPI = 0, int WV = PANEL_W, int GS = 4>
@@ -1570,6 +1572,8 @@ static int gemm_sum_launch(int form, int nterms, const vt_gemm_term *terms, int 
   if (N > 64) {
     BN = 128;
     if (ktot >= 128 && M >= 128 && (long)((M + 127) / 128) * ((N + 127) / 128) * batch >= 512) BM = 128;
+  } else if (N > 32 && ktot >= 256 && (long)((M + 127) / 128) * batch >= 2048) {
+    BM = 128;  // a deep sum into a narrow result: 128 rows per workgroup halve the barriers and the reads of op(B) per row
   }
   if (batch > 65535 || (N + BN - 1) / BN > 65535) return VT_EUNSUPPORTED;
   const dim3 grid((M + BM - 1) / BM, (N + BN - 1) / BN, (unsigned)batch);
@@ -1577,7 +1581,8 @@ static int gemm_sum_launch(int form, int nterms, const vt_gemm_term *terms, int 
   hipStream_t hs = (hipStream_t)s;
 #define VT_SUM_LAUNCH(PR_)                                                                               \
   do {                                                                                                   \
-    if (BM == 128) hipLaunchKernelGGL((k_gemm_sum<PR_, 128, 128>), grid, dim3(256), 0, hs, p);          \
+    if (BM == 128 && BN == 64) hipLaunchKernelGGL((k_gemm_sum<PR_, 128, 64>), grid, dim3(256), 0, hs, p); \
+    else if (BM == 128) hipLaunchKernelGGL((k_gemm_sum<PR_, 128, 128>), grid, dim3(256), 0, hs, p);      \
     else if (BN == 128) hipLaunchKernelGGL((k_gemm_sum<PR_, 64, 128>), grid, dim3(256), 0, hs, p);       \
     else hipLaunchKernelGGL((k_gemm_sum<PR_, 64, 64>), grid, dim3(256), 0, hs, p);                       \
   } while (0)
